@@ -1,0 +1,81 @@
+// common.h -- shared host/device helpers of the MI355X graph library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/mi355x_graph.h"
+
+namespace mgx {
+
+constexpr int kWave = 64;          // CDNA4 wavefront
+constexpr int kBlock = 256;        // 4 waves / workgroup: one per SIMD
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with its own 4 MiB L2
+
+void set_error(const char* fmt, ...);
+
+#define MGX_CHECK_ARG(cond, ...)                    \
+  do {                                              \
+    if (!(cond)) {                                  \
+      ::mgx::set_error(__VA_ARGS__);                \
+      return MGX_ERR_INVALID_ARGUMENT;              \
+    }                                               \
+  } while (0)
+
+#define MGX_UNSUPPORTED(...)                        \
+  do {                                              \
+    ::mgx::set_error(__VA_ARGS__);                  \
+    return MGX_ERR_UNSUPPORTED;                     \
+  } while (0)
+
+#define MGX_CHECK_HIP(expr)                                                         \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      ::mgx::set_error("HIP error %d (%s) at %s:%d", (int)e_, hipGetErrorString(e_), \
+                       __FILE__, __LINE__);                                         \
+      return MGX_ERR_HIP;                                                           \
+    }                                                                               \
+  } while (0)
+
+// Called after every kernel launch: reports launch-configuration errors without synchronising.
+#define MGX_CHECK_LAUNCH() MGX_CHECK_HIP(hipGetLastError())
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<2> { typedef v2f type; };
+template <> struct VecT<4> { typedef v4f type; };
+
+// Blocks b and b+8 are observed to land on the same XCD (round-robin dispatch).  Give each XCD a
+// CONTIGUOUS range of logical blocks so that neighbouring destination rows -- which share
+// source rows on graphs with locality -- hit the same 4 MiB L2.  Speed only, never correctness.
+// `nb` must be a multiple of kXcds.
+__device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
+  return (b % kXcds) * (nb / kXcds) + (b / kXcds);
+}
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int ilog2_ceil(int64_t x) { int l = 0; while ((int64_t(1) << l) < x) ++l; return l; }
+
+template <typename T>
+__device__ __forceinline__ T wave_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, kWave); }
+
+template <int VEC>
+__device__ __forceinline__ typename VecT<VEC>::type vec_shfl_xor(typename VecT<VEC>::type v, int mask);
+template <> __device__ __forceinline__ float vec_shfl_xor<1>(float v, int mask) { return __shfl_xor(v, mask, kWave); }
+template <> __device__ __forceinline__ v2f vec_shfl_xor<2>(v2f v, int mask) {
+  v2f r; r.x = __shfl_xor(v.x, mask, kWave); r.y = __shfl_xor(v.y, mask, kWave); return r;
+}
+template <> __device__ __forceinline__ v4f vec_shfl_xor<4>(v4f v, int mask) {
+  v4f r;
+  r.x = __shfl_xor(v.x, mask, kWave); r.y = __shfl_xor(v.y, mask, kWave);
+  r.z = __shfl_xor(v.z, mask, kWave); r.w = __shfl_xor(v.w, mask, kWave);
+  return r;
+}
+
+}  // namespace mgx

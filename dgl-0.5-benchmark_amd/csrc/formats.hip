@@ -1,0 +1,146 @@
+// formats.hip -- integer graph-format work on the device (bit-exact): stable COO->CSR, degrees.
+//
+// Replaces DGL's lazy COOToCSR / in_degrees behind g.formats(...) and the first kernel call
+// (main_dgl_product_sage.py:158, kernel/dgl-new.py:63, main_dgl_molhiv_gcn.py:41).
+// The sort is a one-off per graph (outside the timed epochs, like the reference's cold-start
+// reps) so it uses rocPRIM's stable LSD radix sort; the row pointer comes from a lower-bound
+// search over the sorted keys and the column gather is a coalesced pass.
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace mgx {
+
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void iota_kernel(Idx* out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) out[i] = (Idx)i;
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void indptr_kernel(const Idx* sorted_rows, int64_t nnz, int64_t n_rows, Idx* indptr) {
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r <= n_rows; r += (int64_t)gridDim.x * kBlock) {
+    int64_t lo = 0, hi = nnz;  // first position whose row >= r
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)sorted_rows[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    indptr[r] = (Idx)lo;
+  }
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void gather_cols_kernel(const Idx* col, const Idx* eids, int64_t nnz, Idx* indices) {
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * kBlock)
+    indices[p] = col[eids[p]];
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void degrees_kernel(const Idx* indptr, int64_t n, Idx* deg, float* inv) {
+  for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < n; v += (int64_t)gridDim.x * kBlock) {
+    const Idx d = indptr[v + 1] - indptr[v];
+    if (deg) deg[v] = d;
+    if (inv) inv[v] = 1.0f / (float)(d > 1 ? d : 1);
+  }
+}
+
+static inline unsigned grid_for(int64_t n) {
+  int64_t b = (n + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > 256 * 32) b = 256 * 32;
+  return (unsigned)b;
+}
+
+static inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+template <typename Idx>
+static hipError_t sort_temp_bytes(int64_t nnz, int end_bit, size_t* bytes) {
+  *bytes = 0;
+  return rocprim::radix_sort_pairs<rocprim::default_config, const Idx*, Idx*, const Idx*, Idx*>(
+      nullptr, *bytes, nullptr, nullptr, nullptr, nullptr, (size_t)nnz, 0, end_bit, nullptr, false);
+}
+
+template <typename Idx>
+static int32_t coo_to_csr_impl(int64_t n_rows, int64_t nnz, const Idx* row, const Idx* col, Idx* indptr, Idx* indices,
+                               Idx* eids, void* ws, int64_t ws_bytes, hipStream_t s) {
+  if (nnz == 0) {
+    MGX_CHECK_HIP(hipMemsetAsync(indptr, 0, sizeof(Idx) * (n_rows + 1), s));
+    return MGX_OK;
+  }
+  const int end_bit = ilog2_ceil(n_rows > 1 ? n_rows : 2);
+  size_t temp = 0;
+  MGX_CHECK_HIP(sort_temp_bytes<Idx>(nnz, end_bit, &temp));
+  const size_t arr = align256(sizeof(Idx) * (size_t)nnz);
+  MGX_CHECK_ARG((size_t)ws_bytes >= 2 * arr + temp, "mgx_coo_to_csr: workspace too small (%lld < %lld)",
+                (long long)ws_bytes, (long long)(2 * arr + temp));
+  Idx* keys_out = (Idx*)ws;
+  Idx* iota = (Idx*)((char*)ws + arr);
+  void* tmp = (char*)ws + 2 * arr;
+  hipLaunchKernelGGL((iota_kernel<Idx>), dim3(grid_for(nnz)), dim3(kBlock), 0, s, iota, nnz);
+  MGX_CHECK_LAUNCH();
+  MGX_CHECK_HIP((rocprim::radix_sort_pairs<rocprim::default_config, const Idx*, Idx*, const Idx*, Idx*>(
+      tmp, temp, row, keys_out, (const Idx*)iota, eids, (size_t)nnz, 0, end_bit, s, false)));
+  hipLaunchKernelGGL((indptr_kernel<Idx>), dim3(grid_for(n_rows + 1)), dim3(kBlock), 0, s, (const Idx*)keys_out, nnz, n_rows, indptr);
+  MGX_CHECK_LAUNCH();
+  hipLaunchKernelGGL((gather_cols_kernel<Idx>), dim3(grid_for(nnz)), dim3(kBlock), 0, s, col, (const Idx*)eids, nnz, indices);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+}  // namespace mgx
+
+extern "C" int64_t mgx_coo_to_csr_workspace(int64_t num_rows, int64_t nnz, int32_t idx_bits) {
+  using namespace mgx;
+  if (nnz <= 0) return 0;
+  const int end_bit = ilog2_ceil(num_rows > 1 ? num_rows : 2);
+  size_t temp = 0;
+  hipError_t e = idx_bits == 32 ? sort_temp_bytes<int32_t>(nnz, end_bit, &temp) : sort_temp_bytes<int64_t>(nnz, end_bit, &temp);
+  if (e != hipSuccess) {
+    set_error("mgx_coo_to_csr_workspace: rocPRIM size query failed: %s", hipGetErrorString(e));
+    return -1;
+  }
+  const size_t arr = align256((size_t)(idx_bits / 8) * (size_t)nnz);
+  return (int64_t)(2 * arr + temp);
+}
+
+extern "C" int32_t mgx_coo_to_csr(int64_t num_rows, int64_t nnz, const void* row, const void* col, int32_t idx_bits,
+                                  void* indptr, void* indices, void* eids, void* workspace, int64_t workspace_bytes,
+                                  void* stream) {
+  using namespace mgx;
+  MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_coo_to_csr: idx_bits must be 32 or 64");
+  MGX_CHECK_ARG(num_rows >= 0 && nnz >= 0, "mgx_coo_to_csr: negative sizes");
+  MGX_CHECK_ARG(indptr != nullptr, "mgx_coo_to_csr: indptr is NULL");
+  MGX_CHECK_ARG(nnz == 0 || (row && col && indices && eids && workspace), "mgx_coo_to_csr: NULL pointer");
+  MGX_CHECK_ARG(idx_bits == 64 || (nnz < (int64_t(1) << 31) && num_rows < (int64_t(1) << 31)), "mgx_coo_to_csr: sizes overflow int32");
+  if (idx_bits == 32)
+    return coo_to_csr_impl<int32_t>(num_rows, nnz, (const int32_t*)row, (const int32_t*)col, (int32_t*)indptr,
+                                    (int32_t*)indices, (int32_t*)eids, workspace, workspace_bytes, (hipStream_t)stream);
+  return coo_to_csr_impl<int64_t>(num_rows, nnz, (const int64_t*)row, (const int64_t*)col, (int64_t*)indptr,
+                                  (int64_t*)indices, (int64_t*)eids, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int32_t mgx_csr_degrees(int64_t num_rows, const void* indptr, int32_t idx_bits, void* deg, void* stream) {
+  using namespace mgx;
+  MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_csr_degrees: idx_bits must be 32 or 64");
+  MGX_CHECK_ARG(num_rows >= 0, "mgx_csr_degrees: negative size");
+  if (num_rows == 0) return MGX_OK;
+  MGX_CHECK_ARG(indptr && deg, "mgx_csr_degrees: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (idx_bits == 32) hipLaunchKernelGGL((degrees_kernel<int32_t>), dim3(grid_for(num_rows)), dim3(kBlock), 0, s, (const int32_t*)indptr, num_rows, (int32_t*)deg, (float*)nullptr);
+  else hipLaunchKernelGGL((degrees_kernel<int64_t>), dim3(grid_for(num_rows)), dim3(kBlock), 0, s, (const int64_t*)indptr, num_rows, (int64_t*)deg, (float*)nullptr);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_csr_inv_degrees(int64_t num_rows, const void* indptr, int32_t idx_bits, float* inv_deg, void* stream) {
+  using namespace mgx;
+  MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_csr_inv_degrees: idx_bits must be 32 or 64");
+  MGX_CHECK_ARG(num_rows >= 0, "mgx_csr_inv_degrees: negative size");
+  if (num_rows == 0) return MGX_OK;
+  MGX_CHECK_ARG(indptr && inv_deg, "mgx_csr_inv_degrees: NULL pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (idx_bits == 32) hipLaunchKernelGGL((degrees_kernel<int32_t>), dim3(grid_for(num_rows)), dim3(kBlock), 0, s, (const int32_t*)indptr, num_rows, (int32_t*)nullptr, inv_deg);
+  else hipLaunchKernelGGL((degrees_kernel<int64_t>), dim3(grid_for(num_rows)), dim3(kBlock), 0, s, (const int64_t*)indptr, num_rows, (int64_t*)nullptr, inv_deg);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}

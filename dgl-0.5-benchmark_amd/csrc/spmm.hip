@@ -1,0 +1,328 @@
+// spmm.hip -- g-SpMM for gfx950 (MI355X): CSR row-segmented wavefront reductions.
+//
+// Replaces what DGL's _CAPI_DGLKernelSpMM executes for the reference call sites
+//   kernel/dgl-new.py:20, main_dgl_product_sage.py:62, main_dgl_reddit_gat.py:10 (GATConv),
+//   main_dgl_proteins_rgcn_for.py:52, main_dgl_molhiv_gcn.py:46.
+//
+// Design (HBM/gather-bound integer+fp32 work; no MFMA):
+//   * one 64-lane wavefront walks one destination row (SPLIT) or 64/G rows (one per lane group);
+//   * lanes run ALONG THE FEATURE DIMENSION: a group of G lanes covers one neighbour's feature
+//     row with 16-byte (VEC=4) loads, so each gathered row is read as whole 64..1024-byte
+//     contiguous segments; 64/G neighbour rows are fetched by ONE wave-instruction and UNROLL
+//     instructions are kept in flight (8..64 rows = 4..8 KiB per wave) to cover HBM latency;
+//   * fp32 accumulation in registers, cross-group combine by xor-shuffles, one coalesced store;
+//     no atomics => bitwise reproducible for a given graph;
+//   * blockIdx is remapped so each XCD (own L2) owns a contiguous range of destination rows.
+#include "common.h"
+
+namespace mgx {
+
+enum { MODE_COPY_LHS = 0, MODE_MUL_EDGE = 1, MODE_COPY_RHS = 2 };
+
+constexpr int kRowsPerBlock = 64;
+
+template <typename Idx>
+struct SpmmFastArgs {
+  const Idx* indptr;
+  const Idx* indices;
+  const Idx* eids;
+  const float* src;        // gathered matrix: U (copy_lhs, mul) or E (copy_rhs)
+  const float* w;          // MODE_MUL_EDGE: [num_edges, H] weights addressed by edge id
+  const float* src_scale;  // optional, per gathered row
+  const float* dst_scale;  // optional, per output row
+  float* out;
+  int64_t n_rows;
+  int64_t nblocks;  // logical blocks, multiple of kXcds
+  int D;            // elements per feature row
+  int H;            // heads of w
+  int F;            // D / H
+  int mean;
+};
+
+template <int G, bool SPLIT>
+struct Unroll {
+  static constexpr int NB = kWave / G;
+  static constexpr int value = SPLIT ? (NB >= 32 ? 1 : (NB >= 8 ? 2 : (NB >= 2 ? 4 : 8))) : (G >= 8 ? 4 : 2);
+};
+
+template <typename Idx, int VEC, int G, int MODE, bool SPLIT>
+__global__ __launch_bounds__(kBlock) void spmm_fast_kernel(const SpmmFastArgs<Idx> a) {
+  typedef typename VecT<VEC>::type V;
+  constexpr int NB = kWave / G;
+  constexpr int UNROLL = Unroll<G, SPLIT>::value;
+  constexpr int ROWS_PER_STEP = SPLIT ? 1 : NB;
+  constexpr int STEP = SPLIT ? NB : 1;
+
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int sub = lane / G;
+  const int l = lane % G;
+  const int f = (blockIdx.y * G + l) * VEC;
+  const bool factive = f < a.D;
+  const int head = (MODE == MODE_MUL_EDGE && factive) ? f / a.F : 0;
+  const int64_t row_base = xcd_remap(blockIdx.x, a.nblocks) * kRowsPerBlock;
+  const int64_t D = a.D;
+
+  for (int r = wave * ROWS_PER_STEP; r < kRowsPerBlock; r += kWavesPerBlock * ROWS_PER_STEP) {
+    if (row_base + r >= a.n_rows) break;  // wave-uniform
+    const int64_t row = row_base + r + (SPLIT ? 0 : sub);
+    const bool ractive = row < a.n_rows;
+    int64_t beg = 0, end = 0;
+    if (ractive) {
+      beg = (int64_t)a.indptr[row];
+      end = (int64_t)a.indptr[row + 1];
+    }
+    V acc = (V)(0.f);
+    for (int64_t p = beg + (SPLIT ? sub : 0); p < end; p += (int64_t)STEP * UNROLL) {
+      int64_t nbr[UNROLL];
+      float wgt[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int64_t q = p + (int64_t)u * STEP;
+        nbr[u] = -1;
+        wgt[u] = 1.f;
+        if (q < end) {
+          if (MODE == MODE_COPY_RHS) {
+            nbr[u] = a.eids ? (int64_t)a.eids[q] : q;
+          } else {
+            nbr[u] = (int64_t)a.indices[q];
+            if (MODE == MODE_MUL_EDGE) {
+              const int64_t e = a.eids ? (int64_t)a.eids[q] : q;
+              wgt[u] = a.w[e * a.H + head];
+            }
+          }
+        }
+      }
+      if (a.src_scale) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+          if (nbr[u] >= 0) wgt[u] *= a.src_scale[nbr[u]];
+      }
+      V val[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        val[u] = (V)(0.f);
+        if (nbr[u] >= 0 && factive) val[u] = *reinterpret_cast<const V*>(a.src + nbr[u] * D + f);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        if (MODE == MODE_MUL_EDGE) acc += val[u] * wgt[u];
+        else if (a.src_scale) acc += val[u] * wgt[u];
+        else acc += val[u];
+      }
+    }
+    if (SPLIT) {
+#pragma unroll
+      for (int off = G; off < kWave; off <<= 1) acc += vec_shfl_xor<VEC>(acc, off);
+    }
+    if (ractive && factive && (!SPLIT || sub == 0)) {
+      if (a.mean) {
+        const int64_t deg = end - beg;
+        acc = acc / (float)(deg > 1 ? deg : 1);
+      }
+      if (a.dst_scale) acc = acc * a.dst_scale[row];
+      *reinterpret_cast<V*>(a.out + row * D + f) = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel: any op x any reduce x arbitrary broadcast tables.  One wave per row, lanes over
+// output elements, serial over the row's edges (storage order => same order as the CPU oracle).
+template <typename Idx>
+struct SpmmGenericArgs {
+  const Idx* indptr;
+  const Idx* indices;
+  const Idx* eids;
+  const float* U;
+  const float* E;
+  const int64_t* u_off;
+  const int64_t* e_off;
+  const float* src_scale;
+  const float* dst_scale;
+  float* out;
+  Idx* arg_u;
+  Idx* arg_e;
+  int64_t n_rows;
+  int64_t nblocks;
+  int64_t u_len, e_len, out_len;
+  int op, reduce;
+};
+
+__device__ __forceinline__ float apply_op(int op, float l, float r) {
+  switch (op) {
+    case MGX_OP_ADD: return l + r;
+    case MGX_OP_SUB: return l - r;
+    case MGX_OP_MUL: return l * r;
+    case MGX_OP_DIV: return l / r;
+    case MGX_OP_COPY_LHS: return l;
+    default: return r;
+  }
+}
+
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void spmm_generic_kernel(const SpmmGenericArgs<Idx> a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int64_t row_base = xcd_remap(blockIdx.x, a.nblocks) * kRowsPerBlock;
+  for (int r = wave; r < kRowsPerBlock; r += kWavesPerBlock) {
+    const int64_t row = row_base + r;
+    if (row >= a.n_rows) break;
+    const int64_t beg = (int64_t)a.indptr[row], end = (int64_t)a.indptr[row + 1];
+    for (int64_t k = lane; k < a.out_len; k += kWave) {
+      // NULL table: identity, or head-wise broadcast when the operand row is shorter than the output row
+      const int64_t uo = !a.U ? 0 : a.u_off ? a.u_off[k] : (a.u_len == a.out_len ? k : k / (a.out_len / a.u_len));
+      const int64_t eo = !a.E ? 0 : a.e_off ? a.e_off[k] : (a.e_len == a.out_len ? k : k / (a.out_len / a.e_len));
+      float acc = a.reduce == MGX_REDUCE_MAX ? -INFINITY : (a.reduce == MGX_REDUCE_MIN ? INFINITY : 0.f);
+      int64_t bu = -1, be = -1;
+      for (int64_t p = beg; p < end; ++p) {
+        const int64_t u = a.indices ? (int64_t)a.indices[p] : 0;
+        const int64_t e = a.eids ? (int64_t)a.eids[p] : p;
+        float lv = a.U ? a.U[u * a.u_len + uo] : 0.f;
+        if (a.src_scale) lv *= a.src_scale[u];
+        const float rv = a.E ? a.E[e * a.e_len + eo] : 0.f;
+        const float val = apply_op(a.op, lv, rv);
+        if (a.reduce == MGX_REDUCE_MAX) {
+          if (val > acc) { acc = val; bu = u; be = e; }
+        } else if (a.reduce == MGX_REDUCE_MIN) {
+          if (val < acc) { acc = val; bu = u; be = e; }
+        } else {
+          acc += val;
+        }
+      }
+      if (a.reduce == MGX_REDUCE_MAX || a.reduce == MGX_REDUCE_MIN) {
+        if (beg == end) acc = 0.f;
+        if (a.arg_u) a.arg_u[row * a.out_len + k] = (Idx)bu;
+        if (a.arg_e) a.arg_e[row * a.out_len + k] = (Idx)be;
+      } else if (a.reduce == MGX_REDUCE_MEAN) {
+        const int64_t deg = end - beg;
+        acc = acc / (float)(deg > 1 ? deg : 1);
+      }
+      if (a.dst_scale) acc *= a.dst_scale[row];
+      a.out[row * a.out_len + k] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename Idx, int VEC, int G, int MODE>
+static void launch_fast_g(const SpmmFastArgs<Idx>& a, bool split, hipStream_t s) {
+  dim3 grid((unsigned)a.nblocks, (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
+  if (split) hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, true>), grid, dim3(kBlock), 0, s, a);
+  else hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, false>), grid, dim3(kBlock), 0, s, a);
+}
+
+template <typename Idx, int VEC, int MODE>
+static void launch_fast_v(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) {
+  const int lanes = (a.D + VEC - 1) / VEC;
+  int G = 1;
+  while (G < lanes && G < kWave) G <<= 1;
+  const int NB = kWave / G;
+  const double avg_deg = a.n_rows > 0 ? (double)nnz / (double)a.n_rows : 0.0;
+  // One row per wave when rows are long enough to feed all NB lane groups, else one row per group.
+  const bool split = (NB == 1) || (avg_deg >= 2.0 * NB);
+  switch (G) {
+    case 1: launch_fast_g<Idx, VEC, 1, MODE>(a, split, s); break;
+    case 2: launch_fast_g<Idx, VEC, 2, MODE>(a, split, s); break;
+    case 4: launch_fast_g<Idx, VEC, 4, MODE>(a, split, s); break;
+    case 8: launch_fast_g<Idx, VEC, 8, MODE>(a, split, s); break;
+    case 16: launch_fast_g<Idx, VEC, 16, MODE>(a, split, s); break;
+    case 32: launch_fast_g<Idx, VEC, 32, MODE>(a, split, s); break;
+    default: launch_fast_g<Idx, VEC, 64, MODE>(a, split, s); break;
+  }
+}
+
+template <typename Idx, int MODE>
+static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) {
+  const bool al16 = ((uintptr_t)a.src % 16 == 0) && ((uintptr_t)a.out % 16 == 0);
+  const bool al8 = ((uintptr_t)a.src % 8 == 0) && ((uintptr_t)a.out % 8 == 0);
+  // MODE_MUL_EDGE needs every lane's VEC features inside one head: F % VEC == 0.
+  const int vec_ok = (MODE == MODE_MUL_EDGE) ? a.F : a.D;
+  if (a.D % 4 == 0 && vec_ok % 4 == 0 && al16) launch_fast_v<Idx, 4, MODE>(a, nnz, s);
+  else if (a.D % 2 == 0 && vec_ok % 2 == 0 && al8) launch_fast_v<Idx, 2, MODE>(a, nnz, s);
+  else launch_fast_v<Idx, 1, MODE>(a, nnz, s);
+}
+
+template <typename Idx>
+static int32_t spmm_impl(const mgx_csr* csr, int32_t op, int32_t reduce, const float* U, const float* E,
+                         int64_t u_len, int64_t e_len, int64_t out_len, const int64_t* u_off,
+                         const int64_t* e_off, const float* src_scale, const float* dst_scale, float* out,
+                         void* arg_u, void* arg_e, hipStream_t s) {
+  const int64_t n_rows = csr->num_rows;
+  if (n_rows == 0 || out_len == 0) return MGX_OK;
+  const int64_t nblocks = round_up((n_rows + kRowsPerBlock - 1) / kRowsPerBlock, kXcds);
+  MGX_CHECK_ARG(nblocks < (int64_t(1) << 31), "mgx_spmm_csr: too many rows (%lld)", (long long)n_rows);
+  const bool summing = reduce == MGX_REDUCE_SUM || reduce == MGX_REDUCE_MEAN;
+  const bool no_bcast = !u_off && !e_off;
+
+  // ---- fast paths ------------------------------------------------------------------------
+  if (summing && out_len < (int64_t(1) << 30)) {
+    SpmmFastArgs<Idx> a;
+    a.indptr = (const Idx*)csr->indptr; a.indices = (const Idx*)csr->indices; a.eids = (const Idx*)csr->eids;
+    a.w = nullptr; a.src_scale = src_scale; a.dst_scale = dst_scale; a.out = out;
+    a.n_rows = n_rows; a.nblocks = nblocks; a.D = (int)out_len; a.H = 1; a.F = (int)out_len;
+    a.mean = reduce == MGX_REDUCE_MEAN;
+    if (op == MGX_OP_COPY_LHS && no_bcast && u_len == out_len) {
+      a.src = U;
+      launch_fast<Idx, MODE_COPY_LHS>(a, csr->nnz, s);
+      MGX_CHECK_LAUNCH();
+      return MGX_OK;
+    }
+    if (op == MGX_OP_COPY_RHS && no_bcast && e_len == out_len && !src_scale) {
+      a.src = E;
+      launch_fast<Idx, MODE_COPY_RHS>(a, csr->nnz, s);
+      MGX_CHECK_LAUNCH();
+      return MGX_OK;
+    }
+    // u_mul_e with one weight per (edge, head): U (N,H,F) x E (E,H,1); also (N,D) x (E,1).
+    // ABI rule: a NULL offset table with e_len < out_len means head-wise broadcast, k -> k / (out_len/e_len).
+    if (op == MGX_OP_MUL && u_len == out_len && no_bcast && e_len >= 1 && out_len % e_len == 0) {
+      a.src = U; a.w = E; a.H = (int)e_len; a.F = (int)(out_len / e_len);
+      launch_fast<Idx, MODE_MUL_EDGE>(a, csr->nnz, s);
+      MGX_CHECK_LAUNCH();
+      return MGX_OK;
+    }
+  }
+
+  // ---- generic ---------------------------------------------------------------------------
+  SpmmGenericArgs<Idx> g;
+  g.indptr = (const Idx*)csr->indptr; g.indices = (const Idx*)csr->indices; g.eids = (const Idx*)csr->eids;
+  g.U = (op == MGX_OP_COPY_RHS) ? nullptr : U;
+  g.E = (op == MGX_OP_COPY_LHS) ? nullptr : E;
+  g.u_off = u_off; g.e_off = e_off; g.src_scale = src_scale; g.dst_scale = dst_scale; g.out = out;
+  g.arg_u = (Idx*)arg_u; g.arg_e = (Idx*)arg_e; g.n_rows = n_rows; g.nblocks = nblocks;
+  g.u_len = u_len; g.e_len = e_len; g.out_len = out_len; g.op = op; g.reduce = reduce;
+  hipLaunchKernelGGL((spmm_generic_kernel<Idx>), dim3((unsigned)nblocks), dim3(kBlock), 0, s, g);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+}  // namespace mgx
+
+extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, int32_t op, int32_t reduce, const float* ufeat,
+                                const float* efeat, int64_t u_len, int64_t e_len, int64_t out_len,
+                                const int64_t* u_off, const int64_t* e_off, const float* src_scale,
+                                const float* dst_scale, float* out, void* arg_u, void* arg_e, void* stream) {
+  using namespace mgx;
+  MGX_CHECK_ARG(csr != nullptr, "mgx_spmm_csr: csr is NULL");
+  MGX_CHECK_ARG(csr->idx_bits == 32 || csr->idx_bits == 64, "mgx_spmm_csr: idx_bits must be 32 or 64, got %d", csr->idx_bits);
+  MGX_CHECK_ARG(csr->num_rows >= 0 && csr->nnz >= 0, "mgx_spmm_csr: negative sizes");
+  MGX_CHECK_ARG(csr->num_rows == 0 || csr->indptr != nullptr, "mgx_spmm_csr: indptr is NULL");
+  MGX_CHECK_ARG(csr->nnz == 0 || csr->indices != nullptr || op == MGX_OP_COPY_RHS, "mgx_spmm_csr: indices is NULL");
+  MGX_CHECK_ARG(op == MGX_OP_ADD || op == MGX_OP_MUL || op == MGX_OP_COPY_LHS || op == MGX_OP_COPY_RHS ||
+                    op == MGX_OP_SUB || op == MGX_OP_DIV,
+                "mgx_spmm_csr: unsupported binary op %d", op);
+  MGX_CHECK_ARG(reduce >= MGX_REDUCE_SUM && reduce <= MGX_REDUCE_MEAN, "mgx_spmm_csr: unsupported reduce op %d", reduce);
+  MGX_CHECK_ARG(op == MGX_OP_COPY_RHS || ufeat != nullptr || csr->num_cols == 0, "mgx_spmm_csr: op needs ufeat");
+  MGX_CHECK_ARG(op == MGX_OP_COPY_LHS || efeat != nullptr || csr->nnz == 0, "mgx_spmm_csr: op needs efeat");
+  MGX_CHECK_ARG(out != nullptr || csr->num_rows == 0 || out_len == 0, "mgx_spmm_csr: out is NULL");
+  MGX_CHECK_ARG(out_len >= 0 && u_len >= 0 && e_len >= 0, "mgx_spmm_csr: negative feature length");
+  const bool cmp = reduce == MGX_REDUCE_MAX || reduce == MGX_REDUCE_MIN;
+  MGX_CHECK_ARG(!cmp || (!src_scale && !dst_scale), "mgx_spmm_csr: src/dst scale only with SUM/MEAN");
+  hipStream_t s = (hipStream_t)stream;
+  if (csr->idx_bits == 32)
+    return spmm_impl<int32_t>(csr, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
+                              dst_scale, out, arg_u, arg_e, s);
+  return spmm_impl<int64_t>(csr, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
+                            dst_scale, out, arg_u, arg_e, s);
+}

@@ -1,0 +1,11 @@
+"""mi355x_graph -- MI355X-native sparse message passing behind DGL's operator surface.
+
+Host-side mirror of the reference interface for the hot path (update_all / apply_edges /
+dgl.ops.gspmm / gsddmm / edge_softmax); all arithmetic runs in csrc/libmi355x_graph.so (HIP, gfx950)
+through the C ABI of include/mi355x_graph.h.
+"""
+from ._lib import DGLError, LIB_PATH  # noqa: F401
+from . import function, ops, sparse  # noqa: F401
+from .graph import DGLGraph, DGLHeteroGraph, GraphIndex, graph, create_block, ALL  # noqa: F401
+
+__version__ = "0.1.0"

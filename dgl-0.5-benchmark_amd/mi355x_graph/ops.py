@@ -1,0 +1,320 @@
+"""Autograd-aware g-SpMM / g-SDDMM / edge_softmax / segment_reduce -- the dgl.ops surface.
+
+Signatures follow the reference call sites:
+  dgl.ops.gspmm(g, op, reduce_op, lhs_data, rhs_data)            kernel/dgl-new.py:20
+  dgl.ops.gsddmm(g, op, lhs_data, rhs_data, lhs_target, rhs_target)   kernel/dgl-new.py:39
+  edge_softmax(graph, logits, eids=ALL, norm_by='dst')           via GATConv, main_dgl_reddit_gat.py:10
+Backward formulas are DGL's: dU of a sum-SpMM is the same SpMM on the reversed
+graph (out-CSR), dE is an SDDMM, etc.  `mean` is fused: the forward kernel divides by
+max(in_degree, 1) and the backward SpMM scales the gathered rows by the same factor, instead of
+DGL's separate elementwise divide.
+"""
+import torch
+
+from ._lib import DGLError
+from . import sparse
+from .graph import DGLGraph, GraphIndex
+
+__all__ = ["gspmm", "gsddmm", "edge_softmax", "segment_reduce", "copy_u_sum", "copy_u_mean", "u_mul_e_sum",
+           "copy_e_sum", "u_add_v", "u_dot_v"]
+
+
+def _gidx(g):
+    if isinstance(g, DGLGraph):
+        return g._index
+    if isinstance(g, GraphIndex):
+        return g
+    raise DGLError("expected a DGLGraph, got %s" % type(g))
+
+
+def _reduce_grad(grad, shape):
+    """Sum `grad` over the dims that were broadcast so that it has `shape` (rows excluded)."""
+    grad_shape = tuple(grad.shape[1:])
+    in_shape = tuple(shape[1:])
+    if in_shape == grad_shape:
+        return grad
+    num_to_squeeze = len(grad_shape) - len(in_shape)
+    in_shape = (1,) * num_to_squeeze + in_shape
+    reduce_idx = [i + 1 for i, (a, b) in enumerate(zip(grad_shape, in_shape)) if a != b]
+    if reduce_idx:
+        grad = grad.sum(dim=tuple(reduce_idx), keepdim=True)
+    return grad.view((-1,) + tuple(shape[1:]))
+
+
+def _need_reduce_last_dim(ufeat, efeat):
+    """(N,H,F) x (E,H,1): the edge gradient is a per-head dot product."""
+    ushp, eshp = ufeat.shape, efeat.shape
+    return ushp[1:-1] == eshp[1:-1] and eshp[-1] == 1 and ushp[-1] > 1
+
+
+def _expand(x, shape):
+    return x.expand(-1, *shape)
+
+
+class GSpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gidx, op, reduce_op, X, Y):
+        csc = gidx.csc()
+        want_arg = reduce_op in ("max", "min")
+        out, argX, argY = sparse.gspmm_raw(csc, op, reduce_op, X, Y, want_arg=want_arg)
+        ctx.backward_cache = gidx, op, reduce_op
+        ctx.x_shape = None if X is None else X.shape
+        ctx.y_shape = None if Y is None else Y.shape
+        req_x = X is not None and X.requires_grad
+        req_y = Y is not None and Y.requires_grad
+        save_x = X if (req_y and op == "mul") else None
+        save_y = Y if (req_x and op == "mul") or (want_arg and op == "mul") else None
+        if want_arg and op == "mul":
+            save_x = X
+        ctx.save_for_backward(save_x, save_y, argX, argY)
+        return out
+
+    @staticmethod
+    def backward(ctx, dZ):
+        gidx, op, reduce_op = ctx.backward_cache
+        X, Y, argX, argY = ctx.saved_tensors
+        dZ = dZ.contiguous()
+        dX = dY = None
+        summing = reduce_op in ("sum", "mean")
+        if summing:
+            inv = gidx.csc().inv_degrees() if reduce_op == "mean" else None
+            if op != "copy_rhs" and ctx.needs_input_grad[3]:
+                rev = gidx.csr()  # rows = src: the reversed graph's in-CSR
+                if op == "mul":
+                    dX, _, _ = sparse.gspmm_raw(rev, "mul", "sum", dZ, Y, src_scale=inv)
+                else:  # add, copy_lhs
+                    dX, _, _ = sparse.gspmm_raw(rev, "copy_lhs", "sum", dZ, None, src_scale=inv)
+                dX = _reduce_grad(dX, ctx.x_shape)
+            if op != "copy_lhs" and ctx.needs_input_grad[4]:
+                dZs = dZ if inv is None else dZ * inv.view((-1,) + (1,) * (dZ.dim() - 1))
+                if op == "mul":
+                    if _need_reduce_last_dim(X, Y):
+                        dY = sparse.gsddmm_raw(gidx, "dot", X, dZs, "u", "v")
+                    else:
+                        dY = sparse.gsddmm_raw(gidx, "mul", X, dZs, "u", "v")
+                else:  # add, copy_rhs
+                    dY = sparse.gsddmm_raw(gidx, "copy_rhs", None, dZs, "u", "v")
+                dY = _reduce_grad(dY, ctx.y_shape)
+        else:  # max / min: route dZ through the arg indices; empty rows (arg = -1) contribute nothing
+            if op != "copy_rhs" and ctx.needs_input_grad[3]:
+                valid = (argX >= 0)
+                idx = argX.clamp(min=0).long()
+                g = dZ
+                if op == "mul":
+                    yexp = _expand(Y, dZ.shape[1:]) if Y.shape[1:] != dZ.shape[1:] else Y
+                    g = dZ * yexp.gather(0, argY.clamp(min=0).long())
+                g = g * valid
+                full = torch.zeros((ctx.x_shape[0],) + tuple(dZ.shape[1:]), dtype=dZ.dtype, device=dZ.device)
+                full.scatter_add_(0, idx, g)
+                dX = _reduce_grad(full, ctx.x_shape)
+            if op != "copy_lhs" and ctx.needs_input_grad[4]:
+                valid = (argY >= 0)
+                idx = argY.clamp(min=0).long()
+                g = dZ
+                if op == "mul":
+                    xexp = _expand(X, dZ.shape[1:]) if X.shape[1:] != dZ.shape[1:] else X
+                    g = dZ * xexp.gather(0, argX.clamp(min=0).long())
+                g = g * valid
+                full = torch.zeros((ctx.y_shape[0],) + tuple(dZ.shape[1:]), dtype=dZ.dtype, device=dZ.device)
+                full.scatter_add_(0, idx, g)
+                dY = _reduce_grad(full, ctx.y_shape)
+        return None, None, None, dX, dY
+
+
+class GSDDMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gidx, op, X, Y, lhs_target, rhs_target):
+        out = sparse.gsddmm_raw(gidx, op, X, Y, lhs_target, rhs_target)
+        ctx.backward_cache = gidx, op, lhs_target, rhs_target
+        ctx.x_shape = None if X is None else X.shape
+        ctx.y_shape = None if Y is None else Y.shape
+        req_x = X is not None and X.requires_grad
+        req_y = Y is not None and Y.requires_grad
+        needs_other = op in ("mul", "dot", "div")
+        ctx.save_for_backward(X if (needs_other and (req_y or op == "div")) else None,
+                              Y if (needs_other and (req_x or req_y)) else None)
+        return out
+
+    @staticmethod
+    def _to_target(gidx, target, edge_grad):
+        """Sum per-edge gradients back onto their target set."""
+        if target == "e":
+            return edge_grad
+        view = gidx.csr() if target == "u" else gidx.csc()
+        out, _, _ = sparse.gspmm_raw(view, "copy_rhs", "sum", None, edge_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dZ):
+        gidx, op, lt, rt = ctx.backward_cache
+        X, Y = ctx.saved_tensors
+        dZ = dZ.contiguous()
+        dX = dY = None
+        if op != "copy_rhs" and ctx.needs_input_grad[2]:
+            if op in ("add", "sub", "copy_lhs"):
+                dX = GSDDMM._to_target(gidx, lt, dZ)
+            elif op in ("mul", "dot", "div"):
+                if lt == "u" and rt == "v" and op in ("mul", "dot"):
+                    # dX[u] = sum_{e: u->v} Y[v] * dZ[e]: a mul-SpMM on the reversed graph
+                    dX, _, _ = sparse.gspmm_raw(gidx.csr(), "mul", "sum", Y, dZ)
+                elif lt == "v" and rt == "u" and op in ("mul", "dot"):
+                    dX, _, _ = sparse.gspmm_raw(gidx.csc(), "mul", "sum", Y, dZ)
+                else:
+                    y_e = sparse.gsddmm_raw(gidx, "copy_rhs", None, Y, lt, rt) if rt != "e" else Y
+                    ge = dZ * y_e if op in ("mul", "dot") else dZ / y_e
+                    dX = GSDDMM._to_target(gidx, lt, ge.contiguous())
+            dX = _reduce_grad(dX, ctx.x_shape)
+        if op != "copy_lhs" and ctx.needs_input_grad[3]:
+            if op in ("add", "copy_rhs"):
+                dY = GSDDMM._to_target(gidx, rt, dZ)
+            elif op == "sub":
+                dY = GSDDMM._to_target(gidx, rt, (-dZ).contiguous())
+            elif op in ("mul", "dot"):
+                if lt == "u" and rt == "v":
+                    dY, _, _ = sparse.gspmm_raw(gidx.csc(), "mul", "sum", X, dZ)
+                elif lt == "v" and rt == "u":
+                    dY, _, _ = sparse.gspmm_raw(gidx.csr(), "mul", "sum", X, dZ)
+                else:
+                    x_e = sparse.gsddmm_raw(gidx, "copy_lhs", X, None, lt, rt) if lt != "e" else X
+                    dY = GSDDMM._to_target(gidx, rt, (dZ * x_e).contiguous())
+            else:  # div: d(x/y)/dy = -x / y^2
+                x_e = sparse.gsddmm_raw(gidx, "copy_lhs", X, None, lt, rt) if lt != "e" else X
+                y_e = sparse.gsddmm_raw(gidx, "copy_rhs", None, Y, lt, rt) if rt != "e" else Y
+                dY = GSDDMM._to_target(gidx, rt, (-dZ * x_e / (y_e * y_e)).contiguous())
+            dY = _reduce_grad(dY, ctx.y_shape)
+        return None, None, dX, dY, None, None
+
+
+class EdgeSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gidx, score, norm_by):
+        view = gidx.csc() if norm_by == "dst" else gidx.csr()
+        out = sparse.edge_softmax_fwd_raw(view, score)
+        ctx.backward_cache = view
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        view = ctx.backward_cache
+        out, = ctx.saved_tensors
+        return None, sparse.edge_softmax_bwd_raw(view, out, grad_out.contiguous()), None
+
+
+class SegmentReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, op, x, offsets):
+        out, arg = sparse.segment_reduce_raw(offsets, x, op, want_arg=op in ("max", "min"))
+        ctx.backward_cache = op, x.shape[0]
+        ctx.save_for_backward(arg, offsets)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        op, n = ctx.backward_cache
+        arg, offsets = ctx.saved_tensors
+        dy = dy.contiguous()
+        if op in ("sum", "mean"):
+            lens = offsets[1:] - offsets[:-1]
+            if op == "mean":
+                dy = dy / lens.clamp(min=1).to(dy.dtype).view((-1,) + (1,) * (dy.dim() - 1))
+            seg = torch.repeat_interleave(torch.arange(lens.shape[0], device=dy.device), lens, output_size=n)
+            dx = sparse.gather_rows_raw(dy, seg) if dy.is_cuda else dy[seg]
+        else:
+            dx = torch.zeros((n,) + tuple(dy.shape[1:]), dtype=dy.dtype, device=dy.device)
+            valid = arg >= 0
+            dx.scatter_add_(0, arg.clamp(min=0), dy * valid)
+        return None, dx, None
+
+
+# ----------------------------------------------------------------------------- public API
+def gspmm(g, op, reduce_op, lhs_data, rhs_data):
+    """Generalized SpMM: out[v] = reduce_{(u->v)} op(lhs[u], rhs[e]).  (kernel/dgl-new.py:20)"""
+    if op not in ("add", "sub", "mul", "div", "copy_lhs", "copy_rhs"):
+        raise DGLError("Unsupported binary op %r for gspmm" % (op,))
+    if reduce_op not in ("sum", "max", "min", "mean"):
+        raise DGLError("Unsupported reduce op %r for gspmm" % (reduce_op,))
+    gidx = _gidx(g)
+    if op == "sub":  # same rewrites as DGL's ops/spmm.py
+        op, rhs_data = "add", -rhs_data
+    elif op == "div":
+        op, rhs_data = "mul", 1.0 / rhs_data
+    expand_l = expand_r = False
+    if op != "copy_rhs":
+        if lhs_data is None:
+            raise DGLError("gspmm: op %r needs lhs_data" % op)
+        if lhs_data.dim() == 1:
+            lhs_data, expand_l = lhs_data.unsqueeze(-1), True
+    if op != "copy_lhs":
+        if rhs_data is None:
+            raise DGLError("gspmm: op %r needs rhs_data" % op)
+        if rhs_data.dim() == 1:
+            rhs_data, expand_r = rhs_data.unsqueeze(-1), True
+    X = None if op == "copy_rhs" else lhs_data
+    Y = None if op == "copy_lhs" else rhs_data
+    out = GSpMM.apply(gidx, op, reduce_op, X, Y)
+    squeeze = (expand_l or X is None) and (expand_r or Y is None) and (expand_l or expand_r)
+    return out.squeeze(-1) if squeeze else out
+
+
+def gsddmm(g, op, lhs_data, rhs_data, lhs_target="u", rhs_target="v"):
+    """Generalized SDDMM: out[e] = op(lhs[t_l(e)], rhs[t_r(e)]).  (kernel/dgl-new.py:39)"""
+    if op not in ("add", "sub", "mul", "div", "dot", "copy_lhs", "copy_rhs"):
+        raise DGLError("Unsupported binary op %r for gsddmm" % (op,))
+    for t in (lhs_target, rhs_target):
+        if t not in ("u", "e", "v"):
+            raise DGLError("Unsupported target %r; expected 'u', 'e' or 'v'" % (t,))
+    gidx = _gidx(g)
+    expand_l = expand_r = False
+    if op != "copy_rhs" and lhs_data is not None and lhs_data.dim() == 1:
+        lhs_data, expand_l = lhs_data.unsqueeze(-1), True
+    if op != "copy_lhs" and rhs_data is not None and rhs_data.dim() == 1:
+        rhs_data, expand_r = rhs_data.unsqueeze(-1), True
+    X = None if op == "copy_rhs" else lhs_data
+    Y = None if op == "copy_lhs" else rhs_data
+    out = GSDDMM.apply(gidx, op, X, Y, lhs_target, rhs_target)
+    squeeze = (expand_l or X is None) and (expand_r or Y is None) and (expand_l or expand_r) and op != "dot"
+    return out.squeeze(-1) if squeeze else out
+
+
+def edge_softmax(graph, logits, eids="__ALL__", norm_by="dst"):
+    """Softmax of edge logits over the in-edges of every destination node (fused kernel)."""
+    if not isinstance(eids, str):
+        raise DGLError("edge_softmax on an edge subset is not supported by this backend")
+    if norm_by not in ("dst", "src"):
+        raise DGLError("norm_by must be 'dst' or 'src'")
+    return EdgeSoftmax.apply(_gidx(graph), logits, norm_by)
+
+
+def segment_reduce(seglen, value, reducer="sum"):
+    """dgl.ops.segment_reduce: reduce consecutive row segments of `value` (AvgPooling readout)."""
+    if reducer not in ("sum", "mean", "max", "min"):
+        raise DGLError("Unsupported segment reducer %r" % (reducer,))
+    offsets = torch.zeros(seglen.shape[0] + 1, dtype=torch.int64, device=value.device)
+    torch.cumsum(seglen.to(value.device).long(), 0, out=offsets[1:])
+    return SegmentReduce.apply(reducer, value, offsets)
+
+
+# named shortcuts (dgl.ops.copy_u_sum, ...)
+def copy_u_sum(g, x):
+    return gspmm(g, "copy_lhs", "sum", x, None)
+
+
+def copy_u_mean(g, x):
+    return gspmm(g, "copy_lhs", "mean", x, None)
+
+
+def copy_e_sum(g, x):
+    return gspmm(g, "copy_rhs", "sum", None, x)
+
+
+def u_mul_e_sum(g, x, y):
+    return gspmm(g, "mul", "sum", x, y)
+
+
+def u_add_v(g, x, y):
+    return gsddmm(g, "add", x, y, "u", "v")
+
+
+def u_dot_v(g, x, y):
+    return gsddmm(g, "dot", x, y, "u", "v")

@@ -1,0 +1,416 @@
+"""Raw (non-autograd) sparse primitives on torch tensors, dispatched to the HIP C ABI.
+
+Mirrors the role of DGL's python/dgl/sparse.py (_gspmm / _gsddmm, UPSTREAM) for the call sites
+kernel/dgl-new.py:20,39 and main_dgl_product_sage.py:62: shape/broadcast bookkeeping and output
+allocation happen here (caller-allocates convention of the seam), the arithmetic happens in
+csrc/*.hip.  Tensors on a HIP device go to `HipBackend`; there is no built-in backend for CPU
+tensors -- message-passing arithmetic on CPU tensors raises DGLError.  (tests/ registers a checker
+backend for multi-process gloo tests; the product never does.)
+"""
+import ctypes
+import functools
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DGLError, MgxCsr, OP, REDUCE, TARGET
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _prod(shape):
+    p = 1
+    for s in shape:
+        p *= int(s)
+    return p
+
+
+class CsrView(object):
+    """An immutable CSR over torch tensors (in-CSR: rows = destination nodes)."""
+
+    __slots__ = ("num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg")
+
+    def __init__(self, num_rows, num_cols, indptr, indices, eids):
+        self.num_rows, self.num_cols = int(num_rows), int(num_cols)
+        self.indptr, self.indices, self.eids = indptr, indices, eids
+        self._c = None
+        self._deg = None
+        self._inv_deg = None
+
+    @property
+    def nnz(self):
+        return int(self.indices.shape[0])
+
+    @property
+    def device(self):
+        return self.indptr.device
+
+    @property
+    def idx_bits(self):
+        return 32 if self.indptr.dtype == torch.int32 else 64
+
+    def c_struct(self):
+        if self._c is None:
+            self._c = MgxCsr(self.num_rows, self.num_cols, self.nnz, self.indptr.data_ptr(),
+                             self.indices.data_ptr() if self.indices.numel() else None,
+                             None if self.eids is None else self.eids.data_ptr(), self.idx_bits, 0)
+        return self._c
+
+    def degrees(self):
+        if self._deg is None:
+            self._deg = backend_for(self.indptr).degrees(self)
+        return self._deg
+
+    def inv_degrees(self):
+        """1 / max(deg, 1) as fp32 -- the factor of fn.mean (main_dgl_product_sage.py:62)."""
+        if self._inv_deg is None:
+            self._inv_deg = backend_for(self.indptr).inv_degrees(self)
+        return self._inv_deg
+
+    def to(self, device):
+        return CsrView(self.num_rows, self.num_cols, self.indptr.to(device), self.indices.to(device),
+                       None if self.eids is None else self.eids.to(device))
+
+    def astype(self, dtype):
+        if self.indptr.dtype == dtype:
+            return self
+        return CsrView(self.num_rows, self.num_cols, self.indptr.to(dtype), self.indices.to(dtype),
+                       None if self.eids is None else self.eids.to(dtype))
+
+
+# ----------------------------------------------------------------------------- broadcasting
+def _is_head_bcast(shape, oshape):
+    """True when `shape` == oshape[:j] + (1,)*(n-j): element k of the output uses operand element
+    k // (out_len / len) -- the (N,H,F) x (E,H,1) pattern; expressed to the C ABI as a NULL table."""
+    if len(shape) != len(oshape):
+        return False
+    j = len(shape)
+    while j > 0 and shape[j - 1] == 1:
+        j -= 1
+    return tuple(shape[:j]) == tuple(oshape[:j])
+
+
+@functools.lru_cache(maxsize=256)
+def _bcast_plan(lshape, rshape):
+    nd = max(len(lshape), len(rshape))
+    ls = (1,) * (nd - len(lshape)) + tuple(lshape)
+    rs = (1,) * (nd - len(rshape)) + tuple(rshape)
+    out = []
+    for a, b in zip(ls, rs):
+        if a != b and a != 1 and b != 1:
+            raise DGLError("Feature shapes %s and %s are not broadcastable" % (lshape, rshape))
+        out.append(max(a, b))
+    out = tuple(out)
+
+    def table(shape):
+        if shape == out or _is_head_bcast(shape, out):
+            return None
+        idx = np.indices(out).reshape(nd, -1)
+        strides = np.ones(nd, np.int64)
+        for d in range(nd - 2, -1, -1):
+            strides[d] = strides[d + 1] * shape[d + 1]
+        off = np.zeros(idx.shape[1], np.int64)
+        for d in range(nd):
+            if shape[d] != 1:
+                off += idx[d] * strides[d]
+        return off
+
+    return out, table(ls), table(rs)
+
+
+_table_cache = {}
+
+
+def _device_table(arr, device):
+    if arr is None:
+        return None
+    key = (arr.tobytes(), str(device))
+    t = _table_cache.get(key)
+    if t is None:
+        t = torch.from_numpy(arr).to(device)
+        _table_cache[key] = t
+    return t
+
+
+# ----------------------------------------------------------------------------- backends
+class HipBackend(object):
+    """Calls the gfx950 library through its C ABI on PyTorch's current HIP stream."""
+
+    name = "hip"
+
+    def _check_dev(self, *tensors):
+        dev = None
+        for t in tensors:
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise DGLError("expected a HIP device tensor, got device %s" % t.device)
+            if dev is None:
+                dev = t.device
+            elif t.device != dev:
+                raise DGLError("tensors on different devices: %s vs %s" % (dev, t.device))
+        return dev
+
+    def coo_to_csr(self, num_rows, num_cols, row, col):
+        dev = self._check_dev(row, col)
+        L = _lib.lib()
+        nnz = row.shape[0]
+        bits = 32 if row.dtype == torch.int32 else 64
+        indptr = torch.empty(num_rows + 1, dtype=row.dtype, device=dev)
+        indices = torch.empty(nnz, dtype=row.dtype, device=dev)
+        eids = torch.empty(nnz, dtype=row.dtype, device=dev)
+        with torch.cuda.device(dev):
+            ws_bytes = L.mgx_coo_to_csr_workspace(num_rows, nnz, bits)
+            if ws_bytes < 0:
+                _lib.check(3)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            _lib.check(L.mgx_coo_to_csr(num_rows, nnz, _ptr(row), _ptr(col), bits, _ptr(indptr), _ptr(indices),
+                                        _ptr(eids), _ptr(ws), ws_bytes, _stream(dev)))
+        return CsrView(num_rows, num_cols, indptr, indices, eids)
+
+    def degrees(self, csr):
+        dev = csr.device
+        deg = torch.empty(csr.num_rows, dtype=csr.indptr.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_csr_degrees(csr.num_rows, _ptr(csr.indptr), csr.idx_bits, _ptr(deg), _stream(dev)))
+        return deg
+
+    def inv_degrees(self, csr):
+        dev = csr.device
+        inv = torch.empty(csr.num_rows, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_csr_inv_degrees(csr.num_rows, _ptr(csr.indptr), csr.idx_bits, _ptr(inv), _stream(dev)))
+        return inv
+
+    def spmm(self, csr, op, reduce, U, E, u_len, e_len, out_len, u_off, e_off, src_scale, dst_scale, want_arg):
+        dev = self._check_dev(csr.indptr, U, E, src_scale, dst_scale)
+        out = torch.empty((csr.num_rows, out_len), dtype=torch.float32, device=dev)
+        arg_u = arg_e = None
+        if want_arg:
+            if op != "copy_rhs":
+                arg_u = torch.empty((csr.num_rows, out_len), dtype=csr.indptr.dtype, device=dev)
+            if op != "copy_lhs":
+                arg_e = torch.empty((csr.num_rows, out_len), dtype=csr.indptr.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_spmm_csr(
+                ctypes.byref(csr.c_struct()), OP[op], REDUCE[reduce], _ptr(U), _ptr(E), u_len, e_len, out_len,
+                _ptr(u_off), _ptr(e_off), _ptr(src_scale), _ptr(dst_scale), _ptr(out), _ptr(arg_u), _ptr(arg_e),
+                _stream(dev)))
+        return out, arg_u, arg_e
+
+    def sddmm(self, graph_index, op, L, R, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size, l_off, r_off):
+        """graph_index supplies either COO (edge-id order) or the in-CSR."""
+        nnz = graph_index.num_edges()
+        dev = self._check_dev(L, R)
+        out = torch.empty((nnz, out_len), dtype=torch.float32, device=dev)
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            if graph_index.has_format("coo") or not graph_index.has_format("csc"):
+                src, dst = graph_index.coo()
+                self._check_dev(src, L, R)
+                bits = 32 if src.dtype == torch.int32 else 64
+                _lib.check(lib.mgx_sddmm_coo(
+                    graph_index.num_src, graph_index.num_dst, nnz, _ptr(src), _ptr(dst), bits, OP[op], _ptr(L), _ptr(R),
+                    TARGET[lhs_target], TARGET[rhs_target], l_len, r_len, out_len, reduce_size, _ptr(l_off), _ptr(r_off),
+                    _ptr(out), _stream(dev)))
+            else:
+                csr = graph_index.csc()
+                self._check_dev(csr.indptr, L, R)
+                _lib.check(lib.mgx_sddmm_csr(
+                    ctypes.byref(csr.c_struct()), OP[op], _ptr(L), _ptr(R), TARGET[lhs_target], TARGET[rhs_target],
+                    l_len, r_len, out_len, reduce_size, _ptr(l_off), _ptr(r_off), _ptr(out), _stream(dev)))
+        return out
+
+    def edge_softmax_fwd(self, csr, z2d):
+        dev = self._check_dev(csr.indptr, z2d)
+        a = torch.empty_like(z2d)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_edge_softmax_fwd(ctypes.byref(csr.c_struct()), z2d.shape[1], _ptr(z2d), _ptr(a), _stream(dev)))
+        return a
+
+    def edge_softmax_bwd(self, csr, a2d, da2d):
+        dev = self._check_dev(csr.indptr, a2d, da2d)
+        dz = torch.empty_like(a2d)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_edge_softmax_bwd(ctypes.byref(csr.c_struct()), a2d.shape[1], _ptr(a2d), _ptr(da2d), _ptr(dz), _stream(dev)))
+        return dz
+
+    def segment_reduce(self, offsets, x2d, reduce, want_arg):
+        dev = self._check_dev(offsets, x2d)
+        n = offsets.shape[0] - 1
+        out = torch.empty((n, x2d.shape[1]), dtype=torch.float32, device=dev)
+        arg = torch.empty((n, x2d.shape[1]), dtype=torch.int64, device=dev) if want_arg else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_segment_reduce(n, _ptr(offsets), x2d.shape[1], REDUCE[reduce], _ptr(x2d), _ptr(out), _ptr(arg), _stream(dev)))
+        return out, arg
+
+    def gather_rows(self, x2d, idx):
+        dev = self._check_dev(x2d, idx)
+        out = torch.empty((idx.shape[0], x2d.shape[1]), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_gather_rows(idx.shape[0], _ptr(idx), 32 if idx.dtype == torch.int32 else 64,
+                                                  x2d.shape[1], _ptr(x2d), _ptr(out), _stream(dev)))
+        return out
+
+    def scatter_add_rows(self, x2d, idx, rows2d):
+        dev = self._check_dev(x2d, idx, rows2d)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_scatter_add_rows(idx.shape[0], _ptr(idx), 32 if idx.dtype == torch.int32 else 64,
+                                                       x2d.shape[1], _ptr(rows2d), _ptr(x2d), _stream(dev)))
+        return x2d
+
+
+_BACKENDS = {"cuda": HipBackend()}
+
+
+def register_backend(device_type, backend):
+    """Hook used by tests/ only (a checker backend for CPU tensors in gloo tests)."""
+    _BACKENDS[device_type] = backend
+
+
+def backend_for(tensor):
+    b = _BACKENDS.get(tensor.device.type)
+    if b is None:
+        raise DGLError(
+            "message passing on %s tensors is not supported: this backend runs on MI355X (HIP) devices only; "
+            "move the graph and features to a cuda/hip device" % tensor.device.type)
+    return b
+
+
+def coo_to_csr_host(num_rows, num_cols, row, col):
+    """Stable COO->CSR for CPU index tensors (host half of the C ABI; needs no GPU)."""
+    nnz = row.shape[0]
+    bits = 32 if row.dtype == torch.int32 else 64
+    row, col = row.contiguous(), col.contiguous()
+    indptr = torch.empty(num_rows + 1, dtype=row.dtype)
+    indices = torch.empty(nnz, dtype=row.dtype)
+    eids = torch.empty(nnz, dtype=row.dtype)
+    _lib.check(_lib.lib().mgx_coo_to_csr_host(num_rows, nnz, _ptr(row), _ptr(col), bits, _ptr(indptr), _ptr(indices), _ptr(eids)))
+    return CsrView(num_rows, num_cols, indptr, indices, eids)
+
+
+def coo_to_csr(num_rows, num_cols, row, col):
+    if row.is_cuda:
+        return _BACKENDS["cuda"].coo_to_csr(num_rows, num_cols, row.contiguous(), col.contiguous())
+    return coo_to_csr_host(num_rows, num_cols, row, col)
+
+
+# ----------------------------------------------------------------------------- raw ops
+def _as_f32(t, what):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise DGLError("%s must be float32 on this backend, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
+def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=False):
+    """out[v] = reduce_{p in row v} op(U[indices[p]], E[eids[p]]).
+
+    U: (num_cols, *ushape) or None; E: (nnz, *eshape) or None.  Returns (out, arg_u, arg_e) with out of
+    shape (num_rows, *bcast(ushape, eshape))."""
+    if op not in ("add", "mul", "copy_lhs", "copy_rhs"):
+        raise DGLError("gspmm_raw: unsupported op %r (sub/div are rewritten by the caller)" % op)
+    U = None if op == "copy_rhs" else _as_f32(U, "gspmm lhs feature")
+    E = None if op == "copy_lhs" else _as_f32(E, "gspmm rhs feature")
+    if op != "copy_rhs" and U is None:
+        raise DGLError("gspmm: op %r needs node features" % op)
+    if op != "copy_lhs" and E is None:
+        raise DGLError("gspmm: op %r needs edge features" % op)
+    if U is not None and U.shape[0] != csr.num_cols:
+        raise DGLError("gspmm: expected %d source rows, got %d" % (csr.num_cols, U.shape[0]))
+    if E is not None and E.shape[0] != csr.nnz:
+        raise DGLError("gspmm: expected %d edge rows, got %d" % (csr.nnz, E.shape[0]))
+    ushape = tuple(U.shape[1:]) if U is not None else ()
+    eshape = tuple(E.shape[1:]) if E is not None else ()
+    if U is not None and E is not None:
+        oshape, u_tab, e_tab = _bcast_plan(ushape, eshape)
+    else:
+        oshape, u_tab, e_tab = (ushape if U is not None else eshape), None, None
+    ref = U if U is not None else E
+    dev = ref.device
+    out, arg_u, arg_e = backend_for(ref).spmm(
+        csr, op, reduce, U, E, _prod(ushape), _prod(eshape), _prod(oshape),
+        _device_table(u_tab, dev), _device_table(e_tab, dev), src_scale, dst_scale, want_arg)
+    shape = (csr.num_rows,) + tuple(oshape)
+    out = out.view(shape)
+    if arg_u is not None:
+        arg_u = arg_u.view(shape)
+    if arg_e is not None:
+        arg_e = arg_e.view(shape)
+    return out, arg_u, arg_e
+
+
+def gsddmm_raw(gidx, op, L, R, lhs_target="u", rhs_target="v"):
+    """out[e] = op(L[t_l(e)], R[t_r(e)]) in edge-id order; `dot` reduces the last dim to size 1."""
+    L = None if op == "copy_rhs" else _as_f32(L, "gsddmm lhs feature")
+    R = None if op == "copy_lhs" else _as_f32(R, "gsddmm rhs feature")
+    if op not in OP:
+        raise DGLError("gsddmm: unsupported op %r" % op)
+    if op != "copy_rhs" and L is None:
+        raise DGLError("gsddmm: op %r needs the lhs operand" % op)
+    if op != "copy_lhs" and R is None:
+        raise DGLError("gsddmm: op %r needs the rhs operand" % op)
+    expect = {"u": gidx.num_src, "v": gidx.num_dst, "e": gidx.num_edges()}
+    for t, tgt, name in ((L, lhs_target, "lhs"), (R, rhs_target, "rhs")):
+        if t is not None and t.shape[0] != expect[tgt]:
+            raise DGLError("gsddmm: %s has %d rows, target %r has %d" % (name, t.shape[0], tgt, expect[tgt]))
+    lshape = tuple(L.shape[1:]) if L is not None else ()
+    rshape = tuple(R.shape[1:]) if R is not None else ()
+    reduce_size = 1
+    if op == "dot":
+        if not lshape or not rshape or lshape[-1] != rshape[-1]:
+            raise DGLError("gsddmm dot: last dims differ: %s vs %s" % (lshape, rshape))
+        reduce_size = lshape[-1]
+        oshape, l_tab, r_tab = _bcast_plan(lshape[:-1], rshape[:-1])
+        out_len = _prod(oshape)
+        oshape = tuple(oshape) + (1,)
+    elif L is not None and R is not None:
+        oshape, l_tab, r_tab = _bcast_plan(lshape, rshape)
+        out_len = _prod(oshape)
+    else:
+        oshape, l_tab, r_tab = (lshape if L is not None else rshape), None, None
+        out_len = _prod(oshape)
+    ref = L if L is not None else R
+    dev = ref.device
+    out = backend_for(ref).sddmm(gidx, op, L, R, lhs_target, rhs_target, _prod(lshape), _prod(rshape), out_len,
+                                 reduce_size, _device_table(l_tab, dev), _device_table(r_tab, dev))
+    return out.view((gidx.num_edges(),) + tuple(oshape))
+
+
+def edge_softmax_fwd_raw(csr, z):
+    z = _as_f32(z, "edge_softmax logits")
+    a = backend_for(z).edge_softmax_fwd(csr, z.view(z.shape[0], -1))
+    return a.view(z.shape)
+
+
+def edge_softmax_bwd_raw(csr, a, da):
+    a, da = _as_f32(a, "edge_softmax out"), _as_f32(da, "edge_softmax grad")
+    dz = backend_for(a).edge_softmax_bwd(csr, a.view(a.shape[0], -1), da.view(da.shape[0], -1))
+    return dz.view(a.shape)
+
+
+def segment_reduce_raw(offsets, x, reduce="sum", want_arg=False):
+    x = _as_f32(x, "segment_reduce input")
+    out, arg = backend_for(x).segment_reduce(offsets, x.view(x.shape[0], -1), reduce, want_arg)
+    shape = (offsets.shape[0] - 1,) + tuple(x.shape[1:])
+    return out.view(shape), (None if arg is None else arg.view(shape))
+
+
+def gather_rows_raw(x, idx):
+    x = _as_f32(x, "gather_rows input")
+    out = backend_for(x).gather_rows(x.view(x.shape[0], -1), idx)
+    return out.view((idx.shape[0],) + tuple(x.shape[1:]))
+
+
+def scatter_add_rows_raw(x, idx, rows):
+    """x[idx[i]] += rows[i] in place; idx must be unique."""
+    backend_for(x).scatter_add_rows(x.view(x.shape[0], -1), idx, _as_f32(rows, "rows").view(rows.shape[0], -1))
+    return x

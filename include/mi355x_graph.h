@@ -1,0 +1,183 @@
+/*
+ * mi355x_graph.h -- C ABI of the MI355X (gfx950 / CDNA4) sparse message-passing library.
+ *
+ * This is the drop-in boundary for the one hot path of dglai/dgl-0.5-benchmark:
+ * what DGLGraph.update_all(builtin, builtin) / apply_edges(builtin) / dgl.ops.gspmm /
+ * dgl.ops.gsddmm / edge_softmax execute.  The reference itself is pure Python; the seam it
+ * crosses is DGL v0.6.x's FFI pair
+ *     _CAPI_DGLKernelSpMM (graph, op, reduce_op, U, E, V, ArgU, ArgE)
+ *     _CAPI_DGLKernelSDDMM(graph, op, lhs, rhs, out, lhs_target, rhs_target)
+ * (UPSTREAM src/array/kernel.cc, called from python/dgl/sparse.py::_gspmm/_gsddmm), reached
+ * from the reference at
+ *     kernel/dgl-new.py:20,39
+ *     end_to_end/full_graph/node_classification/main_dgl_product_sage.py:62
+ *     end_to_end/full_graph/node_classification/main_dgl_reddit_gat.py:10,31-55
+ *     end_to_end/full_graph/node_classification/main_dgl_proteins_rgcn_for.py:52
+ *     end_to_end/full_graph/graph_classification/main_dgl_molhiv_gcn.py:41-52,75
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions (same as the upstream seam):
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`; the CALLER allocates
+ *     every output / arg-index / workspace buffer, the library never allocates or frees;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued
+ *     on it and the call returns without synchronising;
+ *   - graph index arrays are int32 or int64 (`idx_bits`); element offsets are 64-bit inside;
+ *   - features are dense row-major fp32 (`MGX_F32`), `*_len` = elements per row;
+ *   - broadcasting ((N,H,F) op (E,H,1)) is expressed by optional device tables
+ *     `*_off[out_len]` mapping an output element to the operand element (NULL = identity),
+ *     the formulation of DGL's BcastOff;
+ *   - every function returns MGX_OK (0) or an error code; mgx_last_error() gives the text
+ *     (thread-local).  Nothing aborts the process.
+ *
+ * No torch types, no C++ types: plain pointers and sizes, bindable from ctypes / cgo / JNI.
+ */
+#ifndef MI355X_GRAPH_H_
+#define MI355X_GRAPH_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  MGX_OK = 0,
+  MGX_ERR_INVALID_ARGUMENT = 1,
+  MGX_ERR_UNSUPPORTED = 2,
+  MGX_ERR_HIP = 3
+} mgx_status;
+
+/* binary ops of kernel/utils.py:8-16 (binary_op_dict) */
+typedef enum {
+  MGX_OP_ADD = 0, MGX_OP_SUB = 1, MGX_OP_MUL = 2, MGX_OP_DIV = 3,
+  MGX_OP_COPY_LHS = 4, MGX_OP_COPY_RHS = 5, MGX_OP_DOT = 6
+} mgx_op;
+
+/* reducers selectable with kernel/dgl-new.py:51 --spmm-reduce */
+typedef enum { MGX_REDUCE_SUM = 0, MGX_REDUCE_MAX = 1, MGX_REDUCE_MIN = 2, MGX_REDUCE_MEAN = 3 } mgx_reduce;
+
+/* SDDMM operand targets (lhs_target / rhs_target of dgl.ops.gsddmm) */
+typedef enum { MGX_TARGET_U = 0, MGX_TARGET_E = 1, MGX_TARGET_V = 2 } mgx_target;
+
+/* A CSR view.  For message passing this is the IN-CSR ("CSC"): one row per destination node,
+ * indices[p] = source node, eids[p] = id of the edge in the original COO (NULL = identity). */
+typedef struct mgx_csr {
+  int64_t num_rows;
+  int64_t num_cols;
+  int64_t nnz;
+  const void* indptr;   /* [num_rows + 1] */
+  const void* indices;  /* [nnz] */
+  const void* eids;     /* [nnz] or NULL */
+  int32_t idx_bits;     /* 32 or 64 */
+  int32_t reserved;
+} mgx_csr;
+
+/* ------------------------------------------------------------------ misc */
+const char* mgx_last_error(void);
+/* ABI version, bumped on any signature change. */
+int32_t mgx_abi_version(void);
+/* Fills *num_cus / *lds_bytes of the current HIP device; MGX_ERR_HIP when no GPU is usable. */
+int32_t mgx_device_info(int32_t* num_cus, int32_t* lds_bytes_per_cu, char* arch_name, int32_t arch_name_len);
+
+/* ------------------------------------------------------------------ g-SpMM
+ * Replaces _CAPI_DGLKernelSpMM as reached by dgl.ops.gspmm (kernel/dgl-new.py:20) and
+ * update_all(fn.copy_src, fn.mean) (main_dgl_product_sage.py:62), update_all(fn.u_mul_e, fn.sum)
+ * (GATConv, main_dgl_reddit_gat.py:10; main_dgl_proteins_rgcn_for.py:52), update_all(udf, fn.sum)
+ * -> copy_e/sum (main_dgl_molhiv_gcn.py:46).
+ *
+ *   out[v,k] = dst_scale[v] * REDUCE_{p in row v} op( src_scale[u] * U[u, u_off[k]], E[eid(p), e_off[k]] )
+ *
+ * op: ADD, MUL, COPY_LHS, COPY_RHS (callers rewrite SUB/DIV as ADD(-E)/MUL(1/E), as DGL does).
+ * reduce: SUM, MEAN (sum / max(in_degree,1), the divide DGL performs after the kernel),
+ *         MAX / MIN (empty rows give 0; arg_u/arg_e receive the winning source node / edge id,
+ *         -1 for empty rows; first extremum in storage order wins).
+ * src_scale / dst_scale: optional per-node fp32 factors (NULL = 1); used for the fused backward
+ * of `mean` and for symmetric-norm GCN layers.  Only with SUM/MEAN.
+ * arg_u/arg_e: same index width as the graph, [num_rows*out_len], may be NULL.
+ * Deterministic: no atomics, fixed summation order for a given graph. */
+int32_t mgx_spmm_csr(const mgx_csr* csr, int32_t op, int32_t reduce,
+                     const float* ufeat, const float* efeat,
+                     int64_t u_len, int64_t e_len, int64_t out_len,
+                     const int64_t* u_off, const int64_t* e_off,
+                     const float* src_scale, const float* dst_scale,
+                     float* out, void* arg_u, void* arg_e, void* stream);
+
+/* ------------------------------------------------------------------ g-SDDMM
+ * Replaces _CAPI_DGLKernelSDDMM as reached by dgl.ops.gsddmm (kernel/dgl-new.py:39),
+ * apply_edges(fn.u_add_v) inside GATConv (main_dgl_reddit_gat.py:10) and fn.u_dot_v
+ * (link_prediction/gcmc_dgl/model.py:342).
+ *
+ *   out[e,k] = op( L[t_l(e), l_off[k]], R[t_r(e), r_off[k]] ),   e = edge id
+ *   DOT: out[e,k] = sum_{j<reduce_size} L[.., l_off[k]*reduce_size+j] * R[.., r_off[k]*reduce_size+j]
+ *
+ * COO form: src/dst are [nnz] in edge-id order. */
+int32_t mgx_sddmm_coo(int64_t num_src, int64_t num_dst, int64_t nnz,
+                      const void* src, const void* dst, int32_t idx_bits,
+                      int32_t op, const float* lhs, const float* rhs,
+                      int32_t lhs_target, int32_t rhs_target,
+                      int64_t l_len, int64_t r_len, int64_t out_len, int64_t reduce_size,
+                      const int64_t* l_off, const int64_t* r_off,
+                      float* out, void* stream);
+
+/* CSR form (graphs restricted to formats(['csr','csc']), main_dgl_product_sage.py:158): walks
+ * the in-CSR, t(e)=V is the row, t(e)=U is indices[p], output still addressed by edge id. */
+int32_t mgx_sddmm_csr(const mgx_csr* csr,
+                      int32_t op, const float* lhs, const float* rhs,
+                      int32_t lhs_target, int32_t rhs_target,
+                      int64_t l_len, int64_t r_len, int64_t out_len, int64_t reduce_size,
+                      const int64_t* l_off, const int64_t* r_off,
+                      float* out, void* stream);
+
+/* ------------------------------------------------------------------ edge softmax
+ * Replaces dgl.nn.functional.edge_softmax(graph, logits) (norm_by='dst') as called by GATConv
+ * (main_dgl_reddit_gat.py:31-55).  DGL 0.6 runs 2 SpMM + 2 SDDMM + exp; here one fused
+ * row-segmented kernel.  z, a, da, dz: [nnz, H] addressed by edge id.
+ *   fwd: a[e,h]  = exp(z[e,h]-max_v) / sum_{e'->v} exp(z[e',h]-max_v)
+ *   bwd: dz[e,h] = a*da - a * sum_{e'->v}(a*da)                                            */
+int32_t mgx_edge_softmax_fwd(const mgx_csr* csr, int64_t H, const float* z, float* a, void* stream);
+int32_t mgx_edge_softmax_bwd(const mgx_csr* csr, int64_t H, const float* a, const float* da,
+                             float* dz, void* stream);
+
+/* ------------------------------------------------------------------ segment reduce
+ * Replaces dgl.nn.AvgPooling / dgl.ops.segment_reduce (main_dgl_molhiv_gcn.py:75,93).
+ * offsets: int64 [num_segments+1] (cumsum of batch_num_nodes).  reduce: SUM, MEAN, MAX, MIN.
+ * arg (int64 [num_segments*D], MAX/MIN only) may be NULL. */
+int32_t mgx_segment_reduce(int64_t num_segments, const int64_t* offsets, int64_t D, int32_t reduce,
+                           const float* x, float* out, int64_t* arg, void* stream);
+
+/* ------------------------------------------------------------------ formats (integer, bit-exact)
+ * Replace the lazy COO->CSR/CSC construction behind g.formats(...)/first kernel call
+ * (main_dgl_product_sage.py:158, kernel/dgl-new.py:63) and g.in_degrees()
+ * (main_dgl_molhiv_gcn.py:41).
+ *
+ * mgx_coo_to_csr: stable sort of the COO by `row` (edge-id order kept inside a row).
+ *   For the in-CSR pass row = dst, col = src.  Outputs indptr[num_rows+1], indices[nnz],
+ *   eids[nnz] in the same index width.  `workspace` of mgx_coo_to_csr_workspace() bytes. */
+int64_t mgx_coo_to_csr_workspace(int64_t num_rows, int64_t nnz, int32_t idx_bits);
+int32_t mgx_coo_to_csr(int64_t num_rows, int64_t nnz, const void* row, const void* col, int32_t idx_bits,
+                       void* indptr, void* indices, void* eids,
+                       void* workspace, int64_t workspace_bytes, void* stream);
+/* in_degrees / out_degrees from a CSR: deg[v] = indptr[v+1]-indptr[v] (graph index width). */
+int32_t mgx_csr_degrees(int64_t num_rows, const void* indptr, int32_t idx_bits, void* deg, void* stream);
+/* inv_deg[v] = 1 / max(deg,1) as fp32 (the factor of fn.mean and of its backward). */
+int32_t mgx_csr_inv_degrees(int64_t num_rows, const void* indptr, int32_t idx_bits, float* inv_deg, void* stream);
+
+/* Host-side (CPU pointers, no GPU needed) stable COO->CSR used when a graph is prepared on the
+ * CPU before .to(device) (main_dgl_product_sage.py:158 does formats() before to()). */
+int32_t mgx_coo_to_csr_host(int64_t num_rows, int64_t nnz, const void* row_host, const void* col_host,
+                            int32_t idx_bits, void* indptr_host, void* indices_host, void* eids_host);
+
+/* ------------------------------------------------------------------ halo exchange helpers (multi-GPU)
+ * New capability (the reference is single-GPU): pack boundary rows for the RCCL all_to_all and
+ * add received gradient rows back into their owners.
+ *   gather_rows:      out[i,:]      = x[idx[i],:]
+ *   scatter_add_rows: x[idx[i],:]  += in[i,:]   (idx sorted & unique per call => no atomics) */
+int32_t mgx_gather_rows(int64_t n, const void* idx, int32_t idx_bits, int64_t D,
+                        const float* x, float* out, void* stream);
+int32_t mgx_scatter_add_rows(int64_t n, const void* idx, int32_t idx_bits, int64_t D,
+                             const float* in, float* x, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_GRAPH_H_ */
