@@ -1,0 +1,110 @@
+"""Kernel micro-benchmark -- this backend's counterpart of the reference's kernel/dgl-new.py.
+
+Same loop (kernel/dgl-new.py:10-46): for hidden in 1..128 time dgl.ops.gspmm / dgl.ops.gsddmm
+10 times with device events (kernel/utils.py:18-34), discard the first 2 (cold start, hides the
+lazy CSC build).  NOTE: the reference divides the sum of 8 samples by 7 (`n_times - n_cold_start`
+with n_times == 9 after the loop, kernel/dgl-new.py:21-23); this script reports the true mean of 8.
+Datasets are the seeded synthetic stand-ins of mi355x_graph.datasets (no network here).
+Adds what the reference never printed: edges/s and algorithmic GB/s vs the 8 TB/s HBM roofline.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dgl  # noqa: E402
+import dgl.ops  # noqa: E402
+from mi355x_graph.datasets import SHAPES, synthetic_edges  # noqa: E402
+
+N_COLD = 2
+HBM_PEAK = 8.0e12
+
+
+def time_op(fn, reps=10):
+    times = []
+    for i in range(reps):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        torch.cuda.synchronize()
+        if i >= N_COLD:
+            times.append(s.elapsed_time(e) / 1e3)
+    return sum(times) / len(times), min(times)
+
+
+def spmm_bytes(n_dst, n_src, nnz, D, op):
+    b = 4 * (n_dst + 1) + 4 * nnz + 4 * n_src * D + 4 * n_dst * D  # compulsory traffic
+    if op != "copy_lhs":
+        b += 4 * nnz * D + 4 * nnz
+    return b
+
+
+def sddmm_bytes(n_src, n_dst, nnz, D, op):
+    return 8 * nnz + 4 * n_src * D + 4 * n_dst * D + 4 * nnz * (1 if op == "dot" else D)
+
+
+def get_graph(name, device, scale):
+    spec = SHAPES[name]
+    n, m = int(spec["n"] * scale), int(spec["m"] * scale)
+    src, dst = synthetic_edges(n, m, min(spec["max_deg"], n - 1), spec["seed"], device, symmetric=spec["symmetric"])
+    return dgl.graph((src, dst), num_nodes=n)
+
+
+def main():
+    p = argparse.ArgumentParser("Benchmark MI355X message-passing kernels")
+    p.add_argument("--spmm-binary", type=str, default="copy_lhs")
+    p.add_argument("--spmm-reduce", type=str, default="sum")
+    p.add_argument("--sddmm-binary", type=str, default="add")
+    p.add_argument("--gpu", "-g", type=str, default="0")
+    p.add_argument("--datasets", type=str, default="reddit-small,arxiv,proteins")
+    p.add_argument("--hidden", type=str, default="1,2,4,8,16,32,64,128")
+    p.add_argument("--scale", type=float, default=1.0)
+    p.add_argument("--no-sddmm", action="store_true")
+    p.add_argument("--json", type=str, default=None)
+    args = p.parse_args()
+    if args.gpu == "-1":
+        raise SystemExit("this backend has no CPU path; run the CPU oracle through bench.py's cpu_baseline leg")
+    ctx = torch.device("cuda:%d" % int(args.gpu))
+    results = []
+    for ds in args.datasets.split(","):
+        g = get_graph(ds, ctx, args.scale).int().to(ctx)
+        print(g)
+        n_src, n_dst, nnz = g.number_of_src_nodes(), g.number_of_dst_nodes(), g.number_of_edges()
+        print("SPMM\n----------------------------")
+        with torch.no_grad():
+            for n_hid in [int(h) for h in args.hidden.split(",")]:
+                nfeat = torch.rand(n_src, n_hid, device=ctx)
+                efeat = torch.rand(nnz, n_hid, device=ctx) if args.spmm_binary != "copy_lhs" else None
+                avg, best = time_op(lambda: dgl.ops.gspmm(g, args.spmm_binary, args.spmm_reduce, nfeat, efeat))
+                gbs = spmm_bytes(n_dst, n_src, nnz, n_hid, args.spmm_binary) / avg / 1e9
+                print("hidden size: {}, avg time: {:.6f}  ({:.2f} Gedges/s, {:.0f} GB/s algorithmic = {:.1%} of HBM peak; gather {:.0f} GB/s)".format(
+                    n_hid, avg, nnz / avg / 1e9, gbs, gbs * 1e9 / HBM_PEAK, nnz * n_hid * 4 / avg / 1e9))
+                results.append(dict(dataset=ds, kernel="spmm", op=args.spmm_binary, reduce=args.spmm_reduce, hidden=n_hid,
+                                    avg_s=avg, min_s=best, edges_per_s=nnz / avg, algo_GBps=gbs))
+                del nfeat, efeat
+        if not args.no_sddmm:
+            print("SDDMM\n----------------------------")
+            with torch.no_grad():
+                for n_hid in [int(h) for h in args.hidden.split(",")]:
+                    ufeat = torch.rand(n_src, n_hid, device=ctx)
+                    vfeat = torch.rand(n_dst, n_hid, device=ctx)
+                    avg, best = time_op(lambda: dgl.ops.gsddmm(g, args.sddmm_binary, ufeat, vfeat))
+                    gbs = sddmm_bytes(n_src, n_dst, nnz, n_hid, args.sddmm_binary) / avg / 1e9
+                    print("hidden size: {}, avg time: {:.6f}  ({:.2f} Gedges/s, {:.0f} GB/s algorithmic = {:.1%} of HBM peak)".format(
+                        n_hid, avg, nnz / avg / 1e9, gbs, gbs * 1e9 / HBM_PEAK))
+                    results.append(dict(dataset=ds, kernel="sddmm", op=args.sddmm_binary, hidden=n_hid, avg_s=avg,
+                                        min_s=best, edges_per_s=nnz / avg, algo_GBps=gbs))
+                    del ufeat, vfeat
+        del g
+        torch.cuda.empty_cache()
+    if args.json:
+        with open(args.json, "w") as f:
+            json.dump(results, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

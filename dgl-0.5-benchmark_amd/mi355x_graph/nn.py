@@ -1,0 +1,268 @@
+"""dgl.nn.pytorch modules used by the benchmark scripts, written against this backend's ops:
+  GATConv    main_dgl_reddit_gat.py:10,31-55 (u_add_v SDDMM + fused edge_softmax + u_mul_e/sum SpMM)
+  SAGEConv   main_dgl_arxiv_sage_nn.py:9,27-34
+  GraphConv  main_dgl_enzymes_gcn_nn.py:12,29-36
+  AvgPooling / SumPooling / MaxPooling   main_dgl_molhiv_gcn.py:75,93
+Parameter names, shapes and initialisation follow DGL v0.6.x so state_dicts and the scripts'
+reset_parameters() calls (main_dgl_reddit_gat.py:57-59) line up.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._lib import DGLError
+from . import function as fn
+from . import ops
+from .utils import expand_as_pair
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class GATConv(nn.Module):
+    def __init__(self, in_feats, out_feats, num_heads, feat_drop=0., attn_drop=0., negative_slope=0.2,
+                 residual=False, activation=None, allow_zero_in_degree=False, bias=True):
+        super(GATConv, self).__init__()
+        self._num_heads = num_heads
+        self._in_src_feats, self._in_dst_feats = expand_as_pair(in_feats)
+        self._out_feats = out_feats
+        self._allow_zero_in_degree = allow_zero_in_degree
+        if isinstance(in_feats, tuple):
+            self.fc_src = nn.Linear(self._in_src_feats, out_feats * num_heads, bias=False)
+            self.fc_dst = nn.Linear(self._in_dst_feats, out_feats * num_heads, bias=False)
+        else:
+            self.fc = nn.Linear(self._in_src_feats, out_feats * num_heads, bias=False)
+        self.attn_l = nn.Parameter(torch.FloatTensor(size=(1, num_heads, out_feats)))
+        self.attn_r = nn.Parameter(torch.FloatTensor(size=(1, num_heads, out_feats)))
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.leaky_relu = nn.LeakyReLU(negative_slope)
+        if bias:
+            self.bias = nn.Parameter(torch.FloatTensor(size=(num_heads * out_feats,)))
+        else:
+            self.register_buffer("bias", None)
+        if residual:
+            if self._in_dst_feats != out_feats:
+                self.res_fc = nn.Linear(self._in_dst_feats, num_heads * out_feats, bias=False)
+            else:
+                self.res_fc = Identity()
+        else:
+            self.register_buffer("res_fc", None)
+        self.reset_parameters()
+        self.activation = activation
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        if hasattr(self, "fc"):
+            nn.init.xavier_normal_(self.fc.weight, gain=gain)
+        else:
+            nn.init.xavier_normal_(self.fc_src.weight, gain=gain)
+            nn.init.xavier_normal_(self.fc_dst.weight, gain=gain)
+        nn.init.xavier_normal_(self.attn_l, gain=gain)
+        nn.init.xavier_normal_(self.attn_r, gain=gain)
+        if self.bias is not None:
+            nn.init.constant_(self.bias, 0)
+        if isinstance(self.res_fc, nn.Linear):
+            nn.init.xavier_normal_(self.res_fc.weight, gain=gain)
+
+    def set_allow_zero_in_degree(self, set_value):
+        self._allow_zero_in_degree = set_value
+
+    def forward(self, graph, feat, get_attention=False):
+        with graph.local_scope():
+            if not self._allow_zero_in_degree:
+                if bool((graph.in_degrees() == 0).any()):
+                    raise DGLError(
+                        "There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
+                        "This is harmful for some applications, causing silent performance regression. "
+                        "Adding self-loop on the input graph by calling `g = dgl.add_self_loop(g)` will resolve "
+                        "the issue. Setting ``allow_zero_in_degree`` to be `True` when constructing this module "
+                        "will suppress the check and let the code run.")
+            if isinstance(feat, tuple):
+                h_src = self.feat_drop(feat[0])
+                h_dst = self.feat_drop(feat[1])
+                if not hasattr(self, "fc_src"):
+                    feat_src = self.fc(h_src).view(-1, self._num_heads, self._out_feats)
+                    feat_dst = self.fc(h_dst).view(-1, self._num_heads, self._out_feats)
+                else:
+                    feat_src = self.fc_src(h_src).view(-1, self._num_heads, self._out_feats)
+                    feat_dst = self.fc_dst(h_dst).view(-1, self._num_heads, self._out_feats)
+            else:
+                h_src = h_dst = self.feat_drop(feat)
+                feat_src = feat_dst = self.fc(h_src).view(-1, self._num_heads, self._out_feats)
+                if graph.is_block:
+                    feat_dst = feat_src[:graph.number_of_dst_nodes()]
+                    h_dst = h_dst[:graph.number_of_dst_nodes()]
+            el = (feat_src * self.attn_l).sum(dim=-1).unsqueeze(-1)
+            er = (feat_dst * self.attn_r).sum(dim=-1).unsqueeze(-1)
+            graph.srcdata.update({"ft": feat_src, "el": el})
+            graph.dstdata.update({"er": er})
+            graph.apply_edges(fn.u_add_v("el", "er", "e"))
+            e = self.leaky_relu(graph.edata.pop("e"))
+            graph.edata["a"] = self.attn_drop(ops.edge_softmax(graph, e))
+            graph.update_all(fn.u_mul_e("ft", "a", "m"), fn.sum("m", "ft"))
+            rst = graph.dstdata["ft"]
+            if self.res_fc is not None:
+                resval = self.res_fc(h_dst).view(h_dst.shape[0], -1, self._out_feats)
+                rst = rst + resval
+            if self.bias is not None:
+                rst = rst + self.bias.view(1, self._num_heads, self._out_feats)
+            if self.activation:
+                rst = self.activation(rst)
+            if get_attention:
+                return rst, graph.edata["a"]
+            return rst
+
+
+class SAGEConv(nn.Module):
+    def __init__(self, in_feats, out_feats, aggregator_type, feat_drop=0., bias=True, norm=None, activation=None):
+        super(SAGEConv, self).__init__()
+        if aggregator_type not in ("mean", "gcn", "pool"):
+            raise DGLError("Unsupported aggregator type %r on this backend (mean, gcn, pool)" % (aggregator_type,))
+        self._in_src_feats, self._in_dst_feats = expand_as_pair(in_feats)
+        self._out_feats = out_feats
+        self._aggre_type = aggregator_type
+        self.norm = norm
+        self.feat_drop = nn.Dropout(feat_drop)
+        self.activation = activation
+        if aggregator_type == "pool":
+            self.fc_pool = nn.Linear(self._in_src_feats, self._in_src_feats)
+        if aggregator_type != "gcn":
+            self.fc_self = nn.Linear(self._in_dst_feats, out_feats, bias=bias)
+        self.fc_neigh = nn.Linear(self._in_src_feats, out_feats, bias=bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        if self._aggre_type == "pool":
+            nn.init.xavier_uniform_(self.fc_pool.weight, gain=gain)
+        if self._aggre_type != "gcn":
+            nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
+        nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
+
+    def forward(self, graph, feat):
+        with graph.local_scope():
+            if isinstance(feat, tuple):
+                feat_src = self.feat_drop(feat[0])
+                feat_dst = self.feat_drop(feat[1])
+            else:
+                feat_src = feat_dst = self.feat_drop(feat)
+                if graph.is_block:
+                    feat_dst = feat_src[:graph.number_of_dst_nodes()]
+            h_self = feat_dst
+            if graph.number_of_edges() == 0:
+                graph.dstdata["neigh"] = torch.zeros(feat_dst.shape[0], self._in_src_feats).to(feat_dst)
+            # aggregate after the projection when that moves fewer bytes (DGL's lin_before_mp)
+            lin_before_mp = self._in_src_feats > self._out_feats
+            if self._aggre_type == "mean":
+                graph.srcdata["h"] = self.fc_neigh(feat_src) if lin_before_mp else feat_src
+                graph.update_all(fn.copy_src("h", "m"), fn.mean("m", "neigh"))
+                h_neigh = graph.dstdata["neigh"]
+                if not lin_before_mp:
+                    h_neigh = self.fc_neigh(h_neigh)
+            elif self._aggre_type == "gcn":
+                graph.srcdata["h"] = feat_src
+                graph.dstdata["h"] = feat_dst
+                graph.update_all(fn.copy_src("h", "m"), fn.sum("m", "neigh"))
+                degs = graph.in_degrees().to(feat_dst)
+                h_neigh = (graph.dstdata["neigh"] + graph.dstdata["h"]) / (degs.unsqueeze(-1) + 1)
+                h_neigh = self.fc_neigh(h_neigh)
+            else:  # pool
+                graph.srcdata["h"] = F.relu(self.fc_pool(feat_src))
+                graph.update_all(fn.copy_src("h", "m"), fn.max("m", "neigh"))
+                h_neigh = self.fc_neigh(graph.dstdata["neigh"])
+            rst = h_neigh if self._aggre_type == "gcn" else self.fc_self(h_self) + h_neigh
+            if self.activation is not None:
+                rst = self.activation(rst)
+            if self.norm is not None:
+                rst = self.norm(rst)
+            return rst
+
+
+class GraphConv(nn.Module):
+    def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None,
+                 allow_zero_in_degree=False):
+        super(GraphConv, self).__init__()
+        if norm not in ("none", "both", "right"):
+            raise DGLError('Invalid norm value. Must be either "none", "both" or "right". But got "%s".' % norm)
+        self._in_feats, self._out_feats, self._norm = in_feats, out_feats, norm
+        self._allow_zero_in_degree = allow_zero_in_degree
+        if weight:
+            self.weight = nn.Parameter(torch.Tensor(in_feats, out_feats))
+        else:
+            self.register_parameter("weight", None)
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_feats))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+        self._activation = activation
+
+    def reset_parameters(self):
+        if self.weight is not None:
+            nn.init.xavier_uniform_(self.weight)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def set_allow_zero_in_degree(self, set_value):
+        self._allow_zero_in_degree = set_value
+
+    def forward(self, graph, feat, weight=None):
+        with graph.local_scope():
+            if not self._allow_zero_in_degree and bool((graph.in_degrees() == 0).any()):
+                raise DGLError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
+                               "Adding self-loop on the input graph by calling `g = dgl.add_self_loop(g)` will "
+                               "resolve the issue. Setting ``allow_zero_in_degree`` to be `True` when constructing "
+                               "this module will suppress the check and let the code run.")
+            feat_src, feat_dst = expand_as_pair(feat, graph)
+            if self._norm == "both":
+                degs = graph.out_degrees().to(feat_src).clamp(min=1)
+                norm = torch.pow(degs, -0.5)
+                feat_src = feat_src * norm.view((-1,) + (1,) * (feat_src.dim() - 1))
+            if weight is not None and self.weight is not None:
+                raise DGLError("External weight is provided while at the same time the module has defined its own "
+                               "weight parameter. Please create the module with flag weight=False.")
+            weight = self.weight if weight is None else weight
+            if self._in_feats > self._out_feats:
+                if weight is not None:
+                    feat_src = torch.matmul(feat_src, weight)
+                graph.srcdata["h"] = feat_src
+                graph.update_all(fn.copy_src(src="h", out="m"), fn.sum(msg="m", out="h"))
+                rst = graph.dstdata["h"]
+            else:
+                graph.srcdata["h"] = feat_src
+                graph.update_all(fn.copy_src(src="h", out="m"), fn.sum(msg="m", out="h"))
+                rst = graph.dstdata["h"]
+                if weight is not None:
+                    rst = torch.matmul(rst, weight)
+            if self._norm != "none":
+                degs = graph.in_degrees().to(feat_dst).clamp(min=1)
+                norm = torch.pow(degs, -0.5) if self._norm == "both" else 1.0 / degs
+                rst = rst * norm.view((-1,) + (1,) * (feat_dst.dim() - 1))
+            if self.bias is not None:
+                rst = rst + self.bias
+            if self._activation is not None:
+                rst = self._activation(rst)
+            return rst
+
+
+class _Pooling(nn.Module):
+    _op = "sum"
+
+    def forward(self, graph, feat):
+        return ops.segment_reduce(graph.batch_num_nodes(), feat, self._op)
+
+
+class SumPooling(_Pooling):
+    _op = "sum"
+
+
+class AvgPooling(_Pooling):
+    """Per-graph mean of node features (main_dgl_molhiv_gcn.py:75,93)."""
+    _op = "mean"
+
+
+class MaxPooling(_Pooling):
+    _op = "max"

@@ -1,0 +1,326 @@
+"""GPU suite (-m gpu): the HIP library, called through its C ABI, against the CPU oracle and the
+committed golden vectors.  Bar (north_star): index/degree ops bit-exact; fp32 aggregations within
+1e-4 relative of the reference CPU algorithm.  All sizes finish in seconds on the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mi355x_graph as mg
+from mi355x_graph import ops, sparse
+from conftest import random_graph
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+RTOL = 1e-4  # north_star: fp32 aggregations within 1e-4 relative
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + 1e-5))) if a.size else 0.0
+
+
+def mk(n_src, n_dst, src, dst, idtype=torch.int32, formats=None):
+    g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=idtype, device=DEV)
+    return g.formats(formats) if formats else g
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_library_is_loaded_and_sees_gfx950():
+    import ctypes
+    L = mg._lib.lib()
+    cus, lds = ctypes.c_int32(), ctypes.c_int32()
+    name = ctypes.create_string_buffer(64)
+    mg._lib.check(L.mgx_device_info(ctypes.byref(cus), ctypes.byref(lds), name, 64))
+    assert name.value.decode().startswith("gfx950"), name.value
+    assert cus.value == 256
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("shape", [(1, 1, 0), (7, 5, 3), (1000, 1000, 30000), (5000, 300, 200000), (300, 5000, 20000)])
+def test_device_coo_to_csr_and_degrees_bit_exact(oracle, idtype, shape):
+    n_src, n_dst, nnz = shape
+    src, dst = random_graph(n_src, n_dst, nnz, seed=nnz + 1)
+    g = mk(n_src, n_dst, src, dst, idtype)
+    csc, csr = g._index.csc(), g._index.csr()
+    ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
+    assert np.array_equal(csc.indptr.cpu().numpy(), ip)
+    assert np.array_equal(csc.indices.cpu().numpy(), ix)
+    assert np.array_equal(csc.eids.cpu().numpy(), ei)
+    rp, rx, re = oracle.coo_to_csr(n_src, src, dst)
+    assert np.array_equal(csr.indptr.cpu().numpy(), rp) and np.array_equal(csr.indices.cpu().numpy(), rx)
+    assert np.array_equal(csr.eids.cpu().numpy(), re)
+    deg = g.in_degrees()
+    assert deg.dtype == idtype and np.array_equal(deg.cpu().numpy(), oracle.in_degrees(ip))
+    assert np.array_equal(g.out_degrees().cpu().numpy(), np.diff(rp))
+    # host-built CSR moved to the device gives the same arrays
+    gh = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=idtype)
+    gh = gh.formats(["csr", "csc"]).to(DEV)
+    assert torch.equal(gh._index.csc().indices, csc.indices) and torch.equal(gh._index.csc().eids, csc.eids)
+
+
+@pytest.mark.parametrize("name", ["tiny", "g200", "bip", "cora_like"])
+def test_golden_vectors(name):
+    g = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    if name == "tiny":
+        gr = mk(5, 5, g["src"], g["dst"])
+        out = ops.gspmm(gr, "copy_lhs", "sum", T(g["X"]), None)
+        assert np.array_equal(out.cpu().numpy(), g["copy_u_sum"])  # small integers: exact in any order
+        assert np.array_equal(gr.in_degrees().cpu().numpy(), g["in_degrees"])
+        return
+    n_src, n_dst = int(g["n_src"]), int(g["n_dst"])
+    gr = mk(n_src, n_dst, g["src"], g["dst"])
+    X, V = T(g["X"]), T(g["V"])
+    assert rel(ops.gspmm(gr, "copy_lhs", "sum", X, None).cpu(), g["copy_u_sum"]) < RTOL
+    assert rel(ops.gspmm(gr, "copy_lhs", "mean", X, None).cpu(), g["copy_u_mean"]) < RTOL
+    H = g["W"].shape[1]
+    assert rel(ops.gspmm(gr, "mul", "sum", X.view(n_src, H, -1), T(g["W"])).cpu(), g["u_mul_e_sum_f64"]) < RTOL
+    assert np.array_equal(ops.gspmm(gr, "copy_lhs", "max", X, None).cpu().numpy(), g["copy_u_max"])
+    assert np.array_equal(ops.gsddmm(gr, "add", X, V).cpu().numpy(), g["u_add_v"])
+    assert np.array_equal(ops.gsddmm(gr, "mul", X, V).cpu().numpy(), g["u_mul_v"])
+    assert rel(ops.gsddmm(gr, "dot", X, V).cpu(), g["u_dot_v_f64"]) < RTOL
+    a = ops.edge_softmax(gr, T(g["Z"]))
+    assert rel(a.cpu(), g["edge_softmax_f64"]) < RTOL
+    dz = sparse.edge_softmax_bwd_raw(gr._index.csc(), T(g["edge_softmax_f64"].astype(np.float32)), T(g["dA"]))
+    assert float(np.max(np.abs(dz.cpu().numpy() - g["edge_softmax_bwd_f64"]))) < 1e-5
+
+
+SPMM_SHAPES = [
+    # (n_src, n_dst, nnz, D)  -- D sweeps kernel/dgl-new.py:13 (1..128) plus odd / wide rows
+    (500, 500, 6000, 1), (500, 500, 6000, 2), (500, 500, 6000, 4), (500, 500, 6000, 8),
+    (500, 500, 6000, 16), (2000, 2000, 60000, 32), (2000, 2000, 100000, 64), (2000, 2000, 30000, 100),
+    (2000, 2000, 30000, 128), (1500, 700, 20000, 256), (300, 300, 2000, 602), (200, 200, 1500, 1433),
+    (400, 400, 3000, 7), (400, 400, 3000, 6), (50, 5000, 4000, 64), (3000, 40, 150000, 64),
+]
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("shape", SPMM_SHAPES)
+def test_copy_u_sum_and_mean(oracle, shape, idtype):
+    n_src, n_dst, nnz, D = shape
+    src, dst = random_graph(n_src, n_dst, nnz, seed=D)
+    rng = np.random.default_rng(D)
+    X = rng.random((n_src, D), dtype=np.float32)  # U[0,1) as kernel/dgl-new.py:15
+    g = mk(n_src, n_dst, src, dst, idtype)
+    ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
+    for red in ("sum", "mean"):
+        out = ops.gspmm(g, "copy_lhs", red, T(X), None)
+        assert out.shape == (n_dst, D)
+        assert rel(out.cpu(), oracle.spmm(ip, ix, ei, "copy_lhs", red, X, None)) < RTOL
+    # determinism: no atomics => bitwise identical reruns
+    assert torch.equal(ops.gspmm(g, "copy_lhs", "sum", T(X), None), ops.gspmm(g, "copy_lhs", "sum", T(X), None))
+
+
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "copy_lhs", "copy_rhs"])
+@pytest.mark.parametrize("red", ["sum", "max", "min", "mean"])
+def test_gspmm_all_ops_all_reducers(oracle, op, red):
+    """kernel/dgl-new.py:50-51 lets any op x reduce through; efeat has the node feature's width."""
+    n_src, n_dst, nnz, D = 700, 600, 9000, 12
+    src, dst = random_graph(n_src, n_dst, nnz, seed=17)
+    rng = np.random.default_rng(17)
+    X = rng.random((n_src, D), dtype=np.float32)
+    E = rng.random((nnz, D), dtype=np.float32) + 0.5
+    g = mk(n_src, n_dst, src, dst)
+    ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
+    out = ops.gspmm(g, op, red, T(X), T(E))
+    ref = oracle.spmm(ip, ix, ei, op, red, X, E)
+    assert rel(out.cpu(), ref) < RTOL
+
+
+@pytest.mark.parametrize("H,F", [(1, 16), (4, 8), (8, 16), (3, 5), (8, 1), (1, 1)])
+def test_u_mul_e_head_broadcast(oracle, H, F):
+    n, nnz = 900, 15000
+    src, dst = random_graph(n, n, nnz, seed=H * 10 + F)
+    rng = np.random.default_rng(H)
+    X = rng.random((n, H, F), dtype=np.float32)
+    W = rng.random((nnz, H, 1), dtype=np.float32)
+    g = mk(n, n, src, dst)
+    ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+    out = ops.gspmm(g, "mul", "sum", T(X), T(W))
+    assert out.shape == (n, H, F)
+    assert rel(out.cpu(), oracle.spmm(ip, ix, ei, "mul", "sum", X, W)) < RTOL
+    # (N,D) x (E,1) of main_dgl_proteins_rgcn_for.py:52
+    X2, W2 = X.reshape(n, H * F), W[:, 0, :]
+    out = ops.gspmm(g, "mul", "mean", T(X2), T(W2))
+    assert rel(out.cpu(), oracle.spmm(ip, ix, ei, "mul", "mean", X2, W2)) < RTOL
+
+
+def test_general_broadcast_tables(oracle):
+    n, nnz = 300, 4000
+    src, dst = random_graph(n, n, nnz, seed=5)
+    rng = np.random.default_rng(5)
+    X = rng.random((n, 1, 6), dtype=np.float32)
+    E = rng.random((nnz, 4, 1), dtype=np.float32)
+    g = mk(n, n, src, dst)
+    ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+    for op in ("add", "mul"):
+        out = ops.gspmm(g, op, "sum", T(X), T(E))
+        assert out.shape == (n, 4, 6)
+        assert rel(out.cpu(), oracle.spmm(ip, ix, ei, op, "sum", X, E)) < RTOL
+    out = ops.gsddmm(g, "mul", T(X), T(rng.random((n, 4, 1), dtype=np.float32)))
+    assert out.shape == (nnz, 4, 6)
+
+
+def test_max_min_arg_indices_exact(oracle):
+    n_src, n_dst, nnz, D = 400, 500, 5000, 9
+    src, dst = random_graph(n_src, n_dst, nnz, seed=23)
+    rng = np.random.default_rng(23)
+    X = rng.random((n_src, D), dtype=np.float32)
+    g = mk(n_src, n_dst, src, dst)
+    csc = g._index.csc()
+    ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
+    for red in ("max", "min"):
+        out, au, ae = sparse.gspmm_raw(csc, "copy_lhs", red, T(X), None, want_arg=True)
+        ref, ru, _ = oracle.spmm(ip, ix, ei, "copy_lhs", red, X, None, want_arg=True)
+        assert np.array_equal(out.cpu().numpy(), ref)
+        assert np.array_equal(au.cpu().numpy(), ru)
+
+
+SDDMM_SHAPES = [(600, 600, 8000, 1), (600, 600, 8000, 2), (600, 600, 8000, 16), (600, 500, 8000, 64),
+                (300, 400, 5000, 128), (300, 300, 3000, 7), (200, 200, 1000, 300)]
+
+
+@pytest.mark.parametrize("fmt", ["coo", "csr_csc"])
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "dot", "copy_lhs", "copy_rhs"])
+@pytest.mark.parametrize("shape", SDDMM_SHAPES)
+def test_gsddmm(oracle, shape, op, fmt):
+    n_src, n_dst, nnz, D = shape
+    src, dst = random_graph(n_src, n_dst, nnz, seed=D + 3)
+    rng = np.random.default_rng(D)
+    U = rng.random((n_src, D), dtype=np.float32)
+    V = rng.random((n_dst, D), dtype=np.float32) + 0.5
+    g = mk(n_src, n_dst, src, dst, formats=["csr", "csc"] if fmt == "csr_csc" else None)
+    out = ops.gsddmm(g, op, T(U), T(V))
+    ref = oracle.sddmm(src, dst, op, U, V)
+    assert out.shape == ref.shape
+    if op == "dot":
+        assert rel(out.cpu(), ref) < RTOL
+    else:
+        assert np.array_equal(out.cpu().numpy(), ref)  # one rounding per element: bit-exact
+
+
+def test_gsddmm_targets_and_heads(oracle):
+    n, nnz, H, F = 500, 7000, 4, 8
+    src, dst = random_graph(n, n, nnz, seed=9)
+    rng = np.random.default_rng(9)
+    U = rng.random((n, H, F), dtype=np.float32)
+    V = rng.random((n, H, F), dtype=np.float32)
+    Ee = rng.random((nnz, H, 1), dtype=np.float32)
+    g = mk(n, n, src, dst)
+    assert rel(ops.gsddmm(g, "dot", T(U), T(V)).cpu(), oracle.sddmm(src, dst, "dot", U, V)) < RTOL
+    out = ops.gsddmm(g, "mul", T(Ee), T(V), "e", "v")
+    assert np.array_equal(out.cpu().numpy(), oracle.sddmm(src, dst, "mul", Ee, V, "e", "v"))
+    out = ops.gsddmm(g, "sub", T(V), T(U), "v", "u")
+    assert np.array_equal(out.cpu().numpy(), oracle.sddmm(src, dst, "sub", V, U, "v", "u"))
+    el, er = rng.random((n, H, 1), dtype=np.float32), rng.random((n, H, 1), dtype=np.float32)
+    out = ops.gsddmm(g, "add", T(el), T(er))  # GATConv's u_add_v
+    assert np.array_equal(out.cpu().numpy(), oracle.sddmm(src, dst, "add", el, er))
+
+
+@pytest.mark.parametrize("H", [1, 2, 3, 4, 8, 16, 64])
+def test_edge_softmax_fwd_bwd(oracle, H):
+    n, nnz = 800, 30000
+    src, dst = random_graph(n, n, nnz, seed=H)
+    rng = np.random.default_rng(H)
+    Z = (rng.standard_normal((nnz, H)) * 4).astype(np.float32)
+    dA = rng.standard_normal((nnz, H)).astype(np.float32)
+    g = mk(n, n, src, dst)
+    ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+    z = T(Z).requires_grad_(True)
+    a = ops.edge_softmax(g, z)
+    ref = oracle.edge_softmax_fwd(ip, ei, Z)
+    assert rel(a.detach().cpu(), ref) < RTOL
+    a.backward(T(dA))
+    ref_dz = oracle.edge_softmax_bwd(ip, ei, ref, dA)
+    assert float(np.max(np.abs(z.grad.cpu().numpy() - ref_dz))) < 1e-5
+    # (E,H,1) logits as GATConv passes them
+    a3 = ops.edge_softmax(g, T(Z).view(nnz, H, 1))
+    assert torch.equal(a3.view(nnz, H), a.detach())
+
+
+@pytest.mark.parametrize("red", ["sum", "mean", "max", "min"])
+def test_segment_reduce(oracle, red):
+    rng = np.random.default_rng(1)
+    lens = rng.integers(0, 60, size=300)
+    lens[5] = 0
+    x = rng.random((int(lens.sum()), 256), dtype=np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    out = ops.segment_reduce(T(lens), T(x), red)
+    assert rel(out.cpu(), oracle.segment_reduce(off, x, red)) < RTOL
+
+
+def test_edge_cases(oracle):
+    # empty graph, graph without edges, single hub row longer than any cache
+    g = mk(4, 4, np.zeros(0, np.int64), np.zeros(0, np.int64))
+    out = ops.gspmm(g, "copy_lhs", "sum", torch.rand(4, 8, device=DEV), None)
+    assert out.shape == (4, 8) and float(out.abs().sum()) == 0.0
+    assert ops.gsddmm(g, "add", torch.rand(4, 8, device=DEV), torch.rand(4, 8, device=DEV)).shape == (0, 8)
+    n, nnz = 50, 40000
+    rng = np.random.default_rng(2)
+    src = rng.integers(0, n, nnz)
+    dst = np.zeros(nnz, np.int64)  # one hub
+    X = rng.random((n, 64), dtype=np.float32)
+    g = mk(n, n, src, dst)
+    ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+    assert rel(ops.gspmm(g, "copy_lhs", "sum", T(X), None).cpu(), oracle.spmm(ip, ix, ei, "copy_lhs", "sum", X, None)) < RTOL
+    Z = rng.standard_normal((nnz, 2)).astype(np.float32)
+    assert rel(ops.edge_softmax(g, T(Z)).cpu(), oracle.edge_softmax_fwd(ip, ei, Z)) < RTOL
+    with pytest.raises(mg.DGLError):
+        ops.gspmm(g, "copy_lhs", "sum", torch.rand(n + 1, 4, device=DEV), None)
+    with pytest.raises(mg.DGLError):
+        ops.gspmm(g, "pow", "sum", T(X), None)
+    with pytest.raises(mg.DGLError):
+        ops.gspmm(g, "copy_lhs", "sum", T(X).double(), None)
+
+
+def test_autograd_against_dense_torch():
+    """Backward formulas vs torch autograd on the gathered/dense formulation."""
+    n, nnz, H, F = 120, 1500, 2, 4
+    src, dst = random_graph(n, n, nnz, seed=31)
+    g = mk(n, n, src, dst)
+    s, d = T(src), T(dst)
+    torch.manual_seed(0)
+
+    def check(fn_ours, fn_ref, *shapes):
+        xs = [torch.rand(*sh, device=DEV, requires_grad=True) for sh in shapes]
+        ys = [x.detach().clone().requires_grad_(True) for x in xs]
+        a, b = fn_ours(*xs), fn_ref(*ys)
+        assert rel(a.detach().cpu(), b.detach().cpu()) < RTOL
+        w = torch.rand_like(a)
+        (a * w).sum().backward()
+        (b * w).sum().backward()
+        for x, y in zip(xs, ys):
+            assert rel(x.grad.cpu(), y.grad.cpu()) < 1e-3
+
+    def agg(msg):
+        out = torch.zeros((n,) + msg.shape[1:], device=DEV)
+        return out.index_add(0, d, msg)
+
+    deg = torch.bincount(d, minlength=n).clamp(min=1).float()
+    check(lambda x: ops.gspmm(g, "copy_lhs", "sum", x, None), lambda x: agg(x[s]), (n, 8))
+    check(lambda x: ops.gspmm(g, "copy_lhs", "mean", x, None), lambda x: agg(x[s]) / deg[:, None], (n, 8))
+    check(lambda x, w: ops.gspmm(g, "mul", "sum", x, w), lambda x, w: agg(x[s] * w), (n, H, F), (nnz, H, 1))
+    check(lambda x, w: ops.gspmm(g, "mul", "mean", x, w), lambda x, w: agg(x[s] * w) / deg[:, None], (n, 6), (nnz, 1))
+    check(lambda x, w: ops.gspmm(g, "add", "sum", x, w), lambda x, w: agg(x[s] + w), (n, 6), (nnz, 6))
+    check(lambda w: ops.gspmm(g, "copy_rhs", "sum", None, w), lambda w: agg(w), (nnz, 5))
+    check(lambda x, y: ops.gsddmm(g, "add", x, y), lambda x, y: x[s] + y[d], (n, H, 1), (n, H, 1))
+    check(lambda x, y: ops.gsddmm(g, "dot", x, y), lambda x, y: (x[s] * y[d]).sum(-1, keepdim=True), (n, H, F), (n, H, F))
+    check(lambda x, y: ops.gsddmm(g, "mul", x, y), lambda x, y: x[s] * y[d], (n, 7), (n, 7))
+    check(lambda x, y: ops.gsddmm(g, "sub", x, y), lambda x, y: x[s] - y[d], (n, 7), (n, 7))
+    check(lambda x, y: ops.gsddmm(g, "div", x, y + 1), lambda x, y: x[s] / (y[d] + 1), (n, 3), (n, 3))
+    check(lambda x: ops.gsddmm(g, "copy_lhs", x, None), lambda x: x[s], (n, 16))
+
+    def ref_max(x):
+        return torch.zeros(n, 8, device=DEV).scatter_reduce(0, d[:, None].expand(-1, 8), x[s], "amax", include_self=False)
+    check(lambda x: ops.gspmm(g, "copy_lhs", "max", x, None), ref_max, (n, 8))
+
+    def ref_softmax(z):
+        m = torch.full((n, H), -1e30, device=DEV).scatter_reduce(0, d[:, None].expand(-1, H), z, "amax")
+        e = torch.exp(z - m[d])
+        return e / agg(e)[d]
+    check(lambda z: ops.edge_softmax(g, z), ref_softmax, (nnz, H))
