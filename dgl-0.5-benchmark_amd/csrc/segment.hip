@@ -13,7 +13,6 @@ extern "C" int32_t mgx_segment_reduce(int64_t num_segments, const int64_t* offse
   mgx_csr csr;
   csr.num_rows = num_segments;
   csr.num_cols = 0;
-  csr.nnz = 1;  // unknown on the host without a sync; only used for the row-per-wave heuristic
   csr.indptr = offsets;
   csr.indices = nullptr;
   csr.eids = nullptr;
@@ -21,6 +20,6 @@ extern "C" int32_t mgx_segment_reduce(int64_t num_segments, const int64_t* offse
   csr.reserved = 0;
   // nnz drives only the SPLIT heuristic; segments are usually much longer than 64/G rows.
   csr.nnz = num_segments * 64;
-  return mgx_spmm_csr(&csr, MGX_OP_COPY_RHS, reduce, nullptr, x, 0, D, D, nullptr, nullptr, nullptr, nullptr, out,
-                      nullptr, arg, stream);
+  return mgx_spmm_csr(&csr, nullptr, MGX_OP_COPY_RHS, reduce, nullptr, x, 0, D, D, nullptr, nullptr, nullptr, nullptr,
+                      out, nullptr, arg, nullptr, stream);
 }

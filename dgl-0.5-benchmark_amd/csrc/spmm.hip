@@ -31,6 +31,12 @@ struct SpmmFastArgs {
   const float* src_scale;  // optional, per gathered row
   const float* dst_scale;  // optional, per output row
   float* out;
+  // optional schedule (mgx_spmm_plan): work items instead of natural row order
+  const int32_t* item_row;  // >= 0: row written directly; < 0: partial slot -(v+1)
+  const Idx* item_beg;
+  const Idx* item_end;
+  float* partial;           // [num_slots, D] partial sums of split (hub) rows
+  int64_t n_items;  // == n_rows without a plan
   int64_t n_rows;
   int64_t nblocks;  // logical blocks, multiple of kXcds
   int D;            // elements per feature row
@@ -54,23 +60,30 @@ __global__ __launch_bounds__(kBlock) void spmm_fast_kernel(const SpmmFastArgs<Id
   constexpr int STEP = SPLIT ? NB : 1;
 
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int sub = lane / G;
   const int l = lane % G;
   const int f = (blockIdx.y * G + l) * VEC;
   const bool factive = f < a.D;
   const int head = (MODE == MODE_MUL_EDGE && factive) ? f / a.F : 0;
-  const int64_t row_base = xcd_remap(blockIdx.x, a.nblocks) * kRowsPerBlock;
+  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * kRowsPerBlock;
   const int64_t D = a.D;
 
   for (int r = wave * ROWS_PER_STEP; r < kRowsPerBlock; r += kWavesPerBlock * ROWS_PER_STEP) {
-    if (row_base + r >= a.n_rows) break;  // wave-uniform
-    const int64_t row = row_base + r + (SPLIT ? 0 : sub);
-    const bool ractive = row < a.n_rows;
-    int64_t beg = 0, end = 0;
-    if (ractive) {
-      beg = (int64_t)a.indptr[row];
-      end = (int64_t)a.indptr[row + 1];
+    if (item_base + r >= a.n_items) break;  // wave-uniform
+    const int64_t item = item_base + r + (SPLIT ? 0 : sub);
+    const bool iactive = item < a.n_items;
+    int64_t row = 0, beg = 0, end = 0;
+    if (iactive) {
+      if (a.item_row) {
+        row = (int64_t)a.item_row[item];
+        beg = (int64_t)a.item_beg[item];
+        end = (int64_t)a.item_end[item];
+      } else {
+        row = item;
+        beg = (int64_t)a.indptr[item];
+        end = (int64_t)a.indptr[item + 1];
+      }
     }
     V acc = (V)(0.f);
     for (int64_t p = beg + (SPLIT ? sub : 0); p < end; p += (int64_t)STEP * UNROLL) {
@@ -115,14 +128,43 @@ __global__ __launch_bounds__(kBlock) void spmm_fast_kernel(const SpmmFastArgs<Id
 #pragma unroll
       for (int off = G; off < kWave; off <<= 1) acc += vec_shfl_xor<VEC>(acc, off);
     }
-    if (ractive && factive && (!SPLIT || sub == 0)) {
-      if (a.mean) {
-        const int64_t deg = end - beg;
-        acc = acc / (float)(deg > 1 ? deg : 1);
+    if (iactive && factive && (!SPLIT || sub == 0)) {
+      if (row >= 0) {
+        if (a.mean) {
+          const int64_t deg = end - beg;
+          acc = acc / (float)(deg > 1 ? deg : 1);
+        }
+        if (a.dst_scale) acc = acc * a.dst_scale[row];
+        *reinterpret_cast<V*>(a.out + row * D + f) = acc;
+      } else {  // chunk of a split row: the epilogue runs in spmm_hub_fixup_kernel
+        *reinterpret_cast<V*>(a.partial + (-(row + 1)) * D + f) = acc;
       }
-      if (a.dst_scale) acc = acc * a.dst_scale[row];
-      *reinterpret_cast<V*>(a.out + row * D + f) = acc;
     }
+  }
+}
+
+// Sums the partial slots of every split (hub) row in slot order -- deterministic -- and applies
+// the mean / dst_scale epilogue.  One wave per hub row, lanes along the feature dimension.
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void spmm_hub_fixup_kernel(const Idx* indptr, const int32_t* hub_row,
+                                                                const int32_t* hub_slot_ptr, int64_t num_hubs,
+                                                                const float* partial, const float* dst_scale,
+                                                                float* out, int D, int mean) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t h = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (h >= num_hubs) return;
+  const int64_t row = hub_row[h];
+  const int s0 = hub_slot_ptr[h], s1 = hub_slot_ptr[h + 1];
+  float scale = 1.f;
+  for (int k = lane; k < D; k += kWave) {
+    float acc = 0.f;
+    for (int s = s0; s < s1; ++s) acc += partial[(int64_t)s * D + k];
+    if (mean) {
+      const int64_t deg = (int64_t)indptr[row + 1] - (int64_t)indptr[row];
+      acc = acc / (float)(deg > 1 ? deg : 1);
+    }
+    if (dst_scale) acc *= dst_scale[row];
+    out[row * D + k] = acc * scale;
   }
 }
 
@@ -244,7 +286,7 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
 }
 
 template <typename Idx>
-static int32_t spmm_impl(const mgx_csr* csr, int32_t op, int32_t reduce, const float* U, const float* E,
+static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* partial_ws, int32_t op, int32_t reduce, const float* U, const float* E,
                          int64_t u_len, int64_t e_len, int64_t out_len, const int64_t* u_off,
                          const int64_t* e_off, const float* src_scale, const float* dst_scale, float* out,
                          void* arg_u, void* arg_e, hipStream_t s) {
@@ -252,6 +294,13 @@ static int32_t spmm_impl(const mgx_csr* csr, int32_t op, int32_t reduce, const f
   if (n_rows == 0 || out_len == 0) return MGX_OK;
   const int64_t nblocks = round_up((n_rows + kRowsPerBlock - 1) / kRowsPerBlock, kXcds);
   MGX_CHECK_ARG(nblocks < (int64_t(1) << 31), "mgx_spmm_csr: too many rows (%lld)", (long long)n_rows);
+  if (plan) {
+    MGX_CHECK_ARG(plan->num_items >= n_rows && plan->item_row && plan->item_beg && plan->item_end,
+                  "mgx_spmm_csr: malformed plan");
+    MGX_CHECK_ARG(plan->num_slots == 0 || (partial_ws && plan->hub_row && plan->hub_slot_ptr),
+                  "mgx_spmm_csr: plan has split rows but no partial workspace / hub tables");
+    MGX_CHECK_ARG(n_rows < (int64_t(1) << 31), "mgx_spmm_csr: plans need fewer than 2^31 rows");
+  }
   const bool summing = reduce == MGX_REDUCE_SUM || reduce == MGX_REDUCE_MEAN;
   const bool no_bcast = !u_off && !e_off;
 
@@ -262,17 +311,32 @@ static int32_t spmm_impl(const mgx_csr* csr, int32_t op, int32_t reduce, const f
     a.w = nullptr; a.src_scale = src_scale; a.dst_scale = dst_scale; a.out = out;
     a.n_rows = n_rows; a.nblocks = nblocks; a.D = (int)out_len; a.H = 1; a.F = (int)out_len;
     a.mean = reduce == MGX_REDUCE_MEAN;
+    a.item_row = nullptr; a.item_beg = nullptr; a.item_end = nullptr; a.partial = nullptr; a.n_items = n_rows;
+    if (plan) {
+      a.item_row = plan->item_row; a.item_beg = (const Idx*)plan->item_beg; a.item_end = (const Idx*)plan->item_end;
+      a.partial = partial_ws; a.n_items = plan->num_items;
+      a.nblocks = round_up((plan->num_items + kRowsPerBlock - 1) / kRowsPerBlock, kXcds);
+    }
+    auto fixup = [&]() -> int32_t {
+      if (plan && plan->num_hubs > 0) {
+        hipLaunchKernelGGL((spmm_hub_fixup_kernel<Idx>), dim3((unsigned)((plan->num_hubs + kWavesPerBlock - 1) / kWavesPerBlock)),
+                           dim3(kBlock), 0, s, a.indptr, plan->hub_row, plan->hub_slot_ptr, plan->num_hubs,
+                           (const float*)partial_ws, dst_scale, out, a.D, a.mean);
+        MGX_CHECK_LAUNCH();
+      }
+      return MGX_OK;
+    };
     if (op == MGX_OP_COPY_LHS && no_bcast && u_len == out_len) {
       a.src = U;
       launch_fast<Idx, MODE_COPY_LHS>(a, csr->nnz, s);
       MGX_CHECK_LAUNCH();
-      return MGX_OK;
+      return fixup();
     }
     if (op == MGX_OP_COPY_RHS && no_bcast && e_len == out_len && !src_scale) {
       a.src = E;
       launch_fast<Idx, MODE_COPY_RHS>(a, csr->nnz, s);
       MGX_CHECK_LAUNCH();
-      return MGX_OK;
+      return fixup();
     }
     // u_mul_e with one weight per (edge, head): U (N,H,F) x E (E,H,1); also (N,D) x (E,1).
     // ABI rule: a NULL offset table with e_len < out_len means head-wise broadcast, k -> k / (out_len/e_len).
@@ -280,7 +344,7 @@ static int32_t spmm_impl(const mgx_csr* csr, int32_t op, int32_t reduce, const f
       a.src = U; a.w = E; a.H = (int)e_len; a.F = (int)(out_len / e_len);
       launch_fast<Idx, MODE_MUL_EDGE>(a, csr->nnz, s);
       MGX_CHECK_LAUNCH();
-      return MGX_OK;
+      return fixup();
     }
   }
 
@@ -299,10 +363,11 @@ static int32_t spmm_impl(const mgx_csr* csr, int32_t op, int32_t reduce, const f
 
 }  // namespace mgx
 
-extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, int32_t op, int32_t reduce, const float* ufeat,
-                                const float* efeat, int64_t u_len, int64_t e_len, int64_t out_len,
-                                const int64_t* u_off, const int64_t* e_off, const float* src_scale,
-                                const float* dst_scale, float* out, void* arg_u, void* arg_e, void* stream) {
+extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t op, int32_t reduce,
+                                const float* ufeat, const float* efeat, int64_t u_len, int64_t e_len,
+                                int64_t out_len, const int64_t* u_off, const int64_t* e_off, const float* src_scale,
+                                const float* dst_scale, float* out, void* arg_u, void* arg_e, float* partial_ws,
+                                void* stream) {
   using namespace mgx;
   MGX_CHECK_ARG(csr != nullptr, "mgx_spmm_csr: csr is NULL");
   MGX_CHECK_ARG(csr->idx_bits == 32 || csr->idx_bits == 64, "mgx_spmm_csr: idx_bits must be 32 or 64, got %d", csr->idx_bits);
@@ -321,8 +386,8 @@ extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, int32_t op, int32_t reduce, 
   MGX_CHECK_ARG(!cmp || (!src_scale && !dst_scale), "mgx_spmm_csr: src/dst scale only with SUM/MEAN");
   hipStream_t s = (hipStream_t)stream;
   if (csr->idx_bits == 32)
-    return spmm_impl<int32_t>(csr, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
+    return spmm_impl<int32_t>(csr, plan, partial_ws, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
                               dst_scale, out, arg_u, arg_e, s);
-  return spmm_impl<int64_t>(csr, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
+  return spmm_impl<int64_t>(csr, plan, partial_ws, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
                             dst_scale, out, arg_u, arg_e, s);
 }

@@ -1,0 +1,163 @@
+"""Execution schedules (mgx_spmm_plan) for the row-segmented g-SpMM: hub-row splitting and a
+locality-aware row order.  Built once per CSR and cached on it -- preprocessing, like the CSR build
+that the reference's cold-start repetitions hide (kernel/dgl-new.py:8,21).
+
+Why: the gather of neighbour rows is the whole cost of copy_u/sum on ogbn-products-sized graphs
+(E*D*4 = 31.7 GB of row reads against 1.76 GB of compulsory traffic).  Rows of one
+community read the same source rows; walking them back to back on ONE XCD turns those reads into hits
+in that XCD's 4 MiB L2.  Node ids are untouched: only the order in which destination rows are
+processed changes, so results and the DGL-visible numbering are unaffected.
+
+  * split: rows with more than `split` edges become several work items whose partial sums are
+    combined in a fixed order (deterministic), so a 17k-edge hub never serialises on one wavefront;
+  * order: semi-synchronous label propagation (a few rounds of sort + run-length on the device)
+    groups rows into clusters; the schedule is the rows sorted by (final label, earlier labels).
+"""
+import ctypes
+import os
+
+import torch
+
+from ._lib import DGLError
+
+
+class MgxSpmmPlan(ctypes.Structure):
+    _fields_ = [
+        ("num_items", ctypes.c_int64),
+        ("item_row", ctypes.c_void_p),
+        ("item_beg", ctypes.c_void_p),
+        ("item_end", ctypes.c_void_p),
+        ("num_hubs", ctypes.c_int64),
+        ("hub_row", ctypes.c_void_p),
+        ("hub_slot_ptr", ctypes.c_void_p),
+        ("num_slots", ctypes.c_int64),
+    ]
+
+
+class SpmmPlan(object):
+    def __init__(self, item_row, item_beg, item_end, hub_row, hub_slot_ptr, num_slots, order_kind):
+        self.item_row, self.item_beg, self.item_end = item_row, item_beg, item_end
+        self.hub_row, self.hub_slot_ptr, self.num_slots = hub_row, hub_slot_ptr, int(num_slots)
+        self.order_kind = order_kind
+        self._c = None
+
+    @property
+    def num_items(self):
+        return int(self.item_row.shape[0])
+
+    @property
+    def num_hubs(self):
+        return int(self.hub_row.shape[0])
+
+    def c_struct(self):
+        if self._c is None:
+            self._c = MgxSpmmPlan(self.num_items, self.item_row.data_ptr(), self.item_beg.data_ptr(),
+                                  self.item_end.data_ptr(), self.num_hubs,
+                                  self.hub_row.data_ptr() if self.num_hubs else None,
+                                  self.hub_slot_ptr.data_ptr() if self.num_hubs else None, self.num_slots)
+        return self._c
+
+
+def label_propagation(indptr, indices, n, rounds=5, seed=0):
+    """Semi-synchronous LP on a square CSR; returns the label history [(n,) int64 per round]."""
+    dev = indptr.device
+    deg = (indptr[1:] - indptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    cols = indices.long()
+    labels = torch.arange(n, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    history = []
+    for it in range(rounds):
+        key = rows * n + labels[cols]
+        key, _ = torch.sort(key)
+        ukey, cnt = torch.unique_consecutive(key, return_counts=True)
+        del key
+        urow = torch.div(ukey, n, rounding_mode="floor")
+        ulab = ukey - urow * n
+        score = (cnt << 32) | ulab  # unique per row: the larger label wins ties -> deterministic
+        best = torch.zeros(n, dtype=torch.int64, device=dev)
+        best.scatter_reduce_(0, urow, score, reduce="amax", include_self=True)
+        new = best & 0xFFFFFFFF
+        has = best > 0
+        # update a random half of the nodes per round (plain synchronous LP oscillates)
+        flip = torch.rand(n, generator=gen, device=dev) < (0.5 if it < rounds - 1 else 1.1)
+        upd = has & flip
+        labels = torch.where(upd, new, labels)
+        history.append(labels.clone())
+    return history
+
+
+def locality_order(csr, rounds=5):
+    """Row permutation placing rows of one (nested) cluster next to each other."""
+    n = csr.num_rows
+    if n != csr.num_cols:
+        raise DGLError("locality_order needs a square graph")
+    hist = label_propagation(csr.indptr, csr.indices, n, rounds)
+    order = torch.arange(n, device=csr.device)
+    # stable sorts from the finest (earliest) to the coarsest (final) labels = lexicographic order
+    for labels in hist[max(0, len(hist) - 3):]:
+        order = order[torch.sort(labels[order], stable=True)[1]]
+    return order
+
+
+def build_plan(csr, order=None, split=1024, order_kind="natural"):
+    dev = csr.device
+    n = csr.num_rows
+    if n >= 2 ** 31:
+        raise DGLError("schedules support fewer than 2^31 rows")
+    indptr = csr.indptr.long()
+    deg = indptr[1:] - indptr[:-1]
+    if order is None:
+        order = torch.arange(n, device=dev)
+    nchunk = torch.clamp((deg + split - 1) // split, min=1)
+    nchunk_o = nchunk[order]
+    num_items = int(nchunk_o.sum().item())
+    if num_items == n:  # nothing to split
+        rows = order
+        beg, end = indptr[rows], indptr[rows + 1]
+        item_row = rows.to(torch.int32)
+        hub_row = torch.zeros(0, dtype=torch.int32, device=dev)
+        hub_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+        slots = 0
+    else:
+        item_off = torch.cumsum(nchunk_o, 0) - nchunk_o
+        pos = torch.repeat_interleave(torch.arange(n, device=dev), nchunk_o)
+        chunk = torch.arange(num_items, device=dev) - item_off[pos]
+        rows = order[pos]
+        beg = indptr[rows] + chunk * split
+        end = torch.minimum(beg + split, indptr[rows + 1])
+        is_hub = nchunk[rows] > 1
+        slot = torch.cumsum(is_hub.long(), 0) - 1
+        item_row = torch.where(is_hub, -(slot + 1), rows).to(torch.int32)
+        hub_pos = torch.nonzero(nchunk_o > 1).flatten()
+        hub_row = order[hub_pos].to(torch.int32)
+        hub_ptr = torch.zeros(hub_pos.shape[0] + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(nchunk_o[hub_pos], 0, out=hub_ptr[1:])
+        slots = int(hub_ptr[-1].item())
+        hub_ptr = hub_ptr.to(torch.int32)
+    idt = csr.indptr.dtype
+    return SpmmPlan(item_row.contiguous(), beg.to(idt).contiguous(), end.to(idt).contiguous(), hub_row.contiguous(),
+                    hub_ptr.contiguous(), slots, order_kind)
+
+
+# nnz below which the whole gathered matrix is cache resident anyway and clustering cannot pay
+_CLUSTER_MIN_NNZ = int(os.environ.get("MGX_CLUSTER_MIN_NNZ", 4_000_000))
+
+
+def plan_for(csr):
+    """Default policy: always split hubs; cluster the row order only for big square graphs.
+    MGX_SCHEDULE=natural|cluster|none overrides (none: no plan at all)."""
+    mode = os.environ.get("MGX_SCHEDULE", "auto")
+    if mode == "none" or csr.num_rows == 0 or csr.nnz == 0:
+        return None
+    avg = csr.nnz / max(csr.num_rows, 1)
+    split = 1024 if avg >= 32 else 256
+    want_cluster = mode == "cluster" or (mode == "auto" and csr.nnz >= _CLUSTER_MIN_NNZ)
+    order, kind = None, "natural"
+    if want_cluster and csr.num_rows == csr.num_cols and csr.indices.numel():
+        order, kind = locality_order(csr), "cluster"
+    plan = build_plan(csr, order, split, kind)
+    if kind == "natural" and plan.num_hubs == 0:
+        return None  # natural order, nothing split: the plan-free path is identical and leaner
+    return plan

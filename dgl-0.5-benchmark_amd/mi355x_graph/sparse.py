@@ -35,7 +35,7 @@ def _prod(shape):
 class CsrView(object):
     """An immutable CSR over torch tensors (in-CSR: rows = destination nodes)."""
 
-    __slots__ = ("num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg")
+    __slots__ = ("num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan")
 
     def __init__(self, num_rows, num_cols, indptr, indices, eids):
         self.num_rows, self.num_cols = int(num_rows), int(num_cols)
@@ -43,6 +43,7 @@ class CsrView(object):
         self._c = None
         self._deg = None
         self._inv_deg = None
+        self._plan = False  # False = not built yet; None = run without a plan
 
     @property
     def nnz(self):
@@ -73,6 +74,13 @@ class CsrView(object):
         if self._inv_deg is None:
             self._inv_deg = backend_for(self.indptr).inv_degrees(self)
         return self._inv_deg
+
+    def plan(self):
+        """Execution schedule for the summing g-SpMM (schedule.py); built on first use, device only."""
+        if self._plan is False:
+            from . import schedule
+            self._plan = schedule.plan_for(self) if self.indptr.is_cuda else None
+        return self._plan
 
     def to(self, device):
         return CsrView(self.num_rows, self.num_cols, self.indptr.to(device), self.indices.to(device),
@@ -198,11 +206,16 @@ class HipBackend(object):
                 arg_u = torch.empty((csr.num_rows, out_len), dtype=csr.indptr.dtype, device=dev)
             if op != "copy_lhs":
                 arg_e = torch.empty((csr.num_rows, out_len), dtype=csr.indptr.dtype, device=dev)
+        plan = csr.plan() if reduce in ("sum", "mean") else None
+        partial = None
+        if plan is not None and plan.num_slots:
+            partial = torch.empty((plan.num_slots, out_len), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mgx_spmm_csr(
-                ctypes.byref(csr.c_struct()), OP[op], REDUCE[reduce], _ptr(U), _ptr(E), u_len, e_len, out_len,
+                ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()),
+                OP[op], REDUCE[reduce], _ptr(U), _ptr(E), u_len, e_len, out_len,
                 _ptr(u_off), _ptr(e_off), _ptr(src_scale), _ptr(dst_scale), _ptr(out), _ptr(arg_u), _ptr(arg_e),
-                _stream(dev)))
+                _ptr(partial), _stream(dev)))
         return out, arg_u, arg_e
 
     def sddmm(self, graph_index, op, L, R, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size, l_off, r_off):

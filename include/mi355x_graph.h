@@ -72,6 +72,25 @@ typedef struct mgx_csr {
   int32_t reserved;
 } mgx_csr;
 
+/* Optional execution schedule of a CSR for the summing g-SpMM (built once per graph, like the CSR
+ * itself; mi355x_graph/schedule.py builds it).  Work items replace the natural row order:
+ *   - items are walked in array order, 64 per workgroup, each XCD (own L2) taking a contiguous
+ *     range -- a locality-aware order (rows of one community adjacent) turns gathers into L2 hits;
+ *   - rows longer than the split threshold appear as several items (edge ranges) whose partial
+ *     sums go to `partial_ws` slots and are combined in slot order by a fix-up launch, so a hub
+ *     row never serialises on one wavefront and the result stays deterministic.
+ * Every row must be covered exactly once (one direct item, or >= 2 slot items + a hub entry). */
+typedef struct mgx_spmm_plan {
+  int64_t num_items;
+  const int32_t* item_row;  /* [num_items] >= 0: row written directly; < 0: partial slot -(v+1) */
+  const void* item_beg;     /* [num_items] first edge position (graph index width) */
+  const void* item_end;     /* [num_items] one past the last edge position */
+  int64_t num_hubs;
+  const int32_t* hub_row;       /* [num_hubs] rows that were split */
+  const int32_t* hub_slot_ptr;  /* [num_hubs+1] slots of hub h are [ptr[h], ptr[h+1]) */
+  int64_t num_slots;            /* partial_ws holds num_slots * out_len floats */
+} mgx_spmm_plan;
+
 /* ------------------------------------------------------------------ misc */
 const char* mgx_last_error(void);
 /* ABI version, bumped on any signature change. */
@@ -94,13 +113,17 @@ int32_t mgx_device_info(int32_t* num_cus, int32_t* lds_bytes_per_cu, char* arch_
  * src_scale / dst_scale: optional per-node fp32 factors (NULL = 1); used for the fused backward
  * of `mean` and for symmetric-norm GCN layers.  Only with SUM/MEAN.
  * arg_u/arg_e: same index width as the graph, [num_rows*out_len], may be NULL.
- * Deterministic: no atomics, fixed summation order for a given graph. */
-int32_t mgx_spmm_csr(const mgx_csr* csr, int32_t op, int32_t reduce,
+ * NULL offset table: identity when the operand row has out_len elements, otherwise head-wise
+ * broadcast k -> k / (out_len / len)  (the (N,H,F) x (E,H,1) pattern of GATConv).
+ * Deterministic: no atomics, fixed summation order for a given graph (and plan). */
+int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */,
+                     int32_t op, int32_t reduce,
                      const float* ufeat, const float* efeat,
                      int64_t u_len, int64_t e_len, int64_t out_len,
                      const int64_t* u_off, const int64_t* e_off,
                      const float* src_scale, const float* dst_scale,
-                     float* out, void* arg_u, void* arg_e, void* stream);
+                     float* out, void* arg_u, void* arg_e,
+                     float* partial_ws /* [plan->num_slots * out_len] or NULL */, void* stream);
 
 /* ------------------------------------------------------------------ g-SDDMM
  * Replaces _CAPI_DGLKernelSDDMM as reached by dgl.ops.gsddmm (kernel/dgl-new.py:39),

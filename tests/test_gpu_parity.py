@@ -267,7 +267,13 @@ def test_edge_cases(oracle):
     X = rng.random((n, 64), dtype=np.float32)
     g = mk(n, n, src, dst)
     ip, ix, ei = oracle.coo_to_csr(n, dst, src)
-    assert rel(ops.gspmm(g, "copy_lhs", "sum", T(X), None).cpu(), oracle.spmm(ip, ix, ei, "copy_lhs", "sum", X, None)) < RTOL
+    # a 40k-edge fp32 row: the reference CPU algorithm's own sequential rounding error is ~1.3e-4 here,
+    # so both are held to the exact (fp64) sum; the HIP path must be at least as accurate as the oracle
+    exact = np.zeros((n, 64))
+    np.add.at(exact, dst, X[src].astype(np.float64))
+    hip = ops.gspmm(g, "copy_lhs", "sum", T(X), None).cpu()
+    assert rel(hip, exact) < RTOL
+    assert rel(hip, exact) <= rel(oracle.spmm(ip, ix, ei, "copy_lhs", "sum", X, None), exact) + 1e-6
     Z = rng.standard_normal((nnz, 2)).astype(np.float32)
     assert rel(ops.edge_softmax(g, T(Z)).cpu(), oracle.edge_softmax_fwd(ip, ei, Z)) < RTOL
     with pytest.raises(mg.DGLError):
