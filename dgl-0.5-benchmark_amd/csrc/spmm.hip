@@ -13,6 +13,8 @@
 //   * fp32 accumulation in registers, cross-group combine by xor-shuffles, one coalesced store;
 //     no atomics => bitwise reproducible for a given graph;
 //   * blockIdx is remapped so each XCD (own L2) owns a contiguous range of destination rows.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mgx {
@@ -39,11 +41,23 @@ struct SpmmFastArgs {
   int64_t n_items;  // == n_rows without a plan
   int64_t n_rows;
   int64_t nblocks;  // logical blocks, multiple of kXcds
+  int rpb;          // work items per workgroup
   int D;            // elements per feature row
   int H;            // heads of w
   int F;            // D / H
   int mean;
 };
+
+// Work items per workgroup.  Workgroups are dispatched in blockIdx order, so a SMALL value makes
+// the rows in flight on one XCD a tight window of the schedule (256 resident groups x rpb rows)
+// and balances skewed rows better; 16 measured best on MI355X (64: +5..50 %, 256: +20..150 %).
+static int rows_per_block_setting() {
+  const char* e = getenv("MGX_ROWS_PER_BLOCK");
+  int x = e ? atoi(e) : 16;
+  if (x < 4) x = 4;
+  if (x > 1024) x = 1024;
+  return x / 4 * 4;
+}
 
 template <int G, bool SPLIT>
 struct Unroll {
@@ -66,10 +80,10 @@ __global__ __launch_bounds__(kBlock) void spmm_fast_kernel(const SpmmFastArgs<Id
   const int f = (blockIdx.y * G + l) * VEC;
   const bool factive = f < a.D;
   const int head = (MODE == MODE_MUL_EDGE && factive) ? f / a.F : 0;
-  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * kRowsPerBlock;
+  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * a.rpb;
   const int64_t D = a.D;
 
-  for (int r = wave * ROWS_PER_STEP; r < kRowsPerBlock; r += kWavesPerBlock * ROWS_PER_STEP) {
+  for (int r = wave * ROWS_PER_STEP; r < a.rpb; r += kWavesPerBlock * ROWS_PER_STEP) {
     if (item_base + r >= a.n_items) break;  // wave-uniform
     const int64_t item = item_base + r + (SPLIT ? 0 : sub);
     const bool iactive = item < a.n_items;
@@ -140,6 +154,136 @@ __global__ __launch_bounds__(kBlock) void spmm_fast_kernel(const SpmmFastArgs<Id
         *reinterpret_cast<V*>(a.partial + (-(row + 1)) * D + f) = acc;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-per-wave kernel, software pipelined (the SPLIT schedule for graphs whose rows feed all lane
+// groups).  The dependent chain  item -> indptr -> indices -> feature rows  is what bounds a
+// naive row loop (~7 serialized memory round trips per 50-edge row), so here:
+//   * the up-to-64 neighbour ids of a row are fetched by ONE coalesced load (lane j <- edge j) and
+//     handed to the lane groups with ds_bpermute (__shfl), never re-loaded per gather step;
+//   * the NEXT item's bounds and neighbour ids are requested before the current row's gathers
+//     are issued, so they travel under the row loads;
+//   * per-edge scalars (edge id, edge weight with one head, source scale) ride along the same way.
+template <typename Idx, int VEC, int G, int MODE>
+__global__ __launch_bounds__(kBlock) void spmm_rowwave_kernel(const SpmmFastArgs<Idx> a) {
+  typedef typename VecT<VEC>::type V;
+  constexpr int NB = kWave / G;
+  constexpr int U = NB >= 16 ? 1 : (NB >= 8 ? 2 : (NB >= 2 ? 4 : 8));
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int sub = lane / G;
+  const int l = lane % G;
+  const int f = (blockIdx.y * G + l) * VEC;
+  const bool factive = f < a.D;
+  const int head = (MODE == MODE_MUL_EDGE && factive) ? f / a.F : 0;
+  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * a.rpb;
+  const int64_t D = a.D;
+  const bool w_per_edge = MODE == MODE_MUL_EDGE && a.H == 1;  // weight can ride with the ids
+
+  auto load_meta = [&](int64_t item, int64_t& row, int64_t& beg, int64_t& end) {
+    if (a.item_row) {
+      row = (int64_t)a.item_row[item];
+      beg = (int64_t)a.item_beg[item];
+      end = (int64_t)a.item_end[item];
+    } else {
+      row = item;
+      beg = (int64_t)a.indptr[item];
+      end = (int64_t)a.indptr[item + 1];
+    }
+  };
+  // per-lane slice of a row's edge list starting at `base`: gather id, edge id, scalar factor
+  auto load_ids = [&](int64_t base, int64_t end, Idx& gid, Idx& eid, float& sc) {
+    const int64_t q = base + lane;
+    gid = (Idx)-1;
+    eid = (Idx)-1;
+    sc = 1.f;
+    if (q < end) {
+      if (MODE == MODE_COPY_RHS) {
+        gid = a.eids ? a.eids[q] : (Idx)q;
+      } else {
+        gid = a.indices[q];
+        if (MODE == MODE_MUL_EDGE) {
+          eid = a.eids ? a.eids[q] : (Idx)q;
+          if (w_per_edge) sc = a.w[(int64_t)eid];
+        }
+        if (a.src_scale) sc *= a.src_scale[(int64_t)gid];
+      }
+    }
+  };
+
+  int r = wave;
+  if (r >= a.rpb || item_base + r >= a.n_items) return;
+  int64_t row, beg, end;
+  load_meta(item_base + r, row, beg, end);
+  Idx gid, eid;
+  float sc;
+  load_ids(beg, end, gid, eid, sc);
+  const bool scaled = MODE == MODE_MUL_EDGE || a.src_scale != nullptr;
+
+  for (;;) {
+    const int rn = r + kWavesPerBlock;
+    const bool has_next = rn < a.rpb && item_base + rn < a.n_items;
+    int64_t nrow = 0, nbeg = 0, nend = 0;
+    Idx ngid = (Idx)-1, neid = (Idx)-1;
+    float nsc = 1.f;
+    if (has_next) {
+      load_meta(item_base + rn, nrow, nbeg, nend);
+      load_ids(nbeg, nend, ngid, neid, nsc);
+    }
+    V acc = (V)(0.f);
+    for (int64_t base = beg; base < end; base += kWave) {
+      if (base != beg) load_ids(base, end, gid, eid, sc);
+      const int cnt = (int)((end - base) < kWave ? (end - base) : kWave);
+      for (int k = 0; k < cnt; k += NB * U) {
+        int64_t nbr[U];
+        float wgt[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = k + u * NB + sub;
+          const Idx g = __shfl(gid, j & (kWave - 1), kWave);
+          nbr[u] = j < cnt ? (int64_t)g : -1;
+          wgt[u] = 1.f;
+          if (scaled) {
+            wgt[u] = __shfl(sc, j & (kWave - 1), kWave);
+            if (MODE == MODE_MUL_EDGE && !w_per_edge) {
+              const Idx e = __shfl(eid, j & (kWave - 1), kWave);
+              if (j < cnt) wgt[u] *= a.w[(int64_t)e * a.H + head];
+            }
+          }
+        }
+        V val[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          val[u] = (V)(0.f);
+          if (nbr[u] >= 0 && factive) val[u] = *reinterpret_cast<const V*>(a.src + nbr[u] * D + f);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (scaled) acc += val[u] * wgt[u];
+          else acc += val[u];
+        }
+      }
+    }
+#pragma unroll
+    for (int off = G; off < kWave; off <<= 1) acc += vec_shfl_xor<VEC>(acc, off);
+    if (factive && sub == 0) {
+      if (row >= 0) {
+        if (a.mean) {
+          const int64_t deg = end - beg;
+          acc = acc / (float)(deg > 1 ? deg : 1);
+        }
+        if (a.dst_scale) acc = acc * a.dst_scale[row];
+        *reinterpret_cast<V*>(a.out + row * D + f) = acc;
+      } else {
+        *reinterpret_cast<V*>(a.partial + (-(row + 1)) * D + f) = acc;
+      }
+    }
+    if (!has_next) break;
+    r = rn;
+    row = nrow; beg = nbeg; end = nend;
+    gid = ngid; eid = neid; sc = nsc;
   }
 }
 
@@ -248,9 +392,15 @@ __global__ __launch_bounds__(kBlock) void spmm_generic_kernel(const SpmmGenericA
 
 // ---------------------------------------------------------------------------------------------
 template <typename Idx, int VEC, int G, int MODE>
-static void launch_fast_g(const SpmmFastArgs<Idx>& a, bool split, hipStream_t s) {
+static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, hipStream_t s) {
+  constexpr int NB = kWave / G;
+  a.rpb = rows_per_block_setting();
+  if (!split && a.rpb < kWavesPerBlock * NB) a.rpb = kWavesPerBlock * NB;  // one item per lane group
+  a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);
   dim3 grid((unsigned)a.nblocks, (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
-  if (split) hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, true>), grid, dim3(kBlock), 0, s, a);
+  const bool legacy = getenv("MGX_SPMM_LEGACY") != nullptr;  // A/B switch for experiments
+  if (split && !legacy) hipLaunchKernelGGL((spmm_rowwave_kernel<Idx, VEC, G, MODE>), grid, dim3(kBlock), 0, s, a);
+  else if (split) hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, true>), grid, dim3(kBlock), 0, s, a);
   else hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, false>), grid, dim3(kBlock), 0, s, a);
 }
 
@@ -315,8 +465,8 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     if (plan) {
       a.item_row = plan->item_row; a.item_beg = (const Idx*)plan->item_beg; a.item_end = (const Idx*)plan->item_end;
       a.partial = partial_ws; a.n_items = plan->num_items;
-      a.nblocks = round_up((plan->num_items + kRowsPerBlock - 1) / kRowsPerBlock, kXcds);
     }
+    MGX_CHECK_ARG(a.n_items / 4 < (int64_t(1) << 31) - 16, "mgx_spmm_csr: too many work items");
     auto fixup = [&]() -> int32_t {
       if (plan && plan->num_hubs > 0) {
         hipLaunchKernelGGL((spmm_hub_fixup_kernel<Idx>), dim3((unsigned)((plan->num_hubs + kWavesPerBlock - 1) / kWavesPerBlock)),

@@ -300,8 +300,9 @@ def test_autograd_against_dense_torch():
         w = torch.rand_like(a)
         (a * w).sum().backward()
         (b * w).sum().backward()
-        for x, y in zip(xs, ys):
-            assert rel(x.grad.cpu(), y.grad.cpu()) < 1e-3
+        for x, y in zip(xs, ys):  # gradients cancel towards 0: compare against the tensor's scale
+            gx, gy = x.grad.cpu().double(), y.grad.cpu().double()
+            assert float((gx - gy).abs().max() / gy.abs().max().clamp(min=1e-12)) < RTOL
 
     def agg(msg):
         out = torch.zeros((n,) + msg.shape[1:], device=DEV)
