@@ -1,0 +1,212 @@
+"""Full-graph node-classification workloads: this backend's launcher for the model families of
+end_to_end/full_graph/node_classification (the callers of the hot path).
+
+The model classes restate the reference scripts' modules with the same parameters, layer order and
+operator calls so that every aggregation goes through update_all()/GATConv exactly as there:
+  SAGEConv / GraphSAGE   main_dgl_product_sage.py:15-99 (no BatchNorm), main_dgl_arxiv_sage.py:15-105 (BatchNorm)
+  GAT                    main_dgl_reddit_gat.py:14-65 (dgl.nn.pytorch.GATConv stack)
+  train step             main_dgl_product_sage.py:101-110  (zero_grad, forward, nll_loss on train_idx,
+                         backward, Adam step, loss.item() as the host sync)
+Epoch timing follows main_dgl_product_sage.py:175-180 (epochs 1-2 discarded) but reports the
+steady-state mean, not the reference's cumulative running mean.
+Datasets are the seeded synthetic stand-ins of mi355x_graph.datasets (no network here).
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import dgl  # noqa: E402
+import dgl.function as fn  # noqa: E402
+from dgl.nn.pytorch import GATConv  # noqa: E402
+from dgl.utils import expand_as_pair  # noqa: E402
+
+
+class SAGEConv(nn.Module):
+    """mean-aggregator GraphSAGE layer: fc_self(h_v) + fc_neigh(mean_{u->v} h_u); aggregation happens
+    BEFORE the projection, on the un-projected feature (main_dgl_product_sage.py:61-64)."""
+
+    def __init__(self, in_feats, out_feats, self_bias=False, neigh_bias=True):
+        super(SAGEConv, self).__init__()
+        self._in_src_feats, self._in_dst_feats = expand_as_pair(in_feats)
+        self.fc_self = nn.Linear(self._in_dst_feats, out_feats, bias=self_bias)
+        self.fc_neigh = nn.Linear(self._in_src_feats, out_feats, bias=neigh_bias)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        gain = nn.init.calculate_gain("relu")
+        nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
+        nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
+
+    def forward(self, graph, feat):
+        graph = graph.local_var()
+        feat_src, feat_dst = feat if isinstance(feat, tuple) else (feat, feat)
+        graph.srcdata["h"] = feat_src
+        graph.update_all(fn.copy_src("h", "m"), fn.mean("m", "neigh"))
+        return self.fc_self(feat_dst) + self.fc_neigh(graph.dstdata["neigh"])
+
+
+class GraphSAGE(nn.Module):
+    def __init__(self, in_feats, hidden_feats, out_feats, num_layers, dropout, batch_norm=False, neigh_bias=True):
+        super(GraphSAGE, self).__init__()
+        self.layers = nn.ModuleList()
+        self.bns = nn.ModuleList()
+        dims = [in_feats] + [hidden_feats] * (num_layers - 1) + [out_feats]
+        for i in range(num_layers):
+            self.layers.append(SAGEConv(dims[i], dims[i + 1], neigh_bias=neigh_bias))
+            if batch_norm and i < num_layers - 1:
+                self.bns.append(nn.BatchNorm1d(hidden_feats))
+        self.dropout = nn.Dropout(p=dropout)
+
+    def reset_parameters(self):
+        for layer in self.layers:
+            layer.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+
+    def forward(self, g, x):
+        for i, layer in enumerate(self.layers[:-1]):
+            x = layer(g, x)
+            if len(self.bns):
+                x = self.bns[i](x)
+            x = F.relu(x)
+            x = self.dropout(x)
+        x = self.layers[-1](g, x)
+        return x.log_softmax(dim=-1)
+
+
+class GAT(nn.Module):
+    """Stack of dgl.nn GATConv layers: hidden layers are flattened over heads, the output layer is
+    averaged over heads (main_dgl_reddit_gat.py:60-65)."""
+
+    def __init__(self, g, num_layers, in_feats, num_hidden, num_classes, heads, activation=F.elu,
+                 feat_drop=0.0, attn_drop=0.0, negative_slope=0.2):
+        super(GAT, self).__init__()
+        self.num_layers, self.g = num_layers, g
+        self.gat_layers = nn.ModuleList()
+        self.gat_layers.append(GATConv(in_feats, num_hidden, heads[0], 0., 0., negative_slope, activation=activation))
+        for l in range(num_layers - 2):
+            self.gat_layers.append(GATConv(num_hidden * heads[l], num_hidden, heads[l + 1], feat_drop, attn_drop,
+                                           negative_slope, activation=activation))
+        self.gat_layers.append(GATConv(num_hidden * heads[-2], num_classes, heads[-1], feat_drop, attn_drop,
+                                       negative_slope, activation=None))
+
+    def reset_parameters(self):
+        for layer in self.gat_layers:
+            layer.reset_parameters()
+
+    def forward(self, h):
+        for l in range(self.num_layers - 1):
+            h = self.gat_layers[l](self.g, h).flatten(1)
+        return self.gat_layers[-1](self.g, h).mean(1)
+
+
+def sage_train_step(model, g, feats, labels, train_idx, optimizer):
+    """main_dgl_product_sage.py:101-110."""
+    model.train()
+    optimizer.zero_grad()
+    out = model(g, feats)[train_idx]
+    loss = F.nll_loss(out, labels[train_idx])
+    loss.backward()
+    optimizer.step()
+    return loss.item()
+
+
+def gat_train_step(model, feats, labels, train_mask, optimizer, loss_fcn):
+    """main_dgl_reddit_gat.py:155-168."""
+    model.train()
+    logits = model(feats)
+    loss = loss_fcn(logits[train_mask], labels[train_mask])
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return loss.item()
+
+
+SAGE_CONFIGS = {
+    # name: dataset, layers, hidden, dropout, lr, batch_norm, bidirect, neigh_bias   (script defaults)
+    "products": dict(dataset="products", num_layers=3, hidden=64, dropout=0.5, lr=0.01, batch_norm=False,
+                     bidirect=False, neigh_bias=True),   # main_dgl_product_sage.py:136-143
+    "arxiv": dict(dataset="arxiv", num_layers=3, hidden=256, dropout=0.5, lr=0.01, batch_norm=True,
+                  bidirect=True, neigh_bias=False),      # main_dgl_arxiv_sage.py:141-148,162
+    "cora": dict(dataset="cora", num_layers=2, hidden=16, dropout=0.5, lr=0.01, batch_norm=False,
+                 bidirect=False, neigh_bias=True),       # main_dgl_citation_sage.py:100-101,139
+    "reddit": dict(dataset="reddit-small", num_layers=2, hidden=16, dropout=0.5, lr=0.01, batch_norm=False,
+                   bidirect=False, neigh_bias=True),
+}
+
+
+def build_sage(name, device, scale=1.0):
+    from mi355x_graph.datasets import NodeData
+    cfg = SAGE_CONFIGS[name]
+    data = NodeData(cfg["dataset"], device=device, scale=scale)
+    g = data.graph
+    if cfg["bidirect"]:
+        feats_keep = g.ndata["feat"]
+        g = dgl.to_bidirected(g)
+        g.ndata["feat"] = feats_keep
+    g = g.int().formats(["csr", "csc"]).to(device)
+    model = GraphSAGE(data.features.shape[1], cfg["hidden"], data.num_classes, cfg["num_layers"], cfg["dropout"],
+                      cfg["batch_norm"], cfg["neigh_bias"]).to(device)
+    train_idx = torch.nonzero(data.train_mask).flatten()
+    opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
+    return cfg, data, g, model, train_idx, opt
+
+
+def spmm_edges_per_epoch(num_layers, num_edges):
+    """L forward SpMMs + (L-1) backward SpMMs (the input features need no gradient)."""
+    return (2 * num_layers - 1) * num_edges
+
+
+def main():
+    p = argparse.ArgumentParser("full-graph training on the MI355X message-passing backend")
+    p.add_argument("--model", default="sage", choices=["sage", "gat"])
+    p.add_argument("--dataset", default="products")
+    p.add_argument("--epochs", type=int, default=10)
+    p.add_argument("--scale", type=float, default=1.0)
+    p.add_argument("--heads", type=int, default=8)
+    p.add_argument("--num-layers", type=int, default=2)
+    p.add_argument("--num-hidden", type=int, default=16)
+    p.add_argument("--device", type=int, default=0)
+    args = p.parse_args()
+    device = torch.device("cuda:%d" % args.device)
+    dur = []
+    if args.model == "sage":
+        cfg, data, g, model, train_idx, opt = build_sage(args.dataset, device, args.scale)
+        print(g)
+        for epoch in range(1, args.epochs + 1):
+            t0 = time.time()
+            loss = sage_train_step(model, g, data.features, data.labels, train_idx, opt)
+            if epoch >= 3:
+                dur.append(time.time() - t0)
+            print("epoch %d loss %.4f time %.4f" % (epoch, loss, time.time() - t0))
+        edges = spmm_edges_per_epoch(cfg["num_layers"], g.number_of_edges())
+    else:
+        from mi355x_graph.datasets import NodeData
+        data = NodeData(args.dataset, device=device, scale=args.scale)
+        g = dgl.add_self_loop(data.graph).int().to(device)
+        heads = [args.heads] * (args.num_layers - 1) + [1]
+        model = GAT(g, args.num_layers, data.features.shape[1], args.num_hidden, data.num_classes, heads).to(device)
+        opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=2.4e-5)
+        loss_fcn = nn.CrossEntropyLoss()
+        for epoch in range(args.epochs):
+            t0 = time.time()
+            loss = gat_train_step(model, data.features, data.labels, data.train_mask, opt, loss_fcn)
+            if epoch >= 3:
+                dur.append(time.time() - t0)
+            print("epoch %d loss %.4f time %.4f" % (epoch, loss, time.time() - t0))
+        edges = 0
+    if dur:
+        mean = sum(dur) / len(dur)
+        print("Training time/epoch {:.5f}".format(mean))
+        if edges:
+            print("aggregated edges/s {:.3e}".format(edges / mean))
+
+
+if __name__ == "__main__":
+    main()

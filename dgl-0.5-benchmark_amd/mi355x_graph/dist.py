@@ -1,0 +1,371 @@
+"""Multi-GPU full-graph message passing: edge-cut node partition + RCCL all_to_all halo exchange.
+
+New capability (the reference is single-GPU, README.md:12): one process per GPU, each
+owning a set of destination nodes with ALL their in-edges (1-D row partition), so every aggregation
+kernel is local; the only exchange step per layer is the boundary ("halo") source rows:
+
+  forward   send X_own[send_idx] to every peer (packed by mgx_gather_rows into one buffer)
+            -> torch.distributed.all_to_all_single over RCCL/xGMI (per-peer split sizes)
+            -> local g-SpMM over [owned | halo] source rows
+  backward  halo-row gradients travel the transposed all_to_all and are added into their owners
+            with mgx_scatter_add_rows (one call per peer, fixed order => deterministic)
+
+`DistGraph` keeps the DGLGraph surface (srcdata/dstdata/update_all/apply_edges/in_degrees over the
+OWNED nodes) so the model classes of full_graph.py run unmodified on a partition.  Weight
+gradients are summed with one flat all_reduce; the loss is normalised by the global train count so
+the P-way run computes the same mean loss as the 1-GPU run (main_dgl_product_sage.py:105-106).
+"""
+import torch
+import torch.distributed as dist
+
+from ._lib import DGLError
+from . import core, schedule, sparse
+from . import function as fn
+from .graph import DGLGraph, Frame, GraphIndex
+
+
+# ----------------------------------------------------------------------------- partitioning
+def partition_nodes(src, dst, num_nodes, num_parts, rounds=5, clusters=None):
+    """Edge-cut node partition: label-propagation clusters packed into `num_parts` bins balanced on
+    in-edge count (the per-GPU SpMM work), largest cluster first.  Returns (assign [N] int64, stats).
+    METIS is not available offline; this is the build's own partitioner."""
+    dev = src.device
+    if num_parts == 1:
+        return torch.zeros(num_nodes, dtype=torch.int64, device=dev), {"edge_cut": 0.0, "num_clusters": 1}
+    indeg = torch.bincount(dst.long(), minlength=num_nodes)
+    node_w = indeg + 1  # +1 so that isolated nodes still spread out
+    if clusters is None:
+        csc = sparse.coo_to_csr(num_nodes, num_nodes, dst.contiguous(), src.contiguous())
+        cap = int(node_w.sum().item()) // (num_parts * 4) + 1
+        hist = schedule.label_propagation(csc.indptr, csc.indices, num_nodes, rounds)
+        clusters = _cap_clusters(hist, node_w, cap)
+    uniq, inv = torch.unique(clusters, return_inverse=True)
+    c_edges = torch.zeros(uniq.shape[0], dtype=torch.int64, device=dev).index_add_(0, inv, node_w)
+    c_nodes = torch.zeros_like(c_edges)
+    # cluster graph (who talks to whom, how much), then linear-deterministic-greedy placement:
+    # heaviest cluster first, into the part it is most connected to, discounted by that part's load
+    import numpy as np
+    C = int(uniq.shape[0])
+    cs, cd = inv[src.long()], inv[dst.long()]
+    cross = cs != cd
+    pair, cnt = torch.unique(cs[cross] * C + cd[cross], return_counts=True)
+    pa = torch.div(pair, C, rounding_mode="floor")
+    pb = pair - pa * C
+    # symmetrise: affinity(a,b) = edges a->b + b->a
+    a_all = torch.cat([pa, pb]).cpu().numpy()
+    b_all = torch.cat([pb, pa]).cpu().numpy()
+    w_all = torch.cat([cnt, cnt]).cpu().numpy().astype(np.float64)
+    order_e = np.argsort(a_all, kind="stable")
+    a_all, b_all, w_all = a_all[order_e], b_all[order_e], w_all[order_e]
+    ptr = np.zeros(C + 1, np.int64)
+    np.add.at(ptr, a_all + 1, 1)
+    ptr = np.cumsum(ptr)
+    weight = c_edges.cpu().numpy().astype(np.float64)
+    capacity = 1.03 * weight.sum() / num_parts + weight.max() * 0.0
+    part = np.full(C, -1, np.int64)
+    load = np.zeros(num_parts)
+    order = np.argsort(-weight, kind="stable")
+    for sweep in range(3):  # first sweep places, later sweeps move clusters with full knowledge
+        for c in order:
+            nb, w = b_all[ptr[c]:ptr[c + 1]], w_all[ptr[c]:ptr[c + 1]]
+            placed = part[nb] >= 0
+            conn = np.bincount(part[nb][placed], weights=w[placed], minlength=num_parts) if placed.any() else np.zeros(num_parts)
+            cur = part[c]
+            if cur >= 0:
+                load[cur] -= weight[c]
+            room = load + weight[c] <= capacity
+            if not room.any():
+                room = load == load.min()
+            score = np.where(room, (conn + 1e-9) * (1.0 - load / capacity), -np.inf)
+            best = int(np.argmax(score))
+            if conn.max() <= 0:  # no placed neighbour: lightest part
+                best = int(np.argmin(np.where(room, load, np.inf)))
+            part[c] = best
+            load[best] += weight[c]
+    assign = torch.from_numpy(part).to(dev)[inv]
+    assign = _refine(assign, src.long(), dst.long(), node_w, num_parts, 1.03)
+    cut = float((assign[src.long()] != assign[dst.long()]).float().mean().item()) if src.numel() else 0.0
+    return assign, {"edge_cut": cut, "num_clusters": int(uniq.shape[0])}
+
+
+def _refine(assign, src, dst, node_w, num_parts, slack, sweeps=4):
+    """Balanced label-propagation refinement at node level: a node moves to the part holding most of
+    its neighbours when that reduces the cut and the target part has room (heaviest gains first)."""
+    n = assign.shape[0]
+    dev = assign.device
+    total = float(node_w.sum().item())
+    cap = slack * total / num_parts
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)
+    for it in range(sweeps):
+        cnt = torch.zeros(n * num_parts, dtype=torch.float32, device=dev)
+        ones = torch.ones(src.shape[0], dtype=torch.float32, device=dev)
+        cnt.index_add_(0, dst * num_parts + assign[src], ones)
+        cnt.index_add_(0, src * num_parts + assign[dst], ones)
+        cnt = cnt.view(n, num_parts)
+        cur = cnt.gather(1, assign[:, None]).squeeze(1)
+        best_cnt, best = cnt.max(1)
+        gain = best_cnt - cur
+        cand = (gain > 0) & (best != assign) & (torch.rand(n, generator=gen, device=dev) < 0.5)
+        if not bool(cand.any()):
+            break
+        load = torch.zeros(num_parts, dtype=torch.float64, device=dev).index_add_(0, assign, node_w.double())
+        idx = torch.nonzero(cand).flatten()
+        # per target part: accept candidates in order of decreasing gain while the part has room
+        key = best[idx].double() * 1e9 - gain[idx].double()
+        idx = idx[torch.sort(key)[1]]
+        tgt = best[idx]
+        w = node_w[idx].double()
+        first = torch.ones_like(tgt, dtype=torch.bool)
+        first[1:] = tgt[1:] != tgt[:-1]
+        csum = torch.cumsum(w, 0)
+        base = (csum - w)[first]
+        seg = torch.cumsum(first.long(), 0) - 1
+        within = csum - base[seg]
+        room = (cap - load)[tgt]
+        ok = within <= room
+        moved = idx[ok]
+        assign = assign.clone()
+        assign[moved] = tgt[ok]
+    return assign
+
+
+def _cap_clusters(hist, node_w, cap):
+    """Clusters heavier than `cap` fall back to the finer labels of earlier LP rounds; what is still
+    too heavy is cut into chunks of cumulative weight <= cap (node-id order)."""
+    n = node_w.shape[0]
+    dev = node_w.device
+    labels = hist[-1].clone()
+
+    def heavy_mask(lab):
+        u, inv = torch.unique(lab, return_inverse=True)
+        w = torch.zeros(u.shape[0], dtype=torch.int64, device=dev).index_add_(0, inv, node_w)
+        return (w > cap)[inv]
+
+    for level in range(len(hist) - 2, -1, -1):
+        big = heavy_mask(labels)
+        if not bool(big.any()):
+            return labels
+        labels = torch.where(big, hist[level] + n * (len(hist) - 1 - level), labels)
+    big = heavy_mask(labels)
+    if bool(big.any()):
+        order = torch.sort(labels, stable=True)[1]
+        lab_s, w_s = labels[order], node_w[order]
+        csum = torch.cumsum(w_s, 0)
+        first = torch.ones_like(lab_s, dtype=torch.bool)
+        first[1:] = lab_s[1:] != lab_s[:-1]
+        start_csum = (csum - w_s)[first]                      # cumulative weight before each cluster
+        cid = torch.cumsum(first.long(), 0) - 1
+        chunk = torch.div(csum - w_s - start_csum[cid], cap, rounding_mode="floor")
+        new = lab_s * 0 + cid * (int(chunk.max().item()) + 1) + chunk + n * (len(hist) + 1)
+        labels = labels.clone()
+        labels[order] = torch.where(big[order], new, lab_s)
+    return labels
+
+
+class HaloPlan(object):
+    """What one rank sends / receives per layer."""
+
+    def __init__(self, rank, world, n_own, n_halo, send_idx, send_splits, recv_splits):
+        self.rank, self.world = rank, world
+        self.n_own, self.n_halo = n_own, n_halo
+        self.send_idx = send_idx            # local owned-row ids, grouped by destination peer
+        self.send_splits = send_splits      # python ints, len world
+        self.recv_splits = recv_splits
+        off = 0
+        self.send_ranges = []
+        for c in send_splits:
+            self.send_ranges.append((off, off + c))
+            off += c
+
+
+def build_local_partition(src, dst, num_nodes, assign, rank, world, idtype=torch.int32):
+    """From the GLOBAL edge list (every rank holds it in this benchmark) build rank's local block graph
+    over [owned | halo] sources, its halo plan, and the owned global ids.  No communication."""
+    dev = src.device
+    src, dst = src.long(), dst.long()
+    a_src, a_dst = assign[src], assign[dst]
+    own = torch.nonzero(assign == rank).flatten()
+    n_own = int(own.shape[0])
+    g2l = torch.full((num_nodes,), -1, dtype=torch.int64, device=dev)
+    g2l[own] = torch.arange(n_own, device=dev)
+    mine = a_dst == rank
+    es, ed, eo = src[mine], dst[mine], a_src[mine]
+    remote = eo != rank
+    # halo = distinct remote sources, ordered by (owner, global id): the order peers send them in
+    key = eo[remote] * num_nodes + es[remote]
+    hkey = torch.unique(key)
+    h_owner = torch.div(hkey, num_nodes, rounding_mode="floor")
+    n_halo = int(hkey.shape[0])
+    recv_splits = torch.bincount(h_owner, minlength=world).cpu().tolist()
+    l_src = g2l[es]
+    l_src[remote] = n_own + torch.searchsorted(hkey, key)
+    l_dst = g2l[ed]
+    # what I must send: distinct (peer, my node) pairs over the edges leaving my part
+    out = (a_src == rank) & (a_dst != rank)
+    skey = torch.unique(a_dst[out] * num_nodes + src[out])
+    s_peer = torch.div(skey, num_nodes, rounding_mode="floor")
+    send_idx = g2l[skey - s_peer * num_nodes]
+    send_splits = torch.bincount(s_peer, minlength=world).cpu().tolist()
+    block = DGLGraph(GraphIndex(n_own + n_halo, n_own, coo=(l_src.to(idtype).contiguous(), l_dst.to(idtype).contiguous())),
+                     is_block=True)
+    plan = HaloPlan(rank, world, n_own, n_halo, send_idx.to(idtype).contiguous(), send_splits, recv_splits)
+    return block, plan, own
+
+
+# ----------------------------------------------------------------------------- exchange
+class _Comm(object):
+    """Thin wrapper so tests can run the same code over gloo (CPU) and the bench over RCCL."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_to_all(self, out, inp, out_splits, in_splits):
+        if dist.get_backend(self.group) == "gloo":  # gloo has no all_to_all_single: pairwise isend/irecv
+            world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
+            outs = list(out.split(out_splits, 0))
+            inps = list(inp.split(in_splits, 0))
+            outs[rank].copy_(inps[rank])
+            reqs = []
+            for p in range(world):
+                if p == rank:
+                    continue
+                if in_splits[p]:
+                    reqs.append(dist.isend(inps[p].contiguous(), p, group=self.group))
+                if out_splits[p]:
+                    reqs.append(dist.irecv(outs[p], p, group=self.group))
+            for r in reqs:
+                r.wait()
+        else:
+            dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+
+class HaloExchange(torch.autograd.Function):
+    """x_own [n_own, ...] -> [n_own + n_halo, ...]; backward adds halo gradients into their owners."""
+
+    @staticmethod
+    def forward(ctx, x, plan, comm):
+        x = x.contiguous()
+        feat = tuple(x.shape[1:])
+        full = torch.empty((plan.n_own + plan.n_halo,) + feat, dtype=x.dtype, device=x.device)
+        full[:plan.n_own] = x
+        send = sparse.gather_rows_raw(x, plan.send_idx)
+        comm.all_to_all(full[plan.n_own:], send, plan.recv_splits, plan.send_splits)
+        ctx.plan, ctx.comm = plan, comm
+        return full
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, comm = ctx.plan, ctx.comm
+        g = g.contiguous()
+        gx = g[:plan.n_own].clone()
+        back = torch.empty((plan.send_idx.shape[0],) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+        comm.all_to_all(back, g[plan.n_own:], plan.send_splits, plan.recv_splits)
+        for (a, b) in plan.send_ranges:  # one peer at a time: ids are unique inside a peer's list
+            if b > a:
+                sparse.scatter_add_rows_raw(gx, plan.send_idx[a:b], back[a:b])
+        return gx, None, None
+
+
+class DistGraph(DGLGraph):
+    """The owned nodes of one partition behind the DGLGraph surface."""
+
+    def __init__(self, block, plan, comm=None):
+        self._block = block
+        self._plan = plan
+        self._comm = comm or _Comm()
+        self._index = block._index
+        self._is_block = False
+        self._src_frame = Frame(plan.n_own, kind="node")
+        self._dst_frame = self._src_frame
+        self._edge_frame = Frame(block.number_of_edges(), kind="edge")
+        self._batch_num_nodes = None
+        self._batch_num_edges = None
+
+    def _clone(self, index=None, frames=None):
+        g = DistGraph.__new__(DistGraph)
+        g._block, g._plan, g._comm = self._block, self._plan, self._comm
+        g._index, g._is_block = self._index, False
+        if frames is None:
+            g._src_frame = self._src_frame.clone()
+            g._dst_frame = g._src_frame
+            g._edge_frame = self._edge_frame.clone()
+        else:
+            g._src_frame, g._dst_frame, g._edge_frame = frames
+        g._batch_num_nodes = g._batch_num_edges = None
+        return g
+
+    def number_of_nodes(self, ntype=None):
+        return self._plan.n_own
+
+    num_nodes = number_of_nodes
+
+    def number_of_src_nodes(self, ntype=None):
+        return self._plan.n_own
+
+    def number_of_dst_nodes(self, ntype=None):
+        return self._plan.n_own
+
+    def int(self):
+        return self
+
+    def to(self, device, **kw):
+        if torch.device(device) != self.device:
+            raise DGLError("DistGraph lives on its rank's device")
+        return self
+
+    def formats(self, formats=None):
+        return self._index.format_status() if formats is None else self
+
+    def halo_exchange(self, x):
+        return HaloExchange.apply(x, self._plan, self._comm)
+
+    def _local(self, fields):
+        src = Frame(self._plan.n_own + self._plan.n_halo, kind="node")
+        for f in fields:
+            if f not in self._src_frame:
+                raise DGLError("Cannot find field %r in the source node features" % (f,))
+            src[f] = self.halo_exchange(self._src_frame[f])
+        return self._block._clone(frames=(src, self._dst_frame, self._edge_frame))
+
+    @staticmethod
+    def _u_fields(func):
+        if isinstance(func, fn.CopyMessageFunction):
+            return [func.in_field] if func.target == "u" else []
+        if isinstance(func, fn.BinaryMessageFunction):
+            out = []
+            if func.lhs == "u":
+                out.append(func.lhs_field)
+            if func.rhs == "u":
+                out.append(func.rhs_field)
+            return out
+        raise DGLError("DistGraph supports builtin message functions only")
+
+    def update_all(self, message_func, reduce_func, apply_node_func=None, etype=None):
+        blk = self._local(self._u_fields(message_func))
+        core.update_all(blk, message_func, reduce_func, apply_node_func)
+
+    def apply_edges(self, func, edges="__ALL__", etype=None):
+        blk = self._local(self._u_fields(func))
+        core.apply_edges(blk, func)
+
+
+# ----------------------------------------------------------------------------- training helpers
+def allreduce_gradients(model, group=None):
+    """One flat (bucketed) all_reduce(sum) over every parameter gradient -- the payload is tiny for
+    these models (~30k floats for products SAGE), so a single call is latency-optimal on xGMI."""
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def broadcast_parameters(model, src=0, group=None):
+    for p in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(p.data, src, group=group)

@@ -77,16 +77,20 @@ class GSpMM(torch.autograd.Function):
         dX = dY = None
         summing = reduce_op in ("sum", "mean")
         if summing:
-            inv = gidx.csc().inv_degrees() if reduce_op == "mean" else None
+            # mean: d(sum/deg) -> scale dZ rows by 1/max(deg,1) once (one streaming pass) instead of a
+            # per-edge 4-byte gather of the factor inside the reversed SpMM (measured +20 % there)
+            dZs = dZ
+            if reduce_op == "mean":
+                inv = gidx.csc().inv_degrees()
+                dZs = dZ * inv.view((-1,) + (1,) * (dZ.dim() - 1))
             if op != "copy_rhs" and ctx.needs_input_grad[3]:
                 rev = gidx.csr()  # rows = src: the reversed graph's in-CSR
                 if op == "mul":
-                    dX, _, _ = sparse.gspmm_raw(rev, "mul", "sum", dZ, Y, src_scale=inv)
+                    dX, _, _ = sparse.gspmm_raw(rev, "mul", "sum", dZs, Y)
                 else:  # add, copy_lhs
-                    dX, _, _ = sparse.gspmm_raw(rev, "copy_lhs", "sum", dZ, None, src_scale=inv)
+                    dX, _, _ = sparse.gspmm_raw(rev, "copy_lhs", "sum", dZs, None)
                 dX = _reduce_grad(dX, ctx.x_shape)
             if op != "copy_lhs" and ctx.needs_input_grad[4]:
-                dZs = dZ if inv is None else dZ * inv.view((-1,) + (1,) * (dZ.dim() - 1))
                 if op == "mul":
                     if _need_reduce_last_dim(X, Y):
                         dY = sparse.gsddmm_raw(gidx, "dot", X, dZs, "u", "v")

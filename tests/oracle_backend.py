@@ -1,0 +1,104 @@
+"""TEST-ONLY backend: lets host-side logic (dispatch, autograd wiring, halo exchange, partitioning)
+run on CPU tensors by routing the arithmetic to the CPU oracle.  Registered by tests that need it
+(never by the product: mi355x_graph has no CPU path and raises DGLError on CPU tensors)."""
+import numpy as np
+import torch
+
+from mi355x_graph import sparse
+from oracle import oracle as orc
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+class OracleBackend(object):
+    name = "oracle"
+
+    def degrees(self, csr):
+        return (csr.indptr[1:] - csr.indptr[:-1]).to(csr.indptr.dtype)
+
+    def inv_degrees(self, csr):
+        d = (csr.indptr[1:] - csr.indptr[:-1]).clamp(min=1).to(torch.float32)
+        return 1.0 / d
+
+    def spmm(self, csr, op, reduce, U, E, u_len, e_len, out_len, u_off, e_off, src_scale, dst_scale, want_arg):
+        n = csr.num_rows
+        L = orc.lib()
+        Un = None if U is None else np.ascontiguousarray(_np(U).reshape(U.shape[0], -1), np.float32)
+        if src_scale is not None and Un is not None:
+            Un = Un * _np(src_scale)[:, None]
+        En = None if E is None else np.ascontiguousarray(_np(E).reshape(E.shape[0], -1), np.float32)
+        ip = np.ascontiguousarray(_np(csr.indptr), np.int32)
+        ix = np.ascontiguousarray(_np(csr.indices), np.int32)
+        ei = None if csr.eids is None else np.ascontiguousarray(_np(csr.eids), np.int32)
+
+        def table(off, length):
+            if off is not None:
+                return np.ascontiguousarray(_np(off), np.int64)
+            if length == out_len or length == 0:
+                return None
+            return (np.arange(out_len, dtype=np.int64) // (out_len // length))
+
+        uo, eo = table(u_off, u_len), table(e_off, e_len)
+        red = "sum" if reduce == "mean" else reduce
+        out = np.empty((n, out_len), np.float32)
+        au = np.full((n, out_len), -1, np.int32)
+        ae = np.full((n, out_len), -1, np.int32)
+        L.orc_spmm(orc._c64(n), orc._p(ip), orc._p(ix), orc._p(ei), orc._ci(orc.OPS[op]), orc._ci(orc.REDUCES[red]),
+                   orc._p(Un), orc._p(En), orc._c64(u_len), orc._c64(e_len), orc._c64(out_len), orc._p(uo), orc._p(eo),
+                   orc._p(out), orc._p(au), orc._p(ae))
+        if reduce == "mean":
+            out = out / np.maximum(np.diff(ip), 1).astype(np.float32)[:, None]
+        if dst_scale is not None:
+            out = out * _np(dst_scale)[:, None]
+        idt = csr.indptr.dtype
+        return (torch.from_numpy(out), torch.from_numpy(au).to(idt) if want_arg and op != "copy_rhs" else None,
+                torch.from_numpy(ae).to(idt) if want_arg and op != "copy_lhs" else None)
+
+    def sddmm(self, gidx, op, L, R, lt, rt, l_len, r_len, out_len, reduce_size, l_off, r_off):
+        src, dst = gidx.coo()
+        nnz = gidx.num_edges()
+        Ln = None if L is None else np.ascontiguousarray(_np(L).reshape(L.shape[0], -1), np.float32)
+        Rn = None if R is None else np.ascontiguousarray(_np(R).reshape(R.shape[0], -1), np.float32)
+
+        def table(off, length, full):
+            if off is not None:
+                return np.ascontiguousarray(_np(off), np.int64)
+            if length == full or length == 0:
+                return None
+            return (np.arange(out_len, dtype=np.int64) // (full // length))
+
+        full = out_len * reduce_size
+        lo, ro = table(l_off, l_len, full), table(r_off, r_len, full)
+        out = np.empty((nnz, out_len), np.float32)
+        s32 = np.ascontiguousarray(_np(src), np.int32)
+        d32 = np.ascontiguousarray(_np(dst), np.int32)
+        orc.lib().orc_sddmm(orc._c64(nnz), orc._p(s32), orc._p(d32), orc._ci(orc.OPS[op]), orc._p(Ln), orc._p(Rn),
+                            orc._ci(orc.TARGETS[lt]), orc._ci(orc.TARGETS[rt]), orc._c64(l_len), orc._c64(r_len),
+                            orc._c64(out_len), orc._c64(reduce_size), orc._p(lo), orc._p(ro), orc._p(out))
+        return torch.from_numpy(out)
+
+    def edge_softmax_fwd(self, csr, z2d):
+        return torch.from_numpy(orc.edge_softmax_fwd(_np(csr.indptr), _np(csr.eids), _np(z2d)))
+
+    def edge_softmax_bwd(self, csr, a2d, da2d):
+        return torch.from_numpy(orc.edge_softmax_bwd(_np(csr.indptr), _np(csr.eids), _np(a2d), _np(da2d)))
+
+    def segment_reduce(self, offsets, x2d, reduce, want_arg):
+        return torch.from_numpy(orc.segment_reduce(_np(offsets), _np(x2d), reduce)), None
+
+    def gather_rows(self, x2d, idx):
+        return x2d[idx.long()].contiguous()
+
+    def scatter_add_rows(self, x2d, idx, rows2d):
+        x2d.index_add_(0, idx.long(), rows2d)
+        return x2d
+
+
+def install():
+    sparse.register_backend("cpu", OracleBackend())
+
+
+def uninstall():
+    sparse._BACKENDS.pop("cpu", None)

@@ -1,0 +1,149 @@
+"""CPU suite: the multi-GPU path (partition + halo exchange + gradient all-reduce) with world_size 2
+over gloo.  The arithmetic of each rank runs on the TEST-ONLY oracle backend; what is under test is
+the host logic of mi355x_graph/dist.py: a P-way partitioned forward/backward must reproduce the
+1-process result (SURVEY 8e "parity under sharding")."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import mi355x_graph as mg
+from mi355x_graph import dist as mdist
+import oracle_backend
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dgl-0.5-benchmark_amd")
+
+
+def make_problem():
+    from mi355x_graph.datasets import synthetic_edges
+    n = 600
+    src, dst = synthetic_edges(n, 4000, 60, seed=3, symmetric=True)
+    g = torch.Generator().manual_seed(0)
+    feats = torch.rand(n, 12, generator=g)
+    labels = torch.randint(0, 5, (n,), generator=g)
+    train = torch.rand(n, generator=g) < 0.3
+    return n, src, dst, feats, labels, train
+
+
+def build_model():
+    sys.path.insert(0, PKG)
+    import full_graph
+    torch.manual_seed(1)
+    return full_graph.GraphSAGE(12, 8, 5, 3, dropout=0.0)
+
+
+def single_process_reference():
+    import torch.nn.functional as F
+    n, src, dst, feats, labels, train = make_problem()
+    g = mg.graph((src, dst), num_nodes=n).int()
+    model = build_model()
+    out = model(g, feats)
+    loss = F.nll_loss(out[train], labels[train])
+    loss.backward()
+    return out.detach(), loss.item(), [p.grad.clone() for p in model.parameters()]
+
+
+def _worker(rank, world, port, q):
+    import torch.nn.functional as F
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle_backend.install()
+    n, src, dst, feats, labels, train = make_problem()
+    assign, stats = mdist.partition_nodes(src, dst, n, world)
+    block, plan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
+    g = mdist.DistGraph(block, plan)
+    model = build_model()
+    mdist.broadcast_parameters(model)
+    x, y, m = feats[own], labels[own], train[own]
+    total = torch.tensor([float(train.sum())])
+    out = model(g, x)
+    loss = F.nll_loss(out[m], y[m], reduction="sum") / total  # global mean
+    loss.backward()
+    mdist.allreduce_gradients(model)
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    q.put((rank, own.numpy(), out.detach().numpy(), float(lsum), [p.grad.numpy() for p in model.parameters()],
+           stats, plan.n_halo, sum(plan.send_splits)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_way_partition_matches_single_process():
+    oracle_backend.install()
+    try:
+        ref_out, ref_loss, ref_grads = single_process_reference()
+    finally:
+        oracle_backend.uninstall()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    got = torch.zeros_like(ref_out)
+    seen = np.zeros(ref_out.shape[0], bool)
+    for rank, own, out, lsum, grads, stats, n_halo, n_send in res:
+        got[own] = torch.from_numpy(out)
+        assert not seen[own].any()
+        seen[own] = True
+        assert abs(lsum - ref_loss) < 1e-5
+        for g, r in zip(grads, ref_grads):
+            assert np.allclose(g, r.numpy(), rtol=1e-4, atol=1e-6)
+        assert 0.0 < stats["edge_cut"] < 0.6 and n_halo > 0 and n_send > 0
+    assert seen.all()
+    assert torch.allclose(got, ref_out, rtol=1e-4, atol=1e-6)
+
+
+def test_partition_is_balanced_and_cuts_less_than_random():
+    from mi355x_graph.datasets import synthetic_edges
+    n = 40000
+    src, dst = synthetic_edges(n, 500000, 1000, seed=5, symmetric=True)  # 25 % of edges leave their community
+    oracle_backend.install()
+    try:
+        for parts, bound in ((2, 0.25), (4, 0.40), (8, 0.55)):
+            assign, stats = mdist.partition_nodes(src, dst, n, parts)
+            load = torch.bincount(assign[dst], minlength=parts).float()
+            assert load.max() / load.mean() < 1.10
+            rnd = torch.randint(0, parts, (n,))
+            assert stats["edge_cut"] < 0.7 * float((rnd[src] != rnd[dst]).float().mean())
+            assert stats["edge_cut"] < bound
+    finally:
+        oracle_backend.uninstall()
+
+
+def test_halo_plan_consistency():
+    """Every rank's receive list from q must equal q's send list to it (same order)."""
+    from mi355x_graph.datasets import synthetic_edges
+    n, world = 800, 4
+    src, dst = synthetic_edges(n, 6000, 80, seed=9, symmetric=False)
+    oracle_backend.install()
+    try:
+        assign, _ = mdist.partition_nodes(src, dst, n, world)
+    finally:
+        oracle_backend.uninstall()
+    parts = [mdist.build_local_partition(src, dst, n, assign, r, world) for r in range(world)]
+    for r, (block, plan, own) in enumerate(parts):
+        assert plan.n_own == int((assign == r).sum())
+        assert block.number_of_edges() == int((assign[dst] == r).sum())
+        for q in range(world):
+            assert plan.recv_splits[q] == parts[q][1].send_splits[r]
+        assert plan.recv_splits[r] == 0 and plan.send_splits[r] == 0
+        # global ids of what peers send me, in order == my halo order
+        got = []
+        for q in range(world):
+            a, b = parts[q][1].send_ranges[r]
+            got.append(parts[q][2][parts[q][1].send_idx[a:b].long()])
+        got = torch.cat(got)
+        ls, ld = block.edges()
+        es, ed = src[assign[dst] == r], dst[assign[dst] == r]
+        full_ids = torch.cat([own, got])
+        assert torch.equal(full_ids[ls.long()], es) and torch.equal(own[ld.long()], ed)
