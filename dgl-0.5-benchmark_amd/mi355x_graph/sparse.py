@@ -17,6 +17,9 @@ from . import _lib
 from ._lib import DGLError, MgxCsr, OP, REDUCE, TARGET
 
 
+PROFILE = None  # set to a list by bench.py to collect per-launch HIP-event timings of mgx_spmm_csr
+
+
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -211,11 +214,20 @@ class HipBackend(object):
         if plan is not None and plan.num_slots:
             partial = torch.empty((plan.num_slots, out_len), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
+            rec = None
+            if PROFILE is not None:  # bench.py: HIP events on the launch stream around this launch
+                rec = {"op": op, "reduce": reduce, "out_len": out_len, "n_rows": csr.num_rows, "n_cols": csr.num_cols,
+                       "nnz": csr.nnz, "start": torch.cuda.Event(enable_timing=True),
+                       "end": torch.cuda.Event(enable_timing=True)}
+                rec["start"].record(torch.cuda.current_stream(dev))
             _lib.check(_lib.lib().mgx_spmm_csr(
                 ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()),
                 OP[op], REDUCE[reduce], _ptr(U), _ptr(E), u_len, e_len, out_len,
                 _ptr(u_off), _ptr(e_off), _ptr(src_scale), _ptr(dst_scale), _ptr(out), _ptr(arg_u), _ptr(arg_e),
                 _ptr(partial), _stream(dev)))
+            if rec is not None:
+                rec["end"].record(torch.cuda.current_stream(dev))
+                PROFILE.append(rec)
         return out, arg_u, arg_e
 
     def sddmm(self, graph_index, op, L, R, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size, l_off, r_off):
