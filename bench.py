@@ -42,17 +42,29 @@ def spmm_algorithmic_bytes(n_dst, n_src, nnz, D):
     return 4 * (n_dst + 1) + 4 * nnz + 4 * n_src * D + 4 * n_dst * D
 
 
+def host_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(g, feat_dim, hidden, budget_s=30.0):
     """Times the oracle's g-SpMM (row-parallel OpenMP, sequential in-row fp32 accumulation -- the
     algorithm of DGL's CPU kernel) on the epoch's five aggregations, inputs already in host memory."""
     import numpy as np
     from oracle import oracle as orc
     orc.build()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
+    cores = host_cores()
     orc.set_num_threads(cores)
     csc, csr = g._index.csc(), g._index.csr()
     n, nnz = csc.num_rows, csc.nnz

@@ -221,21 +221,25 @@ class _Comm(object):
         self.group = group
 
     def all_to_all(self, out, inp, out_splits, in_splits):
-        if dist.get_backend(self.group) == "gloo":  # gloo has no all_to_all_single: pairwise isend/irecv
+        if dist.get_backend(self.group) == "gloo":  # tests: pairwise isend/irecv staged through host memory
             world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
             outs = list(out.split(out_splits, 0))
             inps = list(inp.split(in_splits, 0))
             outs[rank].copy_(inps[rank])
-            reqs = []
+            reqs, landing = [], []
             for p in range(world):
                 if p == rank:
                     continue
                 if in_splits[p]:
-                    reqs.append(dist.isend(inps[p].contiguous(), p, group=self.group))
+                    reqs.append(dist.isend(inps[p].detach().cpu().contiguous(), p, group=self.group))
                 if out_splits[p]:
-                    reqs.append(dist.irecv(outs[p], p, group=self.group))
+                    buf = torch.empty(outs[p].shape, dtype=outs[p].dtype)
+                    landing.append((outs[p], buf))
+                    reqs.append(dist.irecv(buf, p, group=self.group))
             for r in reqs:
                 r.wait()
+            for dst_t, buf in landing:
+                dst_t.copy_(buf)
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 

@@ -36,53 +36,58 @@ def build_model():
     return full_graph.GraphSAGE(12, 8, 5, 3, dropout=0.0)
 
 
-def single_process_reference():
+def single_process_reference(device="cpu"):
     import torch.nn.functional as F
-    n, src, dst, feats, labels, train = make_problem()
+    n, src, dst, feats, labels, train = [t.to(device) if isinstance(t, torch.Tensor) else t for t in make_problem()]
     g = mg.graph((src, dst), num_nodes=n).int()
-    model = build_model()
+    model = build_model().to(device)
     out = model(g, feats)
     loss = F.nll_loss(out[train], labels[train])
     loss.backward()
-    return out.detach(), loss.item(), [p.grad.clone() for p in model.parameters()]
+    return out.detach().cpu(), loss.item(), [p.grad.cpu().clone() for p in model.parameters()]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, device="cpu"):
     import torch.nn.functional as F
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    oracle_backend.install()
-    n, src, dst, feats, labels, train = make_problem()
+    if device == "cpu":
+        oracle_backend.install()  # CPU tensors: arithmetic by the test-only oracle backend
+    n, src, dst, feats, labels, train = [t.to(device) if isinstance(t, torch.Tensor) else t for t in make_problem()]
     assign, stats = mdist.partition_nodes(src, dst, n, world)
     block, plan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
     g = mdist.DistGraph(block, plan)
-    model = build_model()
-    mdist.broadcast_parameters(model)
+    model = build_model().to(device)
+    if device == "cpu":
+        mdist.broadcast_parameters(model)  # same seed => same init; exercised on the CPU run only
     x, y, m = feats[own], labels[own], train[own]
-    total = torch.tensor([float(train.sum())])
+    total = torch.tensor([float(train.sum())], device=device)
     out = model(g, x)
     loss = F.nll_loss(out[m], y[m], reduction="sum") / total  # global mean
     loss.backward()
-    mdist.allreduce_gradients(model)
-    lsum = loss.detach().clone()
+    for prm in model.parameters():  # gloo all_reduce on host copies (RCCL path: mdist.allreduce_gradients)
+        gcpu = prm.grad.detach().cpu()
+        dist.all_reduce(gcpu)
+        prm.grad.copy_(gcpu)
+    lsum = loss.detach().cpu().clone()
     dist.all_reduce(lsum)
-    q.put((rank, own.numpy(), out.detach().numpy(), float(lsum), [p.grad.numpy() for p in model.parameters()],
-           stats, plan.n_halo, sum(plan.send_splits)))
+    q.put((rank, own.cpu().numpy(), out.detach().cpu().numpy(), float(lsum),
+           [p.grad.cpu().numpy() for p in model.parameters()], stats, plan.n_halo, sum(plan.send_splits)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_two_way_partition_matches_single_process():
-    oracle_backend.install()
+def _run_two_way(device):
+    if device == "cpu":
+        oracle_backend.install()
     try:
-        ref_out, ref_loss, ref_grads = single_process_reference()
+        ref_out, ref_loss, ref_grads = single_process_reference(device)
     finally:
         oracle_backend.uninstall()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + os.getpid() % 2000 + (7 if device != "cpu" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, device)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(2)]
@@ -101,6 +106,19 @@ def test_two_way_partition_matches_single_process():
         assert 0.0 < stats["edge_cut"] < 0.6 and n_halo > 0 and n_send > 0
     assert seen.all()
     assert torch.allclose(got, ref_out, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.timeout(300)
+def test_two_way_partition_matches_single_process():
+    _run_two_way("cpu")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_two_way_partition_on_gpu_matches_single_process():
+    """Two ranks sharing cuda:0 (gloo transport staged through the host): HIP kernels + HaloExchange +
+    mgx_gather_rows / mgx_scatter_add_rows, against the 1-process GPU result."""
+    _run_two_way("cuda:0")
 
 
 def test_partition_is_balanced_and_cuts_less_than_random():
