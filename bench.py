@@ -30,6 +30,16 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
+# Dense layers of the (unmodified) model are rocBLAS/hipBLASLt GEMMs; their default heuristics pick 3 ms kernels for
+# the tall-skinny weight-gradient shapes (K = 2.45 M).  PyTorch's TunableOp selections for exactly these shapes were
+# recorded once on MI355X (dgl-0.5-benchmark_amd/tunableop_products0.csv, 7 min of tuning) and are only LOADED here
+# (tuning off), which is a user-level PyTorch setting, not part of the message-passing library.
+if os.environ.get("MGX_BENCH_TUNABLEOP", "1") == "1":
+    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_RECORD_UNTUNED", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(PKG, "tunableop_products.csv"))
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
@@ -229,7 +239,8 @@ def main():
                                (n, num_edges, spec["feat"], cfg["hidden"], cfg["hidden"], spec["classes"],
                                 "1 GPU" if world == 1 else "edge-cut partition over %d GPUs, RCCL all_to_all halo" % world),
                    "spmm_per_epoch": 2 * cfg["num_layers"] - 1, "final_loss": loss,
-                   "schedule": os.environ.get("MGX_SCHEDULE", "auto"), "partition": part_stats},
+                   "schedule": os.environ.get("MGX_SCHEDULE", "auto"), "partition": part_stats,
+                   "dense_gemm_selection": "tunableop file" if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "default"},
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
