@@ -137,7 +137,16 @@ def load_data(args):
     """dgl.data.load_data(args): args.dataset in {cora, citeseer, pubmed, reddit*}."""
     name = args.dataset
     if name in ("cora", "citeseer", "pubmed"):
-        return NodeData(name)
+        # the citation scripts expect the legacy layout: `.graph` is a networkx DiGraph that they pass to
+        # dgl.from_networkx (main_dgl_citation_sage.py:190)
+        import networkx as nx
+        d = NodeData(name)
+        s, t = d.graph.edges()
+        nxg = nx.DiGraph()
+        nxg.add_nodes_from(range(d.num_nodes))
+        nxg.add_edges_from(zip(s.tolist(), t.tolist()))
+        d.graph = nxg
+        return d
     if name is not None and name.startswith("reddit"):
         return RedditDataset(self_loop=("self-loop" in name))
     raise ValueError("Unknown dataset: {}".format(name))

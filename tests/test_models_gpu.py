@@ -22,6 +22,17 @@ def nerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
 
 
+def grads_close(got, params, tol):
+    """Per-tensor error relative to that tensor's scale; tensors whose true gradient is ~0 (e.g. attention
+    vectors the softmax is nearly invariant to) are held to the scale of the largest gradient instead."""
+    gmax = max(float(p.grad.abs().max()) for p in params if p.grad is not None)
+    for a, p in zip(got, params):
+        if p.grad is None:
+            continue
+        scale = max(float(p.grad.abs().max()), 1e-3 * gmax)
+        assert float((a - p.grad).abs().max()) / scale < tol
+
+
 def agg(dst, msg, n):
     return torch.zeros((n,) + msg.shape[1:], device=msg.device).index_add(0, dst, msg)
 
@@ -52,8 +63,7 @@ def test_sage_products_model_matches_gather_reference():
     ref_loss = F.nll_loss(h.log_softmax(-1)[idx], y[idx])
     ref_loss.backward()
     assert abs(loss.item() - ref_loss.item()) < 1e-5
-    for a, p in zip(got, model.parameters()):
-        assert nerr(a, p.grad) < 1e-4
+    grads_close(got, list(model.parameters()), 1e-4)
 
 
 @pytest.mark.parametrize("heads,layers", [(8, 2), (1, 3)])
@@ -97,8 +107,7 @@ def test_gat_matches_gather_reference(heads, layers):
     ref_loss = F.cross_entropy(ref[mask], y[mask])
     ref_loss.backward()
     assert abs(loss.item() - ref_loss.item()) < 1e-5
-    for a, p in zip(got, model.parameters()):
-        assert nerr(a, p.grad) < 2e-4
+    grads_close(got, list(model.parameters()), 2e-4)
     with pytest.raises(mg.DGLError, match="0-in-degree"):
         g0 = dgl.graph((torch.tensor([0, 1]), torch.tensor([1, 2])), num_nodes=4).int().to(DEV)
         model.gat_layers[0](g0, torch.rand(4, 32, device=DEV))
@@ -140,9 +149,7 @@ def test_molhiv_gcn_batched_udf_and_readout():
     ref = model.graph_pred_fc(pooled)
     assert nerr(out, ref) < 1e-4
     F.binary_cross_entropy_with_logits(ref.view(-1), labels.to(DEV).float()).backward()
-    for a, p in zip(got, model.parameters()):
-        if p.grad is not None:
-            assert nerr(a, p.grad) < 2e-4
+    grads_close(got, list(model.parameters()), 2e-4)
     # bit-exact integer work on the batch: degrees and batch offsets
     assert torch.equal(bg.in_degrees().long(), torch.bincount(d, minlength=n))
     parts = dgl.unbatch(bg.to("cpu"))

@@ -1,0 +1,43 @@
+"""CPU suite (runs only where /root/reference exists): the reference's own training scripts executed
+UNMODIFIED on this repo's `dgl` package -- the plumbing check of BASELINE config 0 ("2-layer GraphSAGE on cora
+... runs without a GPU").  Arithmetic on CPU tensors goes through the test-only oracle backend."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+REF = "/root/reference/end_to_end/full_graph"
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+
+
+def run(script, *args):
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "run_reference_script.py"), os.path.join(REF, script)] + list(args),
+                       capture_output=True, text=True, timeout=600, env=env, cwd=HERE)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    return p.stdout
+
+
+SCRIPTS = [
+    ("node_classification/main_dgl_citation_sage.py", ["--dataset", "cora", "--epochs", "5", "--runs", "1"]),
+    ("node_classification/main_dgl_citation_sage.py", ["--dataset", "cora", "--epochs", "5", "--runs", "1", "--aggr", "sum", "--eval"]),
+    ("node_classification/main_dgl_citation_gat.py", ["--dataset", "cora", "--epochs", "5", "--runs", "1"]),
+    ("node_classification/main_dgl_product_sage.py", ["--epochs", "5", "--runs", "1", "--eval"]),
+    ("node_classification/main_dgl_arxiv_sage.py", ["--epochs", "5", "--runs", "1"]),
+    ("node_classification/main_dgl_arxiv_gat.py", ["--epochs", "5", "--runs", "1"]),
+    ("node_classification/main_dgl_arxiv_sage_nn.py", ["--epochs", "5", "--runs", "1"]),
+    ("node_classification/main_dgl_proteins_rgcn_for.py", ["--epochs", "4", "--runs", "1"]),
+    ("graph_classification/main_dgl_molhiv_gcn.py", ["--epochs", "2", "--runs", "1", "--batch_size", "16", "--num_workers", "0"]),
+]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("script,args", SCRIPTS, ids=[s[0].split("/")[-1] + ("-" + s[1][-1].strip("-") if s[1][-1].startswith("--") else "") for s in SCRIPTS])
+def test_reference_script_runs_unmodified(script, args):
+    out = run(script, *args)
+    times = re.findall(r"Training time/epoch ([0-9.eE+-]+)", out)
+    if "molhiv" not in script:
+        assert times, out[-1500:]
