@@ -6,6 +6,10 @@
 // row-segmented kernel: a wavefront owns a destination row, lanes are laid out as
 // (edge slot, head), the row's logits are read ONCE into registers when in-degree*LH <= 64*kCache
 // (re-read from L2 otherwise), max and sum are combined by xor-shuffles, one write.
+//
+// Hub rows: with an mgx_spmm_plan, rows longer than the plan's split threshold are processed as
+// chunks -- (1) per-chunk statistics (max, sum-exp | sum a*da), (2) a per-hub combine in slot
+// order, (3) a per-chunk normalise -- so a 21k-edge reddit hub no longer serialises on one wave.
 #include <math.h>
 
 #include "common.h"
@@ -13,7 +17,7 @@
 namespace mgx {
 
 constexpr int kCache = 4;
-constexpr int kSmRows = 64;
+constexpr int kSmRows = 16;  // work items per workgroup (same reasoning as spmm.hip)
 
 template <typename Idx>
 struct SoftmaxArgs {
@@ -22,113 +26,246 @@ struct SoftmaxArgs {
   const float* x;   // fwd: z        bwd: a
   const float* y;   // fwd: unused   bwd: da
   float* out;       // fwd: a        bwd: dz
+  // schedule (optional)
+  const int32_t* item_row;
+  const Idx* item_beg;
+  const Idx* item_end;
+  const int32_t* slot_item;     // [num_slots] work item of each partial slot
+  const int32_t* hub_slot_ptr;  // [num_hubs + 1]
+  float* partial;               // [num_slots, 2H]  fwd: (max, sumexp)   bwd: (sum a*da, unused)
+  float* hubstat;               // [num_hubs, 2H]
+  int64_t n_items;
+  int64_t n_slots;
+  int64_t n_hubs;
   int64_t n_rows;
   int64_t nblocks;
   int H;
 };
 
-// LH = lanes per edge (pow2 >= H); 64/LH edges per step.
-template <typename Idx, int LH, bool BWD>
-__global__ __launch_bounds__(kBlock) void edge_softmax_kernel(const SoftmaxArgs<Idx> a) {
+enum { SM_FULL = 0, SM_STATS = 1, SM_APPLY = 2 };
+
+// One edge range [beg, end) of one destination row, handled by one wave.
+//   SM_FULL : statistics + output for a whole row.
+//   SM_STATS: statistics of a chunk -> st0/st1 (fwd: max, sum exp(z - max); bwd: sum a*da, -)
+//   SM_APPLY: output of a chunk from the row's combined statistics st0/st1.
+template <typename Idx, int LH, bool BWD, int MODE>
+__device__ __forceinline__ void softmax_range(const SoftmaxArgs<Idx>& a, int64_t beg, int64_t end, float& st0,
+                                              float& st1) {
   constexpr int EPI = kWave / LH;
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
   const int j = lane / LH, h = lane % LH;
   const bool hactive = h < a.H;
   const int64_t H = a.H;
-  const int64_t row_base = xcd_remap(blockIdx.x, a.nblocks) * kSmRows;
-  for (int r = wave; r < kSmRows; r += kWavesPerBlock) {
-    const int64_t row = row_base + r;
-    if (row >= a.n_rows) break;
-    const int64_t beg = (int64_t)a.indptr[row], end = (int64_t)a.indptr[row + 1];
-    if (beg == end) continue;
-    int64_t es[kCache];
-    float xs[kCache];
-    float red = BWD ? 0.f : -INFINITY;
+  int64_t es[kCache];
+  float xs[kCache];
 #pragma unroll
-    for (int c = 0; c < kCache; ++c) {
-      const int64_t p = beg + j + (int64_t)c * EPI;
-      const bool ok = p < end && hactive;
-      es[c] = ok ? (a.eids ? (int64_t)a.eids[p] : p) : -1;
-    }
-    if (!BWD) {
+  for (int c = 0; c < kCache; ++c) {
+    const int64_t p = beg + j + (int64_t)c * EPI;
+    const bool ok = p < end && hactive;
+    es[c] = ok ? (a.eids ? (int64_t)a.eids[p] : p) : -1;
+  }
+  const int64_t tail = beg + j + (int64_t)kCache * EPI;
+  if (!BWD) {
+    float m = st0, s = st1;
 #pragma unroll
-      for (int c = 0; c < kCache; ++c) {
-        xs[c] = es[c] >= 0 ? a.x[es[c] * H + h] : -INFINITY;
-        red = fmaxf(red, xs[c]);
-      }
-      for (int64_t p = beg + j + (int64_t)kCache * EPI; p < end; p += EPI)
+    for (int c = 0; c < kCache; ++c) xs[c] = es[c] >= 0 ? a.x[es[c] * H + h] : -INFINITY;
+    if (MODE != SM_APPLY) {
+      float red = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < kCache; ++c) red = fmaxf(red, xs[c]);
+      for (int64_t p = tail; p < end; p += EPI)
         if (hactive) red = fmaxf(red, a.x[(a.eids ? (int64_t)a.eids[p] : p) * H + h]);
 #pragma unroll
       for (int off = LH; off < kWave; off <<= 1) red = fmaxf(red, __shfl_xor(red, off, kWave));
-      const float m = red;
-      float s = 0.f;
+      m = red;
+      s = 0.f;
 #pragma unroll
       for (int c = 0; c < kCache; ++c) {
         xs[c] = es[c] >= 0 ? expf(xs[c] - m) : 0.f;
         s += xs[c];
       }
-      for (int64_t p = beg + j + (int64_t)kCache * EPI; p < end; p += EPI)
+      for (int64_t p = tail; p < end; p += EPI)
         if (hactive) s += expf(a.x[(a.eids ? (int64_t)a.eids[p] : p) * H + h] - m);
 #pragma unroll
       for (int off = LH; off < kWave; off <<= 1) s += __shfl_xor(s, off, kWave);
-#pragma unroll
-      for (int c = 0; c < kCache; ++c)
-        if (es[c] >= 0) a.out[es[c] * H + h] = xs[c] / s;
-      for (int64_t p = beg + j + (int64_t)kCache * EPI; p < end; p += EPI)
-        if (hactive) {
-          const int64_t e = a.eids ? (int64_t)a.eids[p] : p;
-          a.out[e * H + h] = expf(a.x[e * H + h] - m) / s;
-        }
+      st0 = m;
+      st1 = s;
+      if (MODE == SM_STATS) return;
     } else {
-      float ys[kCache];
 #pragma unroll
-      for (int c = 0; c < kCache; ++c) {
-        xs[c] = es[c] >= 0 ? a.x[es[c] * H + h] : 0.f;  // a
-        ys[c] = es[c] >= 0 ? a.y[es[c] * H + h] : 0.f;  // da
-        red += xs[c] * ys[c];
+      for (int c = 0; c < kCache; ++c) xs[c] = es[c] >= 0 ? expf(xs[c] - m) : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < kCache; ++c)
+      if (es[c] >= 0) a.out[es[c] * H + h] = xs[c] / s;
+    for (int64_t p = tail; p < end; p += EPI)
+      if (hactive) {
+        const int64_t e = a.eids ? (int64_t)a.eids[p] : p;
+        a.out[e * H + h] = expf(a.x[e * H + h] - m) / s;
       }
-      for (int64_t p = beg + j + (int64_t)kCache * EPI; p < end; p += EPI)
+  } else {
+    float ys[kCache];
+#pragma unroll
+    for (int c = 0; c < kCache; ++c) {
+      xs[c] = es[c] >= 0 ? a.x[es[c] * H + h] : 0.f;  // a
+      ys[c] = es[c] >= 0 ? a.y[es[c] * H + h] : 0.f;  // da
+    }
+    float red = st0;
+    if (MODE != SM_APPLY) {
+      red = 0.f;
+#pragma unroll
+      for (int c = 0; c < kCache; ++c) red += xs[c] * ys[c];
+      for (int64_t p = tail; p < end; p += EPI)
         if (hactive) {
           const int64_t e = a.eids ? (int64_t)a.eids[p] : p;
           red += a.x[e * H + h] * a.y[e * H + h];
         }
 #pragma unroll
       for (int off = LH; off < kWave; off <<= 1) red += __shfl_xor(red, off, kWave);
+      st0 = red;
+      if (MODE == SM_STATS) return;
+    }
 #pragma unroll
-      for (int c = 0; c < kCache; ++c)
-        if (es[c] >= 0) a.out[es[c] * H + h] = xs[c] * ys[c] - xs[c] * red;
-      for (int64_t p = beg + j + (int64_t)kCache * EPI; p < end; p += EPI)
-        if (hactive) {
-          const int64_t e = a.eids ? (int64_t)a.eids[p] : p;
-          const float av = a.x[e * H + h];
-          a.out[e * H + h] = av * a.y[e * H + h] - av * red;
-        }
+    for (int c = 0; c < kCache; ++c)
+      if (es[c] >= 0) a.out[es[c] * H + h] = xs[c] * ys[c] - xs[c] * red;
+    for (int64_t p = tail; p < end; p += EPI)
+      if (hactive) {
+        const int64_t e = a.eids ? (int64_t)a.eids[p] : p;
+        const float av = a.x[e * H + h];
+        a.out[e * H + h] = av * a.y[e * H + h] - av * red;
+      }
+  }
+}
+
+// LH = lanes per edge (pow2 >= H); 64/LH edges per step.
+template <typename Idx, int LH, bool BWD>
+__global__ __launch_bounds__(kBlock) void edge_softmax_kernel(const SoftmaxArgs<Idx> a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int h = lane % LH;
+  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * kSmRows;
+  for (int r = wave; r < kSmRows; r += kWavesPerBlock) {
+    const int64_t item = item_base + r;
+    if (item >= a.n_items) break;
+    int64_t row, beg, end;
+    if (a.item_row) {
+      row = (int64_t)a.item_row[item];
+      beg = (int64_t)a.item_beg[item];
+      end = (int64_t)a.item_end[item];
+    } else {
+      row = item;
+      beg = (int64_t)a.indptr[item];
+      end = (int64_t)a.indptr[item + 1];
+    }
+    if (beg == end) continue;
+    float s0 = 0.f, s1 = 0.f;
+    if (row >= 0) {
+      softmax_range<Idx, LH, BWD, SM_FULL>(a, beg, end, s0, s1);
+    } else {
+      softmax_range<Idx, LH, BWD, SM_STATS>(a, beg, end, s0, s1);
+      const int64_t slot = -(row + 1);
+      if (lane < LH && h < a.H) {  // lanes of edge slot 0 hold the combined value for every head
+        a.partial[slot * 2 * a.H + h] = s0;
+        a.partial[slot * 2 * a.H + a.H + h] = s1;
+      }
     }
   }
 }
 
+// per hub row: combine the chunk statistics in slot order (deterministic); one thread per (hub, head)
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void softmax_hub_combine_kernel(const int32_t* hub_slot_ptr, int64_t n_hubs, int H,
+                                                                     const float* partial, float* hubstat) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_hubs * H) return;
+  const int64_t hub = t / H;
+  const int h = (int)(t % H);
+  const int s_beg = hub_slot_ptr[hub], s_end = hub_slot_ptr[hub + 1];
+  if (!BWD) {
+    float m = -INFINITY;
+    for (int s = s_beg; s < s_end; ++s) m = fmaxf(m, partial[(int64_t)s * 2 * H + h]);
+    float sum = 0.f;
+    for (int s = s_beg; s < s_end; ++s) {
+      const float mc = partial[(int64_t)s * 2 * H + h];
+      if (mc > -INFINITY) sum += partial[(int64_t)s * 2 * H + H + h] * expf(mc - m);
+    }
+    hubstat[hub * 2 * H + h] = m;
+    hubstat[hub * 2 * H + H + h] = sum;
+  } else {
+    float acc = 0.f;
+    for (int s = s_beg; s < s_end; ++s) acc += partial[(int64_t)s * 2 * H + h];
+    hubstat[hub * 2 * H + h] = acc;
+    hubstat[hub * 2 * H + H + h] = 0.f;
+  }
+}
+
+// one wave per partial slot: normalise its chunk with the hub row's combined statistics
+template <typename Idx, int LH, bool BWD>
+__global__ __launch_bounds__(kBlock) void softmax_hub_apply_kernel(const SoftmaxArgs<Idx> a) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int h = lane % LH;
+  const int64_t slot = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (slot >= a.n_slots) return;
+  int64_t lo = 0, hi = a.n_hubs;  // last hub whose first slot <= slot
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)a.hub_slot_ptr[mid] <= slot) lo = mid; else hi = mid;
+  }
+  const int64_t item = a.slot_item[slot];
+  const int64_t beg = (int64_t)a.item_beg[item], end = (int64_t)a.item_end[item];
+  float s0 = 0.f, s1 = 1.f;
+  if (h < a.H) {
+    s0 = a.hubstat[lo * 2 * a.H + h];
+    s1 = a.hubstat[lo * 2 * a.H + a.H + h];
+  }
+  if (beg < end) softmax_range<Idx, LH, BWD, SM_APPLY>(a, beg, end, s0, s1);
+}
+
 template <typename Idx, bool BWD>
-static int32_t softmax_launch(const mgx_csr* csr, int64_t H, const float* x, const float* y, float* out,
-                              hipStream_t s) {
+static int32_t softmax_launch(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, const float* x, const float* y,
+                              float* out, float* ws, hipStream_t s) {
   if (csr->num_rows == 0 || csr->nnz == 0 || H == 0) return MGX_OK;
-  SoftmaxArgs<Idx> a;
+  SoftmaxArgs<Idx> a{};
   a.indptr = (const Idx*)csr->indptr; a.eids = (const Idx*)csr->eids; a.x = x; a.y = y; a.out = out;
-  a.n_rows = csr->num_rows; a.H = (int)H;
-  a.nblocks = round_up((csr->num_rows + kSmRows - 1) / kSmRows, kXcds);
+  a.n_rows = csr->num_rows; a.H = (int)H; a.n_items = csr->num_rows;
+  if (plan) {
+    MGX_CHECK_ARG(plan->item_row && plan->item_beg && plan->item_end && plan->num_items >= csr->num_rows,
+                  "mgx_edge_softmax: malformed plan");
+    a.item_row = plan->item_row; a.item_beg = (const Idx*)plan->item_beg; a.item_end = (const Idx*)plan->item_end;
+    a.n_items = plan->num_items; a.n_slots = plan->num_slots; a.n_hubs = plan->num_hubs;
+    if (plan->num_slots > 0) {
+      MGX_CHECK_ARG(ws && plan->slot_item && plan->hub_slot_ptr, "mgx_edge_softmax: plan has split rows but no workspace / slot tables");
+      a.slot_item = plan->slot_item; a.hub_slot_ptr = plan->hub_slot_ptr;
+      a.partial = ws; a.hubstat = ws + plan->num_slots * 2 * H;
+    }
+  }
+  a.nblocks = round_up((a.n_items + kSmRows - 1) / kSmRows, kXcds);
   MGX_CHECK_ARG(a.nblocks < (int64_t(1) << 31), "mgx_edge_softmax: too many rows");
   int LH = 1;
   while (LH < H) LH <<= 1;
   dim3 grid((unsigned)a.nblocks), block(kBlock);
+  dim3 sgrid((unsigned)((a.n_slots + kWavesPerBlock - 1) / kWavesPerBlock));
+#define MGX_SM_CASE(L)                                                                                      \
+  case L:                                                                                                   \
+    hipLaunchKernelGGL((edge_softmax_kernel<Idx, L, BWD>), grid, block, 0, s, a);                           \
+    if (a.n_slots > 0) {                                                                                    \
+      hipLaunchKernelGGL((softmax_hub_combine_kernel<BWD>), dim3((unsigned)((a.n_hubs * H + kBlock - 1) / kBlock)), \
+                         block, 0, s, a.hub_slot_ptr, a.n_hubs, a.H, (const float*)a.partial, a.hubstat);  \
+      hipLaunchKernelGGL((softmax_hub_apply_kernel<Idx, L, BWD>), sgrid, block, 0, s, a);                   \
+    }                                                                                                       \
+    break;
   switch (LH) {
-    case 1: hipLaunchKernelGGL((edge_softmax_kernel<Idx, 1, BWD>), grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((edge_softmax_kernel<Idx, 2, BWD>), grid, block, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((edge_softmax_kernel<Idx, 4, BWD>), grid, block, 0, s, a); break;
-    case 8: hipLaunchKernelGGL((edge_softmax_kernel<Idx, 8, BWD>), grid, block, 0, s, a); break;
-    case 16: hipLaunchKernelGGL((edge_softmax_kernel<Idx, 16, BWD>), grid, block, 0, s, a); break;
-    case 32: hipLaunchKernelGGL((edge_softmax_kernel<Idx, 32, BWD>), grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL((edge_softmax_kernel<Idx, 64, BWD>), grid, block, 0, s, a); break;
+    MGX_SM_CASE(1) MGX_SM_CASE(2) MGX_SM_CASE(4) MGX_SM_CASE(8) MGX_SM_CASE(16) MGX_SM_CASE(32)
+    default:
+      hipLaunchKernelGGL((edge_softmax_kernel<Idx, 64, BWD>), grid, block, 0, s, a);
+      if (a.n_slots > 0) {
+        hipLaunchKernelGGL((softmax_hub_combine_kernel<BWD>), dim3((unsigned)((a.n_hubs * H + kBlock - 1) / kBlock)),
+                           block, 0, s, a.hub_slot_ptr, a.n_hubs, a.H, (const float*)a.partial, a.hubstat);
+        hipLaunchKernelGGL((softmax_hub_apply_kernel<Idx, 64, BWD>), sgrid, block, 0, s, a);
+      }
+      break;
   }
+#undef MGX_SM_CASE
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
@@ -144,21 +281,22 @@ static int32_t softmax_check(const mgx_csr* csr, int64_t H) {
 
 }  // namespace mgx
 
-extern "C" int32_t mgx_edge_softmax_fwd(const mgx_csr* csr, int64_t H, const float* z, float* a, void* stream) {
+extern "C" int32_t mgx_edge_softmax_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, const float* z,
+                                        float* a, float* ws, void* stream) {
   using namespace mgx;
   int32_t st = softmax_check(csr, H);
   if (st != MGX_OK) return st;
   MGX_CHECK_ARG(csr->nnz == 0 || H == 0 || (z && a), "mgx_edge_softmax_fwd: z/a is NULL");
-  if (csr->idx_bits == 32) return softmax_launch<int32_t, false>(csr, H, z, nullptr, a, (hipStream_t)stream);
-  return softmax_launch<int64_t, false>(csr, H, z, nullptr, a, (hipStream_t)stream);
+  if (csr->idx_bits == 32) return softmax_launch<int32_t, false>(csr, plan, H, z, nullptr, a, ws, (hipStream_t)stream);
+  return softmax_launch<int64_t, false>(csr, plan, H, z, nullptr, a, ws, (hipStream_t)stream);
 }
 
-extern "C" int32_t mgx_edge_softmax_bwd(const mgx_csr* csr, int64_t H, const float* a, const float* da, float* dz,
-                                        void* stream) {
+extern "C" int32_t mgx_edge_softmax_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, const float* a,
+                                        const float* da, float* dz, float* ws, void* stream) {
   using namespace mgx;
   int32_t st = softmax_check(csr, H);
   if (st != MGX_OK) return st;
   MGX_CHECK_ARG(csr->nnz == 0 || H == 0 || (a && da && dz), "mgx_edge_softmax_bwd: a/da/dz is NULL");
-  if (csr->idx_bits == 32) return softmax_launch<int32_t, true>(csr, H, a, da, dz, (hipStream_t)stream);
-  return softmax_launch<int64_t, true>(csr, H, a, da, dz, (hipStream_t)stream);
+  if (csr->idx_bits == 32) return softmax_launch<int32_t, true>(csr, plan, H, a, da, dz, ws, (hipStream_t)stream);
+  return softmax_launch<int64_t, true>(csr, plan, H, a, da, dz, ws, (hipStream_t)stream);
 }

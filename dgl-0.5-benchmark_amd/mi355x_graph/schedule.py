@@ -31,13 +31,15 @@ class MgxSpmmPlan(ctypes.Structure):
         ("hub_row", ctypes.c_void_p),
         ("hub_slot_ptr", ctypes.c_void_p),
         ("num_slots", ctypes.c_int64),
+        ("slot_item", ctypes.c_void_p),
     ]
 
 
 class SpmmPlan(object):
-    def __init__(self, item_row, item_beg, item_end, hub_row, hub_slot_ptr, num_slots, order_kind):
+    def __init__(self, item_row, item_beg, item_end, hub_row, hub_slot_ptr, num_slots, order_kind, slot_item=None):
         self.item_row, self.item_beg, self.item_end = item_row, item_beg, item_end
         self.hub_row, self.hub_slot_ptr, self.num_slots = hub_row, hub_slot_ptr, int(num_slots)
+        self.slot_item = slot_item
         self.order_kind = order_kind
         self._c = None
 
@@ -54,7 +56,8 @@ class SpmmPlan(object):
             self._c = MgxSpmmPlan(self.num_items, self.item_row.data_ptr(), self.item_beg.data_ptr(),
                                   self.item_end.data_ptr(), self.num_hubs,
                                   self.hub_row.data_ptr() if self.num_hubs else None,
-                                  self.hub_slot_ptr.data_ptr() if self.num_hubs else None, self.num_slots)
+                                  self.hub_slot_ptr.data_ptr() if self.num_hubs else None, self.num_slots,
+                                  self.slot_item.data_ptr() if self.num_slots else None)
         return self._c
 
 
@@ -126,6 +129,7 @@ def build_plan(csr, order=None, split=1024, order_kind="natural"):
         hub_row = torch.zeros(0, dtype=torch.int32, device=dev)
         hub_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
         slots = 0
+        slot_item = torch.zeros(0, dtype=torch.int32, device=dev)
     else:
         item_off = torch.cumsum(nchunk_o, 0) - nchunk_o
         pos = torch.repeat_interleave(torch.arange(n, device=dev), nchunk_o)
@@ -142,9 +146,10 @@ def build_plan(csr, order=None, split=1024, order_kind="natural"):
         torch.cumsum(nchunk_o[hub_pos], 0, out=hub_ptr[1:])
         slots = int(hub_ptr[-1].item())
         hub_ptr = hub_ptr.to(torch.int32)
+        slot_item = torch.nonzero(is_hub).flatten().to(torch.int32)  # slots are numbered in item order
     idt = csr.indptr.dtype
     return SpmmPlan(item_row.contiguous(), beg.to(idt).contiguous(), end.to(idt).contiguous(), hub_row.contiguous(),
-                    hub_ptr.contiguous(), slots, order_kind)
+                    hub_ptr.contiguous(), slots, order_kind, slot_item.contiguous())
 
 
 # nnz below which the whole gathered matrix is cache resident anyway and clustering cannot pay

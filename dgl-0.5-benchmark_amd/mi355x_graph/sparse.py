@@ -256,15 +256,29 @@ class HipBackend(object):
     def edge_softmax_fwd(self, csr, z2d):
         dev = self._check_dev(csr.indptr, z2d)
         a = torch.empty_like(z2d)
+        plan, ws = self._softmax_plan(csr, z2d.shape[1], dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_edge_softmax_fwd(ctypes.byref(csr.c_struct()), z2d.shape[1], _ptr(z2d), _ptr(a), _stream(dev)))
+            _lib.check(_lib.lib().mgx_edge_softmax_fwd(ctypes.byref(csr.c_struct()), plan, z2d.shape[1], _ptr(z2d), _ptr(a),
+                                                       _ptr(ws), _stream(dev)))
         return a
+
+    @staticmethod
+    def _softmax_plan(csr, H, dev):
+        plan = csr.plan()
+        if plan is None:
+            return None, None
+        ws = None
+        if plan.num_slots:
+            ws = torch.empty((plan.num_slots + plan.num_hubs) * 2 * H, dtype=torch.float32, device=dev)
+        return ctypes.byref(plan.c_struct()), ws
 
     def edge_softmax_bwd(self, csr, a2d, da2d):
         dev = self._check_dev(csr.indptr, a2d, da2d)
         dz = torch.empty_like(a2d)
+        plan, ws = self._softmax_plan(csr, a2d.shape[1], dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_edge_softmax_bwd(ctypes.byref(csr.c_struct()), a2d.shape[1], _ptr(a2d), _ptr(da2d), _ptr(dz), _stream(dev)))
+            _lib.check(_lib.lib().mgx_edge_softmax_bwd(ctypes.byref(csr.c_struct()), plan, a2d.shape[1], _ptr(a2d), _ptr(da2d),
+                                                       _ptr(dz), _ptr(ws), _stream(dev)))
         return dz
 
     def segment_reduce(self, offsets, x2d, reduce, want_arg):

@@ -89,6 +89,7 @@ typedef struct mgx_spmm_plan {
   const int32_t* hub_row;       /* [num_hubs] rows that were split */
   const int32_t* hub_slot_ptr;  /* [num_hubs+1] slots of hub h are [ptr[h], ptr[h+1]) */
   int64_t num_slots;            /* partial_ws holds num_slots * out_len floats */
+  const int32_t* slot_item;     /* [num_slots] index of the work item that owns each partial slot */
 } mgx_spmm_plan;
 
 /* ------------------------------------------------------------------ misc */
@@ -155,11 +156,14 @@ int32_t mgx_sddmm_csr(const mgx_csr* csr,
  * Replaces dgl.nn.functional.edge_softmax(graph, logits) (norm_by='dst') as called by GATConv
  * (main_dgl_reddit_gat.py:31-55).  DGL 0.6 runs 2 SpMM + 2 SDDMM + exp; here one fused
  * row-segmented kernel.  z, a, da, dz: [nnz, H] addressed by edge id.
+ *   With a plan, split (hub) rows are handled as chunks (statistics, combine, normalise) and `ws` must
+ *   hold (plan->num_slots + plan->num_hubs) * 2 * H floats; without a plan ws may be NULL.
  *   fwd: a[e,h]  = exp(z[e,h]-max_v) / sum_{e'->v} exp(z[e',h]-max_v)
  *   bwd: dz[e,h] = a*da - a * sum_{e'->v}(a*da)                                            */
-int32_t mgx_edge_softmax_fwd(const mgx_csr* csr, int64_t H, const float* z, float* a, void* stream);
-int32_t mgx_edge_softmax_bwd(const mgx_csr* csr, int64_t H, const float* a, const float* da,
-                             float* dz, void* stream);
+int32_t mgx_edge_softmax_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int64_t H,
+                             const float* z, float* a, float* ws, void* stream);
+int32_t mgx_edge_softmax_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int64_t H,
+                             const float* a, const float* da, float* dz, float* ws, void* stream);
 
 /* ------------------------------------------------------------------ segment reduce
  * Replaces dgl.nn.AvgPooling / dgl.ops.segment_reduce (main_dgl_molhiv_gcn.py:75,93).
