@@ -121,11 +121,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the message-passing library has no CPU path")
-    device = torch.device("cuda:%d" % local_rank)
+    # MGX_BENCH_SHARE_GPU=1 + MGX_DIST_BACKEND=gloo: smoke-run the N > 1 code path with all ranks on cuda:0
+    # (1-GPU boxes); the driver's real runs use one GPU per rank over RCCL.
+    share = os.environ.get("MGX_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("MGX_DIST_BACKEND", "nccl")
+    device = torch.device("cuda:%d" % (0 if share else local_rank))
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -159,7 +166,7 @@ def main():
             assign, part_stats = mdist.partition_nodes(src, dst, n, world)
         else:
             assign = torch.empty(n, dtype=torch.int64, device=device)
-        dist.broadcast(assign, 0)
+        mdist.broadcast(assign, 0)
         block, hplan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
         g = mdist.DistGraph(block, hplan)
         own_cpu = own.cpu()
@@ -201,7 +208,7 @@ def main():
     records, sparse.PROFILE = sparse.PROFILE, None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        mdist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # ---- roofline of the dominant kernel: copy_u g-SpMM at D = hidden (4 of the 5 launches per epoch)

@@ -209,6 +209,7 @@ def build_local_partition(src, dst, num_nodes, assign, rank, world, idtype=torch
     send_splits = torch.bincount(s_peer, minlength=world).cpu().tolist()
     block = DGLGraph(GraphIndex(n_own + n_halo, n_own, coo=(l_src.to(idtype).contiguous(), l_dst.to(idtype).contiguous())),
                      is_block=True)
+    block._index.csc().dst_is_src_prefix = True  # [owned | halo]: lets the schedule cluster the owned x owned part
     plan = HaloPlan(rank, world, n_own, n_halo, send_idx.to(idtype).contiguous(), send_splits, recv_splits)
     return block, plan, own
 
@@ -355,6 +356,31 @@ class DistGraph(DGLGraph):
 
 
 # ----------------------------------------------------------------------------- training helpers
+def _staged(group):
+    """gloo (tests / single-GPU smoke runs) moves device tensors through host memory."""
+    return dist.get_backend(group) == "gloo"
+
+
+def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+    if _staged(group) and t.is_cuda:
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def broadcast(t, src=0, group=None):
+    if _staged(group) and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src, group=group)
+    return t
+
+
 def allreduce_gradients(model, group=None):
     """One flat (bucketed) all_reduce(sum) over every parameter gradient -- the payload is tiny for
     these models (~30k floats for products SAGE), so a single call is latency-optimal on xGMI."""
@@ -362,7 +388,7 @@ def allreduce_gradients(model, group=None):
     if not grads:
         return
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for g in grads:
         n = g.numel()
@@ -372,4 +398,4 @@ def allreduce_gradients(model, group=None):
 
 def broadcast_parameters(model, src=0, group=None):
     for p in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(p.data, src, group=group)
+        broadcast(p.data, src, group=group)

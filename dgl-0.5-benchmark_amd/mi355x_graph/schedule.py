@@ -69,6 +69,9 @@ def label_propagation(indptr, indices, n, rounds=5, seed=0, node_w=None, max_wei
     deg = (indptr[1:] - indptr[:-1]).long()
     rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
     cols = indices.long()
+    if cols.numel() and int(cols.max().item()) >= n:  # block graph [dst-prefix | extra sources]: cluster the square part
+        keep = cols < n
+        rows, cols = rows[keep], cols[keep]
     labels = torch.arange(n, device=dev)
     gen = torch.Generator(device=dev)
     gen.manual_seed(seed)
@@ -100,8 +103,8 @@ def label_propagation(indptr, indices, n, rounds=5, seed=0, node_w=None, max_wei
 def locality_order(csr, rounds=5):
     """Row permutation placing rows of one (nested) cluster next to each other."""
     n = csr.num_rows
-    if n != csr.num_cols:
-        raise DGLError("locality_order needs a square graph")
+    if n > csr.num_cols:
+        raise DGLError("locality_order needs the destination nodes to be a prefix of the source nodes")
     hist = label_propagation(csr.indptr, csr.indices, n, rounds)
     order = torch.arange(n, device=csr.device)
     # stable sorts from the finest (earliest) to the coarsest (final) labels = lexicographic order
@@ -165,7 +168,8 @@ def plan_for(csr):
     split = int(os.environ.get("MGX_SPLIT", 256))  # 256 measured best on MI355X (1024: +5..10 %)
     want_cluster = mode == "cluster" or (mode == "auto" and csr.nnz >= _CLUSTER_MIN_NNZ)
     order, kind = None, "natural"
-    if want_cluster and csr.num_rows == csr.num_cols and csr.indices.numel():
+    square_like = csr.num_rows == csr.num_cols or getattr(csr, "dst_is_src_prefix", False)
+    if want_cluster and square_like and csr.indices.numel():
         order, kind = locality_order(csr), "cluster"
     plan = build_plan(csr, order, split, kind)
     if kind == "natural" and plan.num_hubs == 0:

@@ -38,7 +38,8 @@ def _prod(shape):
 class CsrView(object):
     """An immutable CSR over torch tensors (in-CSR: rows = destination nodes)."""
 
-    __slots__ = ("num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan")
+    __slots__ = ("num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan",
+                 "dst_is_src_prefix")
 
     def __init__(self, num_rows, num_cols, indptr, indices, eids):
         self.num_rows, self.num_cols = int(num_rows), int(num_cols)
@@ -47,6 +48,7 @@ class CsrView(object):
         self._deg = None
         self._inv_deg = None
         self._plan = False  # False = not built yet; None = run without a plan
+        self.dst_is_src_prefix = False  # block graphs whose destination nodes are the first source nodes
 
     @property
     def nnz(self):
