@@ -81,6 +81,11 @@ __device__ __forceinline__ void sddmm_edges(const SddmmArgs<Idx>& a, const int64
     if (e[i] >= 0 && kactive) *reinterpret_cast<V*>(a.out + e[i] * a.out_len + kc) = sddmm_op<V>(a.op, lv[i], rv[i]);
 }
 
+// COO form, software pipelined like spmm_rowwave_kernel: a wave owns kCooChunks * 64 consecutive edges;
+// the (src, dst) ids of 64 edges arrive by ONE coalesced load each (lane j <- edge j) and are handed to the
+// lane groups with ds_bpermute; the next 64 ids are requested before the current gathers are issued.
+constexpr int kCooChunks = 8;
+
 template <typename Idx, int VEC, int G, bool DIRECT>
 __global__ __launch_bounds__(kBlock) void sddmm_coo_kernel(const SddmmArgs<Idx> a) {
   constexpr int NB = kWave / G;
@@ -88,19 +93,36 @@ __global__ __launch_bounds__(kBlock) void sddmm_coo_kernel(const SddmmArgs<Idx> 
   const int sub = lane / G, l = lane % G;
   const int kc = (blockIdx.y * G + l) * VEC;
   const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-  const int64_t e0 = wave_id * (NB * kSddmmUnroll * kSddmmIters);
+  const int64_t e0 = wave_id * (kWave * kCooChunks);
+  if (e0 >= a.nnz) return;
   const bool need_u = a.lhs_target == MGX_TARGET_U || a.rhs_target == MGX_TARGET_U;
   const bool need_v = a.lhs_target == MGX_TARGET_V || a.rhs_target == MGX_TARGET_V;
-  for (int it = 0; it < kSddmmIters; ++it) {
-    int64_t u[kSddmmUnroll], v[kSddmmUnroll], e[kSddmmUnroll];
+  auto load_ids = [&](int64_t base, Idx& mu, Idx& mv) {
+    const int64_t q = base + lane;
+    mu = (need_u && q < a.nnz) ? a.src[q] : (Idx)0;
+    mv = (need_v && q < a.nnz) ? a.dst[q] : (Idx)0;
+  };
+  Idx mu, mv;
+  load_ids(e0, mu, mv);
+  for (int c = 0; c < kCooChunks; ++c) {
+    const int64_t base = e0 + (int64_t)c * kWave;
+    if (base >= a.nnz) break;  // wave-uniform
+    Idx nu = 0, nv = 0;
+    if (c + 1 < kCooChunks) load_ids(base + kWave, nu, nv);
+    const int cnt = (int)((a.nnz - base) < kWave ? (a.nnz - base) : kWave);
+    for (int k = 0; k < cnt; k += NB * kSddmmUnroll) {
+      int64_t u[kSddmmUnroll], v[kSddmmUnroll], e[kSddmmUnroll];
 #pragma unroll
-    for (int i = 0; i < kSddmmUnroll; ++i) {
-      const int64_t q = e0 + (int64_t)(it * kSddmmUnroll + i) * NB + sub;
-      e[i] = q < a.nnz ? q : -1;
-      u[i] = (e[i] >= 0 && need_u) ? (int64_t)a.src[q] : 0;
-      v[i] = (e[i] >= 0 && need_v) ? (int64_t)a.dst[q] : 0;
+      for (int i = 0; i < kSddmmUnroll; ++i) {
+        const int j = k + i * NB + sub;
+        u[i] = (int64_t)__shfl(mu, j & (kWave - 1), kWave);
+        v[i] = (int64_t)__shfl(mv, j & (kWave - 1), kWave);
+        e[i] = j < cnt ? base + j : -1;
+      }
+      sddmm_edges<Idx, VEC, G, false, DIRECT>(a, u, v, e, kc);
     }
-    sddmm_edges<Idx, VEC, G, false, DIRECT>(a, u, v, e, kc);
+    mu = nu;
+    mv = nv;
   }
 }
 
@@ -198,12 +220,11 @@ __global__ __launch_bounds__(kBlock) void sddmm_dot_kernel(const SddmmArgs<Idx> 
 // ---------------------------------------------------------------------------------------------
 template <typename Idx, int VEC, int G, bool CSR, bool DIRECT>
 static void launch_ew(const SddmmArgs<Idx>& a, hipStream_t s) {
-  constexpr int NB = kWave / G;
   const unsigned gy = (unsigned)((a.out_len + G * VEC - 1) / (G * VEC));
   if (CSR) {
     hipLaunchKernelGGL((sddmm_csr_kernel<Idx, VEC, G, DIRECT>), dim3((unsigned)a.nblocks, gy), dim3(kBlock), 0, s, a);
   } else {
-    const int64_t per_block = (int64_t)kWavesPerBlock * NB * kSddmmUnroll * kSddmmIters;
+    const int64_t per_block = (int64_t)kWavesPerBlock * kWave * kCooChunks;
     const int64_t nb = (a.nnz + per_block - 1) / per_block;
     hipLaunchKernelGGL((sddmm_coo_kernel<Idx, VEC, G, DIRECT>), dim3((unsigned)nb, gy), dim3(kBlock), 0, s, a);
   }
