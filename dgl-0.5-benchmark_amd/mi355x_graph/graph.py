@@ -31,6 +31,7 @@ class GraphIndex(object):
         self._num_edges = None
         self._hidden_csc = None  # in-CSR built for SpMM on graphs restricted to formats('coo')
         self._hidden_csr = None
+        self._canonical = None
 
     # -- basic facts
     def _any(self):
@@ -120,6 +121,32 @@ class GraphIndex(object):
     def create_formats_(self):
         for f in self._formats:
             getattr(self, f)()
+
+    def canonical(self):
+        """The same graph with its edges RENUMBERED in in-CSR (destination-major) order.
+
+        Returns (index, perm) with perm[new_edge_id] = old_edge_id (perm is None when the graph already
+        is in that order).  Edge tensors that are internal to a module (GATConv's logits / attention)
+        can live in this order: the in-CSR then needs no edge-id indirection, so edge_softmax, the
+        weighted g-SpMM and the CSR-walk g-SDDMM stream E-sized tensors instead of gathering 4-byte
+        elements at random edge ids."""
+        if self._canonical is None:
+            csc = self.csc()
+            if csc.eids is None:
+                self._canonical = (self, None)
+            else:
+                perm = csc.eids
+                inv = torch.empty_like(perm)
+                inv[perm.long()] = torch.arange(perm.shape[0], dtype=perm.dtype, device=perm.device)
+                c_csc = sparse.CsrView(csc.num_rows, csc.num_cols, csc.indptr, csc.indices, None)
+                c_csc._plan = csc.plan()  # same rows and edge ranges: the schedule carries over
+                c_csc.dst_is_src_prefix = csc.dst_is_src_prefix
+                csr = self.csr()
+                c_csr = sparse.CsrView(csr.num_rows, csr.num_cols, csr.indptr, csr.indices, inv[csr.eids.long()])
+                c_csr._plan = csr.plan()
+                idx = GraphIndex(self.num_src, self.num_dst, coo=None, csr=c_csr, csc=c_csc, formats=("csr", "csc"))
+                self._canonical = (idx, perm)
+        return self._canonical
 
     # -- derived graphs
     def with_formats(self, formats):

@@ -97,13 +97,12 @@ class GATConv(nn.Module):
                     h_dst = h_dst[:graph.number_of_dst_nodes()]
             el = (feat_src * self.attn_l).sum(dim=-1).unsqueeze(-1)
             er = (feat_dst * self.attn_r).sum(dim=-1).unsqueeze(-1)
-            graph.srcdata.update({"ft": feat_src, "el": el})
-            graph.dstdata.update({"er": er})
-            graph.apply_edges(fn.u_add_v("el", "er", "e"))
-            e = self.leaky_relu(graph.edata.pop("e"))
-            graph.edata["a"] = self.attn_drop(ops.edge_softmax(graph, e))
-            graph.update_all(fn.u_mul_e("ft", "a", "m"), fn.sum("m", "ft"))
-            rst = graph.dstdata["ft"]
+            # e and a are internal to the module: keep them in in-CSR (destination-major) edge order so that
+            # u_add_v, edge_softmax and u_mul_e/sum stream them instead of gathering by edge id
+            cidx, perm = graph._index.canonical()
+            e = self.leaky_relu(ops.gsddmm(cidx, "add", el, er, "u", "v"))
+            a = self.attn_drop(ops.edge_softmax(cidx, e))
+            rst = ops.gspmm(cidx, "mul", "sum", feat_src, a)
             if self.res_fc is not None:
                 resval = self.res_fc(h_dst).view(h_dst.shape[0], -1, self._out_feats)
                 rst = rst + resval
@@ -112,7 +111,11 @@ class GATConv(nn.Module):
             if self.activation:
                 rst = self.activation(rst)
             if get_attention:
-                return rst, graph.edata["a"]
+                if perm is not None:  # back to the caller's edge-id order
+                    a_user = torch.empty_like(a)
+                    a_user[perm.long()] = a
+                    a = a_user
+                return rst, a
             return rst
 
 

@@ -32,14 +32,17 @@ class MgxSpmmPlan(ctypes.Structure):
         ("hub_slot_ptr", ctypes.c_void_p),
         ("num_slots", ctypes.c_int64),
         ("slot_item", ctypes.c_void_p),
+        ("item_node", ctypes.c_void_p),
     ]
 
 
 class SpmmPlan(object):
-    def __init__(self, item_row, item_beg, item_end, hub_row, hub_slot_ptr, num_slots, order_kind, slot_item=None):
+    def __init__(self, item_row, item_beg, item_end, hub_row, hub_slot_ptr, num_slots, order_kind, slot_item=None,
+                 item_node=None):
         self.item_row, self.item_beg, self.item_end = item_row, item_beg, item_end
         self.hub_row, self.hub_slot_ptr, self.num_slots = hub_row, hub_slot_ptr, int(num_slots)
         self.slot_item = slot_item
+        self.item_node = item_node
         self.order_kind = order_kind
         self._c = None
 
@@ -57,7 +60,8 @@ class SpmmPlan(object):
                                   self.item_end.data_ptr(), self.num_hubs,
                                   self.hub_row.data_ptr() if self.num_hubs else None,
                                   self.hub_slot_ptr.data_ptr() if self.num_hubs else None, self.num_slots,
-                                  self.slot_item.data_ptr() if self.num_slots else None)
+                                  self.slot_item.data_ptr() if self.num_slots else None,
+                                  None if self.item_node is None else self.item_node.data_ptr())
         return self._c
 
 
@@ -152,7 +156,7 @@ def build_plan(csr, order=None, split=1024, order_kind="natural"):
         slot_item = torch.nonzero(is_hub).flatten().to(torch.int32)  # slots are numbered in item order
     idt = csr.indptr.dtype
     return SpmmPlan(item_row.contiguous(), beg.to(idt).contiguous(), end.to(idt).contiguous(), hub_row.contiguous(),
-                    hub_ptr.contiguous(), slots, order_kind, slot_item.contiguous())
+                    hub_ptr.contiguous(), slots, order_kind, slot_item.contiguous(), rows.to(torch.int32).contiguous())
 
 
 # nnz below which the whole gathered matrix is cache resident anyway and clustering cannot pay

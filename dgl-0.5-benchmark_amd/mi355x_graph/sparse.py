@@ -250,8 +250,10 @@ class HipBackend(object):
             else:
                 csr = graph_index.csc()
                 self._check_dev(csr.indptr, L, R)
+                plan = csr.plan()
                 _lib.check(lib.mgx_sddmm_csr(
-                    ctypes.byref(csr.c_struct()), OP[op], _ptr(L), _ptr(R), TARGET[lhs_target], TARGET[rhs_target],
+                    ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()),
+                    OP[op], _ptr(L), _ptr(R), TARGET[lhs_target], TARGET[rhs_target],
                     l_len, r_len, out_len, reduce_size, _ptr(l_off), _ptr(r_off), _ptr(out), _stream(dev)))
         return out
 

@@ -90,6 +90,7 @@ typedef struct mgx_spmm_plan {
   const int32_t* hub_slot_ptr;  /* [num_hubs+1] slots of hub h are [ptr[h], ptr[h+1]) */
   int64_t num_slots;            /* partial_ws holds num_slots * out_len floats */
   const int32_t* slot_item;     /* [num_slots] index of the work item that owns each partial slot */
+  const int32_t* item_node;     /* [num_items] the row of EVERY item (direct or split); used by mgx_sddmm_csr */
 } mgx_spmm_plan;
 
 /* ------------------------------------------------------------------ misc */
@@ -145,7 +146,7 @@ int32_t mgx_sddmm_coo(int64_t num_src, int64_t num_dst, int64_t nnz,
 
 /* CSR form (graphs restricted to formats(['csr','csc']), main_dgl_product_sage.py:158): walks
  * the in-CSR, t(e)=V is the row, t(e)=U is indices[p], output still addressed by edge id. */
-int32_t mgx_sddmm_csr(const mgx_csr* csr,
+int32_t mgx_sddmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */,
                       int32_t op, const float* lhs, const float* rhs,
                       int32_t lhs_target, int32_t rhs_target,
                       int64_t l_len, int64_t r_len, int64_t out_len, int64_t reduce_size,

@@ -331,3 +331,45 @@ def test_autograd_against_dense_torch():
         e = torch.exp(z - m[d])
         return e / agg(e)[d]
     check(lambda z: ops.edge_softmax(g, z), ref_softmax, (nnz, H))
+
+
+def test_canonical_edge_order_is_equivalent(oracle):
+    """GraphIndex.canonical(): edges renumbered in in-CSR order; every op must give the same result as on
+    the original graph after permuting edge tensors (perm[new] = old)."""
+    n, nnz, H, F = 700, 20000, 4, 8
+    src, dst = random_graph(n, n, nnz, seed=77)
+    g = mk(n, n, src, dst)
+    cidx, perm = g._index.canonical()
+    assert perm is not None and cidx.csc().eids is None
+    ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+    assert np.array_equal(perm.cpu().numpy(), ei)
+    rng = np.random.default_rng(7)
+    X = T(rng.random((n, H, F), dtype=np.float32))
+    el, er = T(rng.random((n, H, 1), dtype=np.float32)), T(rng.random((n, H, 1), dtype=np.float32))
+    W = T(rng.random((nnz, H, 1), dtype=np.float32))
+    p = perm.long()
+    e0 = ops.gsddmm(g, "add", el, er)
+    e1 = ops.gsddmm(cidx, "add", el, er)
+    assert torch.equal(e1, e0[p])
+    assert torch.equal(ops.edge_softmax(cidx, e1), ops.edge_softmax(g, e0)[p])
+    assert rel(ops.gspmm(cidx, "mul", "sum", X, W[p]).cpu(), ops.gspmm(g, "mul", "sum", X, W).cpu()) < 1e-6
+    assert rel(ops.gsddmm(cidx, "dot", X, X).cpu(), ops.gsddmm(g, "dot", X, X)[p].cpu()) < 1e-6
+    # backward through the canonical graph (reverse CSR carries the renumbered ids)
+    w1 = W[p].clone().requires_grad_(True)
+    w0 = W.clone().requires_grad_(True)
+    x1, x0 = X.clone().requires_grad_(True), X.clone().requires_grad_(True)
+    ops.gspmm(cidx, "mul", "sum", x1, w1).pow(2).sum().backward()
+    ops.gspmm(g, "mul", "sum", x0, w0).pow(2).sum().backward()
+    assert rel(x1.grad.cpu(), x0.grad.cpu()) < 1e-5 and rel(w1.grad.cpu(), w0.grad[p].cpu()) < 1e-5
+    # GATConv returns attention in the caller's edge-id order
+    from mi355x_graph.nn import GATConv
+    torch.manual_seed(0)
+    conv = GATConv(16, 8, 2, allow_zero_in_degree=True).to(DEV)
+    h = torch.rand(n, 16, device=DEV)
+    out, att = conv(g, h, get_attention=True)
+    s, d = torch.from_numpy(src).to(DEV), torch.from_numpy(dst).to(DEV)
+    sums = torch.zeros(n, 2, 1, device=DEV).index_add(0, d, att)
+    has = torch.bincount(d, minlength=n) > 0
+    assert torch.allclose(sums[has], torch.ones_like(sums[has]), atol=1e-5)
+    ref = torch.zeros(n, 2, 8, device=DEV).index_add(0, d, conv.fc(h).view(n, 2, 8)[s] * att) + conv.bias.view(1, 2, 8)
+    assert rel(out.detach().cpu(), ref.detach().cpu()) < RTOL
