@@ -372,4 +372,4 @@ def test_canonical_edge_order_is_equivalent(oracle):
     has = torch.bincount(d, minlength=n) > 0
     assert torch.allclose(sums[has], torch.ones_like(sums[has]), atol=1e-5)
     ref = torch.zeros(n, 2, 8, device=DEV).index_add(0, d, conv.fc(h).view(n, 2, 8)[s] * att) + conv.bias.view(1, 2, 8)
-    assert rel(out.detach().cpu(), ref.detach().cpu()) < RTOL
+    assert float((out - ref).abs().max() / ref.abs().max()) < RTOL  # signed sums cancel: compare at the tensor's scale
