@@ -21,5 +21,5 @@ extern "C" int32_t mgx_segment_reduce(int64_t num_segments, const int64_t* offse
   // nnz drives only the SPLIT heuristic; segments are usually much longer than 64/G rows.
   csr.nnz = num_segments * 64;
   return mgx_spmm_csr(&csr, nullptr, MGX_OP_COPY_RHS, reduce, nullptr, x, 0, D, D, nullptr, nullptr, nullptr, nullptr,
-                      out, nullptr, arg, nullptr, stream);
+                      out, nullptr, arg, nullptr, 0, stream);
 }

@@ -46,6 +46,7 @@ struct SpmmFastArgs {
   int H;            // heads of w
   int F;            // D / H
   int mean;
+  int accum;  // out += result (MGX_SPMM_ACCUMULATE)
 };
 
 // Work items per workgroup.  Workgroups are dispatched in blockIdx order, so a SMALL value makes
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(kBlock) void spmm_fast_kernel(const SpmmFastArgs<Id
           acc = acc / (float)(deg > 1 ? deg : 1);
         }
         if (a.dst_scale) acc = acc * a.dst_scale[row];
+        if (a.accum) acc += *reinterpret_cast<const V*>(a.out + row * D + f);
         *reinterpret_cast<V*>(a.out + row * D + f) = acc;
       } else {  // chunk of a split row: the epilogue runs in spmm_hub_fixup_kernel
         *reinterpret_cast<V*>(a.partial + (-(row + 1)) * D + f) = acc;
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave_kernel(const SpmmFastArgs
           acc = acc / (float)(deg > 1 ? deg : 1);
         }
         if (a.dst_scale) acc = acc * a.dst_scale[row];
+        if (a.accum) acc += *reinterpret_cast<const V*>(a.out + row * D + f);
         *reinterpret_cast<V*>(a.out + row * D + f) = acc;
       } else {
         *reinterpret_cast<V*>(a.partial + (-(row + 1)) * D + f) = acc;
@@ -293,7 +296,7 @@ template <typename Idx>
 __global__ __launch_bounds__(kBlock) void spmm_hub_fixup_kernel(const Idx* indptr, const int32_t* hub_row,
                                                                 const int32_t* hub_slot_ptr, int64_t num_hubs,
                                                                 const float* partial, const float* dst_scale,
-                                                                float* out, int D, int mean) {
+                                                                float* out, int D, int mean, int accum) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t h = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
   if (h >= num_hubs) return;
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(kBlock) void spmm_hub_fixup_kernel(const Idx* indpt
       acc = acc / (float)(deg > 1 ? deg : 1);
     }
     if (dst_scale) acc *= dst_scale[row];
+    if (accum) acc += out[row * D + k];
     out[row * D + k] = acc * scale;
   }
 }
@@ -332,7 +336,7 @@ struct SpmmGenericArgs {
   int64_t n_rows;
   int64_t nblocks;
   int64_t u_len, e_len, out_len;
-  int op, reduce;
+  int op, reduce, accum;
 };
 
 __device__ __forceinline__ float apply_op(int op, float l, float r) {
@@ -385,6 +389,7 @@ __global__ __launch_bounds__(kBlock) void spmm_generic_kernel(const SpmmGenericA
         acc = acc / (float)(deg > 1 ? deg : 1);
       }
       if (a.dst_scale) acc *= a.dst_scale[row];
+      if (a.accum) acc += a.out[row * a.out_len + k];
       a.out[row * a.out_len + k] = acc;
     }
   }
@@ -436,7 +441,7 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
 }
 
 template <typename Idx>
-static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* partial_ws, int32_t op, int32_t reduce, const float* U, const float* E,
+static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* partial_ws, int accumulate, int32_t op, int32_t reduce, const float* U, const float* E,
                          int64_t u_len, int64_t e_len, int64_t out_len, const int64_t* u_off,
                          const int64_t* e_off, const float* src_scale, const float* dst_scale, float* out,
                          void* arg_u, void* arg_e, hipStream_t s) {
@@ -461,6 +466,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     a.w = nullptr; a.src_scale = src_scale; a.dst_scale = dst_scale; a.out = out;
     a.n_rows = n_rows; a.nblocks = nblocks; a.D = (int)out_len; a.H = 1; a.F = (int)out_len;
     a.mean = reduce == MGX_REDUCE_MEAN;
+    a.accum = accumulate;
     a.item_row = nullptr; a.item_beg = nullptr; a.item_end = nullptr; a.partial = nullptr; a.n_items = n_rows;
     if (plan) {
       a.item_row = plan->item_row; a.item_beg = (const Idx*)plan->item_beg; a.item_end = (const Idx*)plan->item_end;
@@ -471,7 +477,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
       if (plan && plan->num_hubs > 0) {
         hipLaunchKernelGGL((spmm_hub_fixup_kernel<Idx>), dim3((unsigned)((plan->num_hubs + kWavesPerBlock - 1) / kWavesPerBlock)),
                            dim3(kBlock), 0, s, a.indptr, plan->hub_row, plan->hub_slot_ptr, plan->num_hubs,
-                           (const float*)partial_ws, dst_scale, out, a.D, a.mean);
+                           (const float*)partial_ws, dst_scale, out, a.D, a.mean, a.accum);
         MGX_CHECK_LAUNCH();
       }
       return MGX_OK;
@@ -505,7 +511,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
   g.E = (op == MGX_OP_COPY_LHS) ? nullptr : E;
   g.u_off = u_off; g.e_off = e_off; g.src_scale = src_scale; g.dst_scale = dst_scale; g.out = out;
   g.arg_u = (Idx*)arg_u; g.arg_e = (Idx*)arg_e; g.n_rows = n_rows; g.nblocks = nblocks;
-  g.u_len = u_len; g.e_len = e_len; g.out_len = out_len; g.op = op; g.reduce = reduce;
+  g.u_len = u_len; g.e_len = e_len; g.out_len = out_len; g.op = op; g.reduce = reduce; g.accum = accumulate;
   hipLaunchKernelGGL((spmm_generic_kernel<Idx>), dim3((unsigned)nblocks), dim3(kBlock), 0, s, g);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
@@ -517,7 +523,7 @@ extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, i
                                 const float* ufeat, const float* efeat, int64_t u_len, int64_t e_len,
                                 int64_t out_len, const int64_t* u_off, const int64_t* e_off, const float* src_scale,
                                 const float* dst_scale, float* out, void* arg_u, void* arg_e, float* partial_ws,
-                                void* stream) {
+                                int32_t flags, void* stream) {
   using namespace mgx;
   MGX_CHECK_ARG(csr != nullptr, "mgx_spmm_csr: csr is NULL");
   MGX_CHECK_ARG(csr->idx_bits == 32 || csr->idx_bits == 64, "mgx_spmm_csr: idx_bits must be 32 or 64, got %d", csr->idx_bits);
@@ -534,10 +540,12 @@ extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, i
   MGX_CHECK_ARG(out_len >= 0 && u_len >= 0 && e_len >= 0, "mgx_spmm_csr: negative feature length");
   const bool cmp = reduce == MGX_REDUCE_MAX || reduce == MGX_REDUCE_MIN;
   MGX_CHECK_ARG(!cmp || (!src_scale && !dst_scale), "mgx_spmm_csr: src/dst scale only with SUM/MEAN");
+  const int accumulate = (flags & MGX_SPMM_ACCUMULATE) ? 1 : 0;
+  MGX_CHECK_ARG(!accumulate || !cmp, "mgx_spmm_csr: MGX_SPMM_ACCUMULATE only with SUM/MEAN");
   hipStream_t s = (hipStream_t)stream;
   if (csr->idx_bits == 32)
-    return spmm_impl<int32_t>(csr, plan, partial_ws, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
+    return spmm_impl<int32_t>(csr, plan, partial_ws, accumulate, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
                               dst_scale, out, arg_u, arg_e, s);
-  return spmm_impl<int64_t>(csr, plan, partial_ws, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
+  return spmm_impl<int64_t>(csr, plan, partial_ws, accumulate, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
                             dst_scale, out, arg_u, arg_e, s);
 }

@@ -42,7 +42,7 @@ SIGNATURES = {
     "mgx_abi_version": (_i32, []),
     "mgx_device_info": (_i32, [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32]),
     "mgx_spmm_csr": (_i32, [_csr_p, _vp, _i32, _i32, _fp, _fp, _i64, _i64, _i64, _vp, _vp, _fp, _fp, _fp, _vp, _vp,
-                            _fp, _vp]),
+                            _fp, _i32, _vp]),
     "mgx_sddmm_coo": (_i32, [_i64, _i64, _i64, _vp, _vp, _i32, _i32, _fp, _fp, _i32, _i32, _i64, _i64, _i64, _i64,
                              _vp, _vp, _fp, _vp]),
     "mgx_sddmm_csr": (_i32, [_csr_p, _vp, _i32, _fp, _fp, _i32, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _fp, _vp]),

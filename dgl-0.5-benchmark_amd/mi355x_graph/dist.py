@@ -166,7 +166,8 @@ def _cap_clusters(hist, node_w, cap):
 class HaloPlan(object):
     """What one rank sends / receives per layer."""
 
-    def __init__(self, rank, world, n_own, n_halo, send_idx, send_splits, recv_splits):
+    def __init__(self, rank, world, n_own, n_halo, send_idx, send_splits, recv_splits, loc=None, halo=None, inv_deg=None):
+        self.loc, self.halo, self.inv_deg = loc, halo, inv_deg  # split structure for the overlapped copy_u path
         self.rank, self.world = rank, world
         self.n_own, self.n_halo = n_own, n_halo
         self.send_idx = send_idx            # local owned-row ids, grouped by destination peer
@@ -210,7 +211,14 @@ def build_local_partition(src, dst, num_nodes, assign, rank, world, idtype=torch
     block = DGLGraph(GraphIndex(n_own + n_halo, n_own, coo=(l_src.to(idtype).contiguous(), l_dst.to(idtype).contiguous())),
                      is_block=True)
     block._index.csc().dst_is_src_prefix = True  # [owned | halo]: lets the schedule cluster the owned x owned part
-    plan = HaloPlan(rank, world, n_own, n_halo, send_idx.to(idtype).contiguous(), send_splits, recv_splits)
+    # the same edges split by source ownership: the owned x owned part can run while the halo rows travel
+    keep = ~remote
+    loc = GraphIndex(n_own, n_own, coo=(l_src[keep].to(idtype).contiguous(), l_dst[keep].to(idtype).contiguous()))
+    halo = GraphIndex(n_halo, n_own, coo=((l_src[remote] - n_own).to(idtype).contiguous(),
+                                          l_dst[remote].to(idtype).contiguous()))
+    inv_deg = 1.0 / torch.bincount(l_dst, minlength=n_own).clamp(min=1).to(torch.float32)
+    plan = HaloPlan(rank, world, n_own, n_halo, send_idx.to(idtype).contiguous(), send_splits, recv_splits,
+                    loc, halo, inv_deg)
     return block, plan, own
 
 
@@ -243,6 +251,64 @@ class _Comm(object):
                 dst_t.copy_(buf)
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
+
+    def all_to_all_async(self, out, inp, out_splits, in_splits):
+        """Returns a handle whose wait() orders the CURRENT stream after the exchange (RCCL runs it on the
+        process group's own stream, so kernels launched in between overlap with it)."""
+        if dist.get_backend(self.group) == "gloo":
+            self.all_to_all(out, inp, out_splits, in_splits)
+            return _Done()
+        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
+
+
+class _Done(object):
+    def wait(self):
+        return True
+
+
+class DistCopyU(torch.autograd.Function):
+    """update_all(copy_u, sum|mean) on a partition with the exchange hidden behind the local work:
+
+      forward   pack boundary rows -> all_to_all (async, RCCL stream) || g-SpMM over owned sources
+                -> wait -> g-SpMM over halo sources accumulating into the same output
+      backward  g-SpMM^T producing halo-row gradients -> all_to_all (async) || g-SpMM^T over owned rows
+                -> wait -> add received rows into their owners (per peer, fixed order)
+    Both halves write through dst_scale = 1/max(deg,1) for `mean` (deg = full in-degree)."""
+
+    @staticmethod
+    def forward(ctx, x, plan, comm, reduce):
+        x = x.contiguous()
+        feat = tuple(x.shape[1:])
+        send = sparse.gather_rows_raw(x, plan.send_idx)
+        recv = torch.empty((plan.n_halo,) + feat, dtype=x.dtype, device=x.device)
+        work = comm.all_to_all_async(recv, send, plan.recv_splits, plan.send_splits)
+        scale = plan.inv_deg if reduce == "mean" else None
+        out, _, _ = sparse.gspmm_raw(plan.loc.csc(), "copy_lhs", "sum", x, None, dst_scale=scale)
+        work.wait()
+        if plan.n_halo:
+            sparse.gspmm_raw(plan.halo.csc(), "copy_lhs", "sum", recv, None, dst_scale=scale, accumulate_into=out)
+        ctx.plan, ctx.comm, ctx.reduce = plan, comm, reduce
+        return out
+
+    @staticmethod
+    def backward(ctx, dZ):
+        plan, comm = ctx.plan, ctx.comm
+        dZ = dZ.contiguous()
+        if ctx.reduce == "mean":
+            dZ = dZ * plan.inv_deg.view((-1,) + (1,) * (dZ.dim() - 1))
+        feat = tuple(dZ.shape[1:])
+        back = torch.empty((plan.send_idx.shape[0],) + feat, dtype=dZ.dtype, device=dZ.device)
+        if plan.n_halo:
+            g_halo, _, _ = sparse.gspmm_raw(plan.halo.csr(), "copy_lhs", "sum", dZ, None)
+        else:
+            g_halo = torch.empty((0,) + feat, dtype=dZ.dtype, device=dZ.device)
+        work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
+        gx, _, _ = sparse.gspmm_raw(plan.loc.csr(), "copy_lhs", "sum", dZ, None)
+        work.wait()
+        for (a, b) in plan.send_ranges:
+            if b > a:
+                sparse.scatter_add_rows_raw(gx, plan.send_idx[a:b], back[a:b])
+        return gx, None, None, None
 
 
 class HaloExchange(torch.autograd.Function):
@@ -347,6 +413,13 @@ class DistGraph(DGLGraph):
         raise DGLError("DistGraph supports builtin message functions only")
 
     def update_all(self, message_func, reduce_func, apply_node_func=None, etype=None):
+        if (isinstance(message_func, fn.CopyMessageFunction) and message_func.target == "u"
+                and isinstance(reduce_func, fn.SimpleReduceFunction) and reduce_func.name in ("sum", "mean")
+                and reduce_func.msg_field == message_func.out_field and self._plan.loc is not None
+                and apply_node_func is None):
+            x = self._src_frame[message_func.in_field]
+            self._dst_frame[reduce_func.out_field] = DistCopyU.apply(x, self._plan, self._comm, reduce_func.name)
+            return
         blk = self._local(self._u_fields(message_func))
         core.update_all(blk, message_func, reduce_func, apply_node_func)
 

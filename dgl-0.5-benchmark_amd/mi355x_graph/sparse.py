@@ -202,9 +202,13 @@ class HipBackend(object):
             _lib.check(_lib.lib().mgx_csr_inv_degrees(csr.num_rows, _ptr(csr.indptr), csr.idx_bits, _ptr(inv), _stream(dev)))
         return inv
 
-    def spmm(self, csr, op, reduce, U, E, u_len, e_len, out_len, u_off, e_off, src_scale, dst_scale, want_arg):
-        dev = self._check_dev(csr.indptr, U, E, src_scale, dst_scale)
-        out = torch.empty((csr.num_rows, out_len), dtype=torch.float32, device=dev)
+    def spmm(self, csr, op, reduce, U, E, u_len, e_len, out_len, u_off, e_off, src_scale, dst_scale, want_arg,
+             accumulate_into=None):
+        dev = self._check_dev(csr.indptr, U, E, src_scale, dst_scale, accumulate_into)
+        if accumulate_into is not None:
+            out = accumulate_into.view(csr.num_rows, out_len)
+        else:
+            out = torch.empty((csr.num_rows, out_len), dtype=torch.float32, device=dev)
         arg_u = arg_e = None
         if want_arg:
             if op != "copy_rhs":
@@ -226,7 +230,7 @@ class HipBackend(object):
                 ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()),
                 OP[op], REDUCE[reduce], _ptr(U), _ptr(E), u_len, e_len, out_len,
                 _ptr(u_off), _ptr(e_off), _ptr(src_scale), _ptr(dst_scale), _ptr(out), _ptr(arg_u), _ptr(arg_e),
-                _ptr(partial), _stream(dev)))
+                _ptr(partial), 1 if accumulate_into is not None else 0, _stream(dev)))
             if rec is not None:
                 rec["end"].record(torch.cuda.current_stream(dev))
                 PROFILE.append(rec)
@@ -354,7 +358,7 @@ def _as_f32(t, what):
     return t.contiguous()
 
 
-def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=False):
+def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=False, accumulate_into=None):
     """out[v] = reduce_{p in row v} op(U[indices[p]], E[eids[p]]).
 
     U: (num_cols, *ushape) or None; E: (nnz, *eshape) or None.  Returns (out, arg_u, arg_e) with out of
@@ -381,7 +385,8 @@ def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=Fa
     dev = ref.device
     out, arg_u, arg_e = backend_for(ref).spmm(
         csr, op, reduce, U, E, _prod(ushape), _prod(eshape), _prod(oshape),
-        _device_table(u_tab, dev), _device_table(e_tab, dev), src_scale, dst_scale, want_arg)
+        _device_table(u_tab, dev), _device_table(e_tab, dev), src_scale, dst_scale, want_arg,
+        **({"accumulate_into": accumulate_into} if accumulate_into is not None else {}))
     shape = (csr.num_rows,) + tuple(oshape)
     out = out.view(shape)
     if arg_u is not None:

@@ -56,6 +56,9 @@ typedef enum {
 /* reducers selectable with kernel/dgl-new.py:51 --spmm-reduce */
 typedef enum { MGX_REDUCE_SUM = 0, MGX_REDUCE_MAX = 1, MGX_REDUCE_MIN = 2, MGX_REDUCE_MEAN = 3 } mgx_reduce;
 
+/* flags of mgx_spmm_csr */
+enum { MGX_SPMM_ACCUMULATE = 1 };
+
 /* SDDMM operand targets (lhs_target / rhs_target of dgl.ops.gsddmm) */
 typedef enum { MGX_TARGET_U = 0, MGX_TARGET_E = 1, MGX_TARGET_V = 2 } mgx_target;
 
@@ -125,7 +128,8 @@ int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NUL
                      const int64_t* u_off, const int64_t* e_off,
                      const float* src_scale, const float* dst_scale,
                      float* out, void* arg_u, void* arg_e,
-                     float* partial_ws /* [plan->num_slots * out_len] or NULL */, void* stream);
+                     float* partial_ws /* [plan->num_slots * out_len] or NULL */,
+                     int32_t flags /* MGX_SPMM_ACCUMULATE: out += result (SUM/MEAN only) */, void* stream);
 
 /* ------------------------------------------------------------------ g-SDDMM
  * Replaces _CAPI_DGLKernelSDDMM as reached by dgl.ops.gsddmm (kernel/dgl-new.py:39),

@@ -22,7 +22,8 @@ class OracleBackend(object):
         d = (csr.indptr[1:] - csr.indptr[:-1]).clamp(min=1).to(torch.float32)
         return 1.0 / d
 
-    def spmm(self, csr, op, reduce, U, E, u_len, e_len, out_len, u_off, e_off, src_scale, dst_scale, want_arg):
+    def spmm(self, csr, op, reduce, U, E, u_len, e_len, out_len, u_off, e_off, src_scale, dst_scale, want_arg,
+             accumulate_into=None):
         n = csr.num_rows
         L = orc.lib()
         Un = None if U is None else np.ascontiguousarray(_np(U).reshape(U.shape[0], -1), np.float32)
@@ -53,6 +54,9 @@ class OracleBackend(object):
         if dst_scale is not None:
             out = out * _np(dst_scale)[:, None]
         idt = csr.indptr.dtype
+        if accumulate_into is not None:
+            accumulate_into.view(n, out_len).add_(torch.from_numpy(out))
+            return accumulate_into.view(n, out_len), None, None
         return (torch.from_numpy(out), torch.from_numpy(au).to(idt) if want_arg and op != "copy_rhs" else None,
                 torch.from_numpy(ae).to(idt) if want_arg and op != "copy_lhs" else None)
 

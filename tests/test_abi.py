@@ -25,17 +25,17 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(handle, s), "libmi355x_graph.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes SIGNATURES and the header disagree"
-    assert _lib.lib().mgx_abi_version() == 4
+    assert _lib.lib().mgx_abi_version() == 5
 
 
 def test_bad_arguments_raise_not_crash():
     L = _lib.lib()
-    st = L.mgx_spmm_csr(None, None, 0, 0, None, None, 1, 1, 1, None, None, None, None, None, None, None, None, None)
+    st = L.mgx_spmm_csr(None, None, 0, 0, None, None, 1, 1, 1, None, None, None, None, None, None, None, None, 0, None)
     assert st == 1 and b"csr is NULL" in L.mgx_last_error()
     with pytest.raises(mg.DGLError):
         _lib.check(st)
     c = _lib.MgxCsr(1, 1, 0, None, None, None, 16, 0)
-    assert L.mgx_spmm_csr(ctypes.byref(c), None, 0, 0, None, None, 1, 1, 1, None, None, None, None, None, None, None, None, None) == 1
+    assert L.mgx_spmm_csr(ctypes.byref(c), None, 0, 0, None, None, 1, 1, 1, None, None, None, None, None, None, None, None, 0, None) == 1
     assert L.mgx_sddmm_coo(1, 1, 1, None, None, 32, 99, None, None, 0, 2, 1, 1, 1, 1, None, None, None, None) == 1
 
 

@@ -44,7 +44,19 @@ def single_process_reference(device="cpu"):
     out = model(g, feats)
     loss = F.nll_loss(out[train], labels[train])
     loss.backward()
-    return out.detach().cpu(), loss.item(), [p.grad.cpu().clone() for p in model.parameters()]
+    return out.detach().cpu(), loss.item(), [p.grad.cpu().clone() for p in model.parameters()], generic_path(g, feats).cpu()
+
+
+def generic_path(g, x):
+    """apply_edges(u_add_v) + update_all(u_mul_e, sum): on a DistGraph this takes the generic route
+    (HaloExchange of every source field + the [owned | halo] block), not the overlapped copy_u route."""
+    import mi355x_graph.function as fn
+    g = g.local_var()
+    g.ndata["a"] = x[:, :1].contiguous()
+    g.ndata["h"] = x
+    g.apply_edges(fn.u_add_v("a", "a", "w"))
+    g.update_all(fn.u_mul_e("h", "w", "m"), fn.sum("m", "o"))
+    return g.ndata["o"]
 
 
 def _worker(rank, world, port, q, device="cpu"):
@@ -72,7 +84,8 @@ def _worker(rank, world, port, q, device="cpu"):
     lsum = loss.detach().cpu().clone()
     dist.all_reduce(lsum)
     q.put((rank, own.cpu().numpy(), out.detach().cpu().numpy(), float(lsum),
-           [p.grad.cpu().numpy() for p in model.parameters()], stats, plan.n_halo, sum(plan.send_splits)))
+           [p.grad.cpu().numpy() for p in model.parameters()], stats, plan.n_halo, sum(plan.send_splits),
+           generic_path(g, x).cpu().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,7 +94,7 @@ def _run_two_way(device):
     if device == "cpu":
         oracle_backend.install()
     try:
-        ref_out, ref_loss, ref_grads = single_process_reference(device)
+        ref_out, ref_loss, ref_grads, ref_generic = single_process_reference(device)
     finally:
         oracle_backend.uninstall()
     ctx = mp.get_context("spawn")
@@ -95,9 +108,11 @@ def _run_two_way(device):
         p.join(60)
         assert p.exitcode == 0
     got = torch.zeros_like(ref_out)
+    got_generic = torch.zeros_like(ref_generic)
     seen = np.zeros(ref_out.shape[0], bool)
-    for rank, own, out, lsum, grads, stats, n_halo, n_send in res:
+    for rank, own, out, lsum, grads, stats, n_halo, n_send, gen in res:
         got[own] = torch.from_numpy(out)
+        got_generic[own] = torch.from_numpy(gen)
         assert not seen[own].any()
         seen[own] = True
         assert abs(lsum - ref_loss) < 1e-5
@@ -106,6 +121,7 @@ def _run_two_way(device):
         assert 0.0 < stats["edge_cut"] < 0.6 and n_halo > 0 and n_send > 0
     assert seen.all()
     assert torch.allclose(got, ref_out, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(got_generic, ref_generic, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.timeout(300)
