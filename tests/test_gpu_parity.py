@@ -373,3 +373,22 @@ def test_canonical_edge_order_is_equivalent(oracle):
     assert torch.allclose(sums[has], torch.ones_like(sums[has]), atol=1e-5)
     ref = torch.zeros(n, 2, 8, device=DEV).index_add(0, d, conv.fc(h).view(n, 2, 8)[s] * att) + conv.bias.view(1, 2, 8)
     assert float((out - ref).abs().max() / ref.abs().max()) < RTOL  # signed sums cancel: compare at the tensor's scale
+
+
+def test_spmm_accumulate_and_scales(oracle):
+    """MGX_SPMM_ACCUMULATE + src/dst scales (the multi-GPU overlapped path and the fused mean backward)."""
+    n_src, n_dst, D = 900, 700, 64
+    rng = np.random.default_rng(3)
+    s1, d1 = random_graph(n_src, n_dst, 30000, seed=31)
+    s2, d2 = random_graph(400, n_dst, 9000, seed=32)
+    X, Y = rng.random((n_src, D), dtype=np.float32), rng.random((400, D), dtype=np.float32)
+    ds = rng.random(n_dst).astype(np.float32) + 0.5
+    ss = rng.random(n_src).astype(np.float32) + 0.5
+    g1, g2 = mk(n_src, n_dst, s1, d1), mk(400, n_dst, s2, d2)
+    out, _, _ = sparse.gspmm_raw(g1._index.csc(), "copy_lhs", "sum", T(X), None, src_scale=T(ss), dst_scale=T(ds))
+    ret, _, _ = sparse.gspmm_raw(g2._index.csc(), "copy_lhs", "sum", T(Y), None, dst_scale=T(ds), accumulate_into=out)
+    assert ret.data_ptr() == out.data_ptr()
+    i1 = oracle.coo_to_csr(n_dst, d1, s1)
+    i2 = oracle.coo_to_csr(n_dst, d2, s2)
+    ref = (oracle.spmm(*i1, "copy_lhs", "sum", X * ss[:, None], None) + oracle.spmm(*i2, "copy_lhs", "sum", Y, None)) * ds[:, None]
+    assert rel(out.cpu(), ref) < RTOL
