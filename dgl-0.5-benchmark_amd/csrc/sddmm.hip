@@ -242,6 +242,9 @@ static void launch_g(const SddmmArgs<Idx>& a, hipStream_t s) {
   const int64_t lanes = ((DOT ? a.reduce_size : a.out_len) + VEC - 1) / VEC;
   int G = 1;
   while (G < lanes && G < kWave) G <<= 1;
+  // dot: wider reduce dims loop inside a 16-lane group -- 4 edges per wave-instruction and 16 in flight
+  // hide the gather latency better than one edge per 64 lanes (reddit GAT, RS = 41: 11.5 -> see profiles)
+  if (DOT && G > 16) G = 16;
   switch (G) {
     case 1: launch_one<Idx, VEC, 1, CSR, DIRECT, DOT>(a, s); break;
     case 2: launch_one<Idx, VEC, 2, CSR, DIRECT, DOT>(a, s); break;
