@@ -181,3 +181,36 @@ def test_halo_plan_consistency():
         es, ed = src[assign[dst] == r], dst[assign[dst] == r]
         full_ids = torch.cat([own, got])
         assert torch.equal(full_ids[ls.long()], es) and torch.equal(own[ld.long()], ed)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_rccl_api_path_single_rank():
+    """One rank over the real RCCL backend: exercises all_to_all_single(async_op=True) / Work.wait(), the flat gradient
+    all_reduce and broadcast exactly as bench.py --gpus N calls them (degenerate sizes: no halo with one part)."""
+    import torch.nn.functional as F
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(29500 + os.getpid() % 2000 + 13)
+    dev = torch.device("cuda:0")
+    try:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    except Exception as e:  # pragma: no cover
+        pytest.skip("RCCL not usable here: %r" % (e,))
+    try:
+        n, src, dst, feats, labels, train = [t.to(dev) if isinstance(t, torch.Tensor) else t for t in make_problem()]
+        assign, _ = mdist.partition_nodes(src, dst, n, 1)
+        block, plan, own = mdist.build_local_partition(src, dst, n, assign, 0, 1)
+        assert plan.n_halo == 0 and plan.n_own == n
+        g = mdist.DistGraph(block, plan)
+        model = build_model().to(dev)
+        mdist.broadcast_parameters(model)
+        out = model(g, feats)
+        loss = F.nll_loss(out[train], labels[train])
+        loss.backward()
+        mdist.allreduce_gradients(model)
+        ref_out, ref_loss, ref_grads, ref_gen = single_process_reference("cuda:0")
+        assert torch.allclose(out.detach().cpu(), ref_out, rtol=1e-4, atol=1e-6)
+        for p, r in zip(model.parameters(), ref_grads):
+            assert torch.allclose(p.grad.cpu(), r, rtol=1e-4, atol=1e-6)
+        assert torch.allclose(generic_path(g, feats).cpu(), ref_gen, rtol=1e-4, atol=1e-6)
+    finally:
+        dist.destroy_process_group()
