@@ -39,6 +39,7 @@ struct SpmmFastArgs {
   const Idx* item_end;
   float* partial;           // [num_slots, D] partial sums of split (hub) rows
   int64_t n_items;  // == n_rows without a plan
+  int64_t src_rows; // rows of the gathered matrix (num_cols, or nnz for copy_rhs)
   int64_t n_rows;
   int64_t nblocks;  // logical blocks, multiple of kXcds
   int rpb;          // work items per workgroup
@@ -168,11 +169,16 @@ __global__ __launch_bounds__(kBlock) void spmm_fast_kernel(const SpmmFastArgs<Id
 //   * the NEXT item's bounds and neighbour ids are requested before the current row's gathers
 //     are issued, so they travel under the row loads;
 //   * per-edge scalars (edge id, edge weight with one head, source scale) ride along the same way.
-template <typename Idx, int VEC, int G, int MODE>
+template <int G>
+struct RowwaveUnroll {
+  static constexpr int NB = kWave / G;
+  static constexpr int value = NB >= 16 ? 1 : (NB >= 8 ? 2 : (NB >= 2 ? 4 : 8));
+};
+
+template <typename Idx, int VEC, int G, int MODE, int U = RowwaveUnroll<G>::value>
 __global__ __launch_bounds__(kBlock) void spmm_rowwave_kernel(const SpmmFastArgs<Idx> a) {
   typedef typename VecT<VEC>::type V;
   constexpr int NB = kWave / G;
-  constexpr int U = NB >= 16 ? 1 : (NB >= 8 ? 2 : (NB >= 2 ? 4 : 8));
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int sub = lane / G;
@@ -290,6 +296,171 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave_kernel(const SpmmFastArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// spmm_rowwave32_kernel: the row-per-wave kernel re-written for instruction count (int32 ids, gathered
+// matrix < 4 GiB).  rocprofv3 showed the first version spent ~1500 VALU instructions per wave-row batch --
+// 64-bit multiply-add per gather address, a compare + exec-mask branch around every load -- i.e. it was
+// VALU-issue bound (≈1.6 ms of a 2.75 ms launch), not memory bound.  Here:
+//   * lane j turns its neighbour id into a 32-bit BYTE OFFSET once (one v_mul per 64 edges); the offset,
+//     not the id, travels through ds_bpermute, and the load uses the scalar-base + 32-bit-voffset form;
+//   * steps whose 64/G*U edges are all valid run unpredicated; only the last step of a chunk clamps
+//     its lane index and masks the loaded value;
+//   * MODE / weight handling / feature-lane masking are template parameters, so the loop has no
+//     uniform branches.
+// WMODE: 0 = plain sum, 1 = one scalar per edge (u_mul_e with one head and/or src_scale), 2 = weight per
+// (edge, head) loaded after the edge id arrives.  LANEMASK: D is not a multiple of the lane-group width.
+template <int VEC, int G, int MODE, int WMODE, bool LANEMASK>
+__global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
+  typedef typename VecT<VEC>::type V;
+  constexpr int NB = kWave / G;
+  constexpr int U = RowwaveUnroll<G>::value;
+  constexpr int STEP = NB * U;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int sub = lane / G;
+  const int l = lane % G;
+  const int f = (blockIdx.y * G + l) * VEC;
+  const bool factive = LANEMASK ? (f < a.D) : true;
+  const int head = (WMODE == 2 && factive) ? f / a.F : 0;
+  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * a.rpb;
+  const uint32_t rowbytes = (uint32_t)a.D * 4u;
+  const uint32_t f4 = factive ? (uint32_t)f * 4u : 0u;  // idle feature lanes re-read the row start; never stored
+  const char* __restrict__ srcb = reinterpret_cast<const char*>(a.src);
+  const int bidx0 = sub * 4;  // byte index of this lane group's first edge for ds_bpermute
+
+  auto load_meta = [&](int64_t item, int64_t& row, int32_t& beg, int32_t& end) {
+    if (a.item_row) {
+      row = (int64_t)a.item_row[item];
+      beg = a.item_beg[item];
+      end = a.item_end[item];
+    } else {
+      row = item;
+      beg = a.indptr[item];
+      end = a.indptr[item + 1];
+    }
+  };
+  // lane j's slice of the edge list: byte offset of the gathered row, edge id, per-edge scalar
+  auto load_ids = [&](int32_t base, int32_t end, uint32_t& goff, int32_t& eid, float& sc) {
+    const int32_t q = base + lane;
+    goff = 0;
+    eid = 0;
+    sc = 1.f;
+    if (q < end) {
+      int32_t gid;
+      if (MODE == MODE_COPY_RHS) {
+        gid = a.eids ? a.eids[q] : q;
+      } else {
+        gid = a.indices[q];
+        if (MODE == MODE_MUL_EDGE) {
+          eid = a.eids ? a.eids[q] : q;
+          if (WMODE == 1) sc = a.w[eid];
+        }
+        if (WMODE == 1 && a.src_scale) sc *= a.src_scale[gid];
+      }
+      goff = (uint32_t)gid * rowbytes;
+    }
+  };
+
+  // gathers of one step (STEP edges starting at edge k of the current 64-edge chunk); lanes past the end of
+  // the chunk re-read edge 0 (valid memory, same cache line as a live lane) and are zeroed in consume_step
+  auto issue_step = [&](int k, int cnt, uint32_t goff, int32_t eid, float sc, V (&val)[U], float (&wgt)[U]) {
+    const bool full = k + STEP <= cnt;  // wave-uniform
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int bi = bidx0 + (k + u * NB) * 4;
+      if (!full) bi = (k + u * NB + sub < cnt) ? bi : 0;
+      const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)goff) + f4;
+      wgt[u] = 1.f;
+      if (WMODE == 1) wgt[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(bi, __float_as_int(sc)));
+      if (WMODE == 2) {
+        const int e = __builtin_amdgcn_ds_bpermute(bi, eid);
+        wgt[u] = a.w[(int64_t)e * a.H + head];
+      }
+      val[u] = *reinterpret_cast<const V*>(srcb + off);
+    }
+  };
+  auto consume_step = [&](int k, int cnt, const V (&val)[U], const float (&wgt)[U], V& acc) {
+    if (k + STEP <= cnt) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (WMODE != 0) acc += val[u] * wgt[u];
+        else acc += val[u];
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const V vv = (k + u * NB + sub < cnt) ? val[u] : (V)(0.f);
+        if (WMODE != 0) acc += vv * wgt[u];
+        else acc += vv;
+      }
+    }
+  };
+
+  int r = wave;
+  if (r >= a.rpb || item_base + r >= a.n_items) return;
+  int64_t row;
+  int32_t beg, end;
+  load_meta(item_base + r, row, beg, end);
+  uint32_t goff;
+  int32_t eid;
+  float sc;
+  load_ids(beg, end, goff, eid, sc);
+
+  for (;;) {
+    const int rn = r + kWavesPerBlock;
+    const bool has_next = rn < a.rpb && item_base + rn < a.n_items;
+    int64_t nrow = 0;
+    int32_t nbeg = 0, nend = 0, neid = 0;
+    uint32_t ngoff = 0;
+    float nsc = 1.f;
+    if (has_next) {
+      load_meta(item_base + rn, nrow, nbeg, nend);
+      load_ids(nbeg, nend, ngoff, neid, nsc);
+    }
+    V acc = (V)(0.f);
+    for (int32_t cbase = beg; cbase < end; cbase += kWave) {
+      if (cbase != beg) load_ids(cbase, end, goff, eid, sc);
+      const int cnt = (end - cbase) < kWave ? (end - cbase) : kWave;
+      // Two value buffers in ping-pong: the gathers of step k+1 are issued before step k is summed, so
+      // consecutive steps of a row overlap instead of paying one memory round trip each.
+      V va[U], vb[U];
+      float wa[U], wb[U];
+      issue_step(0, cnt, goff, eid, sc, va, wa);
+      int k = STEP;
+      for (;;) {
+        if (k >= cnt) { consume_step(k - STEP, cnt, va, wa, acc); break; }
+        issue_step(k, cnt, goff, eid, sc, vb, wb);
+        consume_step(k - STEP, cnt, va, wa, acc);
+        k += STEP;
+        if (k >= cnt) { consume_step(k - STEP, cnt, vb, wb, acc); break; }
+        issue_step(k, cnt, goff, eid, sc, va, wa);
+        consume_step(k - STEP, cnt, vb, wb, acc);
+        k += STEP;
+      }
+    }
+#pragma unroll
+    for (int off = G; off < kWave; off <<= 1) acc += vec_shfl_xor<VEC>(acc, off);
+    if (factive && sub == 0) {
+      if (row >= 0) {
+        if (a.mean) {
+          const int deg = end - beg;
+          acc = acc / (float)(deg > 1 ? deg : 1);
+        }
+        if (a.dst_scale) acc = acc * a.dst_scale[row];
+        float* op = a.out + row * (int64_t)a.D + f;
+        if (a.accum) acc += *reinterpret_cast<const V*>(op);
+        *reinterpret_cast<V*>(op) = acc;
+      } else {
+        *reinterpret_cast<V*>(a.partial + (-(row + 1)) * (int64_t)a.D + f) = acc;
+      }
+    }
+    if (!has_next) break;
+    r = rn;
+    row = nrow; beg = nbeg; end = nend;
+    goff = ngoff; eid = neid; sc = nsc;
+  }
+}
+
 // Sums the partial slots of every split (hub) row in slot order -- deterministic -- and applies
 // the mean / dst_scale epilogue.  One wave per hub row, lanes along the feature dimension.
 template <typename Idx>
@@ -396,6 +567,26 @@ __global__ __launch_bounds__(kBlock) void spmm_generic_kernel(const SpmmGenericA
 }
 
 // ---------------------------------------------------------------------------------------------
+// int32 graphs whose gathered matrix is addressable with 32-bit byte offsets take the lean kernel
+template <int VEC, int G, int MODE>
+static bool launch_rowwave32(const SpmmFastArgs<int32_t>& a, int64_t src_rows, dim3 grid, hipStream_t s) {
+  if (getenv("MGX_SPMM_V1") != nullptr) return false;  // A/B switch
+  if (src_rows * (int64_t)a.D * 4 >= (int64_t(1) << 32)) return false;
+  const bool lanemask = a.D % (G * VEC) != 0;
+  int wmode = 0;
+  if (MODE == MODE_MUL_EDGE) wmode = a.H == 1 ? 1 : 2;
+  else if (a.src_scale) wmode = 1;
+  if (MODE == MODE_MUL_EDGE && a.H > 1 && a.src_scale) return false;  // not needed by any caller
+#define MGX_RW32(W, LM) hipLaunchKernelGGL((spmm_rowwave32_kernel<VEC, G, MODE, W, LM>), grid, dim3(kBlock), 0, s, a)
+  if (wmode == 0) { if (lanemask) MGX_RW32(0, true); else MGX_RW32(0, false); }
+  else if (wmode == 1) { if (lanemask) MGX_RW32(1, true); else MGX_RW32(1, false); }
+  else { if (lanemask) MGX_RW32(2, true); else MGX_RW32(2, false); }
+#undef MGX_RW32
+  return true;
+}
+template <int VEC, int G, int MODE>
+static bool launch_rowwave32(const SpmmFastArgs<int64_t>&, int64_t, dim3, hipStream_t) { return false; }
+
 template <typename Idx, int VEC, int G, int MODE>
 static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, hipStream_t s) {
   constexpr int NB = kWave / G;
@@ -403,6 +594,7 @@ static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, hipStream_t s) {
   if (!split && a.rpb < kWavesPerBlock * NB) a.rpb = kWavesPerBlock * NB;  // one item per lane group
   a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);
   dim3 grid((unsigned)a.nblocks, (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
+  if (split && launch_rowwave32<VEC, G, MODE>(a, a.src_rows, grid, s)) return;
   const bool legacy = getenv("MGX_SPMM_LEGACY") != nullptr;  // A/B switch for experiments
   if (split && !legacy) hipLaunchKernelGGL((spmm_rowwave_kernel<Idx, VEC, G, MODE>), grid, dim3(kBlock), 0, s, a);
   else if (split) hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, true>), grid, dim3(kBlock), 0, s, a);
@@ -483,13 +675,13 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
       return MGX_OK;
     };
     if (op == MGX_OP_COPY_LHS && no_bcast && u_len == out_len) {
-      a.src = U;
+      a.src = U; a.src_rows = csr->num_cols;
       launch_fast<Idx, MODE_COPY_LHS>(a, csr->nnz, s);
       MGX_CHECK_LAUNCH();
       return fixup();
     }
     if (op == MGX_OP_COPY_RHS && no_bcast && e_len == out_len && !src_scale) {
-      a.src = E;
+      a.src = E; a.src_rows = csr->nnz;
       launch_fast<Idx, MODE_COPY_RHS>(a, csr->nnz, s);
       MGX_CHECK_LAUNCH();
       return fixup();
@@ -497,7 +689,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     // u_mul_e with one weight per (edge, head): U (N,H,F) x E (E,H,1); also (N,D) x (E,1).
     // ABI rule: a NULL offset table with e_len < out_len means head-wise broadcast, k -> k / (out_len/e_len).
     if (op == MGX_OP_MUL && u_len == out_len && no_bcast && e_len >= 1 && out_len % e_len == 0) {
-      a.src = U; a.w = E; a.H = (int)e_len; a.F = (int)(out_len / e_len);
+      a.src = U; a.w = E; a.H = (int)e_len; a.F = (int)(out_len / e_len); a.src_rows = csr->num_cols;
       launch_fast<Idx, MODE_MUL_EDGE>(a, csr->nnz, s);
       MGX_CHECK_LAUNCH();
       return fixup();

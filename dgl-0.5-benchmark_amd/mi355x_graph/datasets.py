@@ -39,7 +39,7 @@ def _power_law_degrees(n, total, max_deg, gen, device, alpha=2.1):
     return d.clamp(min=0.5, max=float(max_deg))
 
 
-def synthetic_edges(n, m, max_deg, seed, device="cpu", mixing=0.25, symmetric=True, permute=True):
+def synthetic_edges(n, m, max_deg, seed, device="cpu", mixing=0.25, symmetric=True, permute=True, avg_comm=None):
     """m edges over n nodes: endpoints drawn proportionally to a power-law weight; a fraction
     (1 - mixing) of the edges stays inside the source's planted community.  Returns int64 (src, dst);
     when `symmetric`, both directions are stored (2m directed edges, like OGB's DGL graphs)."""
@@ -48,7 +48,7 @@ def synthetic_edges(n, m, max_deg, seed, device="cpu", mixing=0.25, symmetric=Tr
     gen.manual_seed(seed)
     w = _power_law_degrees(n, 2.0 * m, max_deg, gen, device)
     # planted communities: contiguous ranges of power-law sizes
-    avg_c = max(16, min(n // 8, int(8 * math.sqrt(n))))
+    avg_c = avg_comm or max(16, min(n // 8, int(8 * math.sqrt(n))))
     n_comm = max(1, n // avg_c)
     cuts = torch.sort(torch.randint(0, n, (n_comm - 1,), generator=gen, device=device))[0] if n_comm > 1 else \
         torch.zeros(0, dtype=torch.int64, device=device)
