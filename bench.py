@@ -227,7 +227,7 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("dataset") == args.dataset and tj.get("D") == D:
                 traffic = tj.get("hbm_bytes_per_launch")
-        roofline = {"bound": "hbm", "kernel": "mgx::spmm_rowwave_kernel (copy_u/sum, D=%d)" % D,
+        roofline = {"bound": "hbm", "kernel": "mgx::spmm_rowwave32_kernel<4,16,copy_lhs> (copy_u/sum, D=%d)" % D,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(avg * 1e3, 4),

@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def find(d, suffix):
     f = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None  # newest run in that directory
 
 
 def short(name):
@@ -68,9 +68,9 @@ def main():
         lines.append("%-70s %8d %14.1f %14.1f %10.3f" % (short(k)[:70], n, rd / 1e6, wr / 1e6, l2))
         summary[k] = {"launches": n, "hbm_read_bytes": rd, "hbm_write_bytes": wr, "l2_hit_rate": l2}
     open(os.path.join(HERE, tag + "_pmc_summary.txt"), "w").write("\n".join(lines) + "\n")
-    # dominant kernel of bench.py: copy_u/sum g-SpMM at D=64 = spmm_rowwave_kernel<int, 4, 16, 0>
+    # dominant kernel of bench.py: copy_u/sum g-SpMM at D=64 = spmm_rowwave32_kernel<VEC=4, G=16, copy_lhs, WMODE=0, no lane mask>
     for k, v in summary.items():
-        if "spmm_rowwave_kernel<int, 4, 16, 0>" in k:
+        if "spmm_rowwave32_kernel<4, 16, 0, 0, false>" in k:
             json.dump({"dataset": "products", "D": 64, "kernel": k,
                        "hbm_bytes_per_launch": int(v["hbm_read_bytes"] + v["hbm_write_bytes"]),
                        "hbm_read_bytes": int(v["hbm_read_bytes"]), "hbm_write_bytes": int(v["hbm_write_bytes"]),
