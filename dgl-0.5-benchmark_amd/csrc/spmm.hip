@@ -595,9 +595,7 @@ static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, hipStream_t s) {
   a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);
   dim3 grid((unsigned)a.nblocks, (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
   if (split && launch_rowwave32<VEC, G, MODE>(a, a.src_rows, grid, s)) return;
-  const bool legacy = getenv("MGX_SPMM_LEGACY") != nullptr;  // A/B switch for experiments
-  if (split && !legacy) hipLaunchKernelGGL((spmm_rowwave_kernel<Idx, VEC, G, MODE>), grid, dim3(kBlock), 0, s, a);
-  else if (split) hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, true>), grid, dim3(kBlock), 0, s, a);
+  if (split) hipLaunchKernelGGL((spmm_rowwave_kernel<Idx, VEC, G, MODE>), grid, dim3(kBlock), 0, s, a);
   else hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, false>), grid, dim3(kBlock), 0, s, a);
 }
 
