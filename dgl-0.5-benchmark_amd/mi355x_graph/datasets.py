@@ -9,6 +9,7 @@ permuted so the natural numbering carries no locality.  Nothing here comes from 
   LegacyTUDataset / Subset           main_dgl_enzymes_gcn.py:11,155-163
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -85,6 +86,7 @@ class NodeData(object):
 
     def __init__(self, name, device="cpu", feat_dim=None, scale=1.0, gen_device=None):
         spec = dict(SHAPES[name])
+        scale = scale * float(os.environ.get("MGX_DATASET_SCALE", "1"))  # tests shrink the stand-ins
         n = max(16, int(spec["n"] * scale))
         m = max(16, int(spec["m"] * scale))
         feat = feat_dim or spec["feat"]

@@ -32,6 +32,7 @@ class GraphIndex(object):
         self._hidden_csc = None  # in-CSR built for SpMM on graphs restricted to formats('coo')
         self._hidden_csr = None
         self._canonical = None
+        self.dst_is_src_prefix = False  # blocks: destination nodes are the first source nodes
 
     # -- basic facts
     def _any(self):
@@ -98,6 +99,7 @@ class GraphIndex(object):
             return self._hidden_csc
         src, dst = self.coo()
         view = sparse.coo_to_csr(self.num_dst, self.num_src, dst, src)
+        view.dst_is_src_prefix = self.dst_is_src_prefix
         if self.allowed("csc"):
             self._csc = view
         else:
@@ -177,6 +179,7 @@ class GraphIndex(object):
         coo = None if self._coo is None else (self._coo[0].to(device), self._coo[1].to(device))
         g = GraphIndex(self.num_src, self.num_dst, coo, mv(self._csr), mv(self._csc), self._formats)
         g._hidden_csc, g._hidden_csr = mv(self._hidden_csc), mv(self._hidden_csr)
+        g.dst_is_src_prefix = self.dst_is_src_prefix
         return g
 
     def astype(self, dtype):
@@ -188,6 +191,7 @@ class GraphIndex(object):
         coo = None if self._coo is None else (self._coo[0].to(dtype), self._coo[1].to(dtype))
         g = GraphIndex(self.num_src, self.num_dst, coo, cv(self._csr), cv(self._csc), self._formats)
         g._hidden_csc, g._hidden_csr = cv(self._hidden_csc), cv(self._hidden_csr)
+        g.dst_is_src_prefix = self.dst_is_src_prefix
         return g
 
     def in_degrees(self):
@@ -425,6 +429,10 @@ class DGLGraph(object):
 
     def set_batch_num_edges(self, val):
         self._batch_num_edges = torch.as_tensor(val, dtype=torch.int64, device=self.device)
+
+    def subgraph(self, nodes, **kwargs):
+        from .sampling import node_subgraph
+        return node_subgraph(self, nodes)
 
     # -- message passing (implemented in core.py to keep this file structural)
     def update_all(self, message_func, reduce_func, apply_node_func=None, etype=None):

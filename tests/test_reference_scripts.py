@@ -9,13 +9,14 @@ import sys
 import pytest
 
 REF = "/root/reference/end_to_end/full_graph"
+REF_SAMPLING = "/root/reference/end_to_end/sampling/node-classification"
 HERE = os.path.dirname(os.path.abspath(__file__))
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
 
 
-def run(script, *args):
-    env = dict(os.environ, OMP_NUM_THREADS="4")
-    p = subprocess.run([sys.executable, os.path.join(HERE, "run_reference_script.py"), os.path.join(REF, script)] + list(args),
+def run(script, *args, root=REF, **extra_env):
+    env = dict(os.environ, OMP_NUM_THREADS="4", **extra_env)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "run_reference_script.py"), os.path.join(root, script)] + list(args),
                        capture_output=True, text=True, timeout=600, env=env, cwd=HERE)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     return p.stdout
@@ -41,3 +42,12 @@ def test_reference_script_runs_unmodified(script, args):
     times = re.findall(r"Training time/epoch ([0-9.eE+-]+)", out)
     if "molhiv" not in script:
         assert times, out[-1500:]
+
+
+@pytest.mark.timeout(900)
+def test_neighbor_sampling_script_runs_unmodified():
+    """reddit/ns-sage-dgl.py (MultiLayerNeighborSampler + NodeDataLoader + dglnn.SAGEConv on
+    blocks, full-neighbour inference) on a 1 %-scale reddit stand-in."""
+    out = run("reddit/ns-sage-dgl.py", "--gpu", "-1", "--num-epochs", "7", "--num-workers", "0", "--eval-every", "5",
+              "--batch-size", "256", root=REF_SAMPLING, MGX_DATASET_SCALE="0.01")
+    assert "Avg epoch time" in out and "Test Acc" in out, out[-1500:]
