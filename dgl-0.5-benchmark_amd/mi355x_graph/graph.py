@@ -33,6 +33,7 @@ class GraphIndex(object):
         self._hidden_csr = None
         self._canonical = None
         self.dst_is_src_prefix = False  # blocks: destination nodes are the first source nodes
+        self.max_in_degree_hint = None
 
     # -- basic facts
     def _any(self):

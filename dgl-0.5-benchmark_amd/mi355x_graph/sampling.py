@@ -54,7 +54,7 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
     return src, dst, eid
 
 
-def to_block(g_or_edges, dst_nodes, num_nodes=None, idtype=torch.int64):
+def to_block(g_or_edges, dst_nodes, num_nodes=None, idtype=torch.int64, dst_sorted=False, max_in_degree=None):
     """Bipartite block: dst = `dst_nodes` (kept in order), src = dst_nodes followed by the other sources.
     `g_or_edges` is (src, dst[, eid]) in global ids."""
     src, dst = g_or_edges[0].long(), g_or_edges[1].long()
@@ -71,9 +71,19 @@ def to_block(g_or_edges, dst_nodes, num_nodes=None, idtype=torch.int64):
     extra = uniq[lut[uniq] < 0]
     lut[extra] = dst_nodes.shape[0] + torch.arange(extra.shape[0], device=dev)
     src_nodes = torch.cat([dst_nodes, extra])
-    block = DGLGraph(GraphIndex(src_nodes.shape[0], dst_nodes.shape[0],
-                                coo=(lut[src].to(idtype).contiguous(), lut[dst].to(idtype).contiguous())), is_block=True)
+    l_src, l_dst = lut[src].to(idtype).contiguous(), lut[dst].to(idtype).contiguous()
+    csc = None
+    if dst_sorted:  # edges arrive grouped by destination in dst_nodes order: the in-CSR is a cumsum away (no sort)
+        from .sparse import CsrView
+        indptr = torch.zeros(dst_nodes.shape[0] + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(torch.bincount(l_dst.long(), minlength=dst_nodes.shape[0]), 0, out=indptr[1:])
+        csc = CsrView(dst_nodes.shape[0], src_nodes.shape[0], indptr.to(idtype), l_src, None)
+        csc.dst_is_src_prefix = True
+        if max_in_degree is not None and max_in_degree <= 256:
+            csc._plan = None  # no row can need splitting and the block is tiny: skip the schedule (and its host syncs)
+    block = DGLGraph(GraphIndex(src_nodes.shape[0], dst_nodes.shape[0], coo=(l_src, l_dst), csc=csc), is_block=True)
     block._index.dst_is_src_prefix = True
+    block._index.max_in_degree_hint = max_in_degree
     block.srcdata[NID] = src_nodes
     block.dstdata[NID] = dst_nodes
     if eid is not None:
@@ -95,7 +105,9 @@ class MultiLayerNeighborSampler(object):
         n = g.number_of_nodes()
         for fanout in reversed(self.fanouts):
             frontier = sample_neighbors(g, seeds, fanout, generator=generator)
-            block = to_block(frontier, seeds, num_nodes=n, idtype=g.idtype)
+            # sample_neighbors returns edges grouped by seed in seed order (CSR positions sorted inside a seed)
+            block = to_block(frontier, seeds, num_nodes=n, idtype=g.idtype, dst_sorted=True,
+                             max_in_degree=fanout if (fanout is not None and fanout >= 0) else None)
             seeds = block.srcdata[NID]
             blocks.insert(0, block)
         return blocks

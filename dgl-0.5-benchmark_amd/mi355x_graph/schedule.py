@@ -163,11 +163,22 @@ def build_plan(csr, order=None, split=1024, order_kind="natural"):
 _CLUSTER_MIN_NNZ = int(os.environ.get("MGX_CLUSTER_MIN_NNZ", 4_000_000))
 
 
+_SMALL_NNZ = 200_000
+
+
+def _no_hubs_cheaply(csr):
+    """Small graphs (sampled blocks, batched molecules): one fused max over the degrees, one host sync."""
+    deg = csr.indptr[1:] - csr.indptr[:-1]
+    return int(deg.max().item()) <= int(os.environ.get("MGX_SPLIT", 256))
+
+
 def plan_for(csr):
     """Default policy: always split hubs; cluster the row order only for big square graphs.
     MGX_SCHEDULE=natural|cluster|none overrides (none: no plan at all)."""
     mode = os.environ.get("MGX_SCHEDULE", "auto")
     if mode == "none" or csr.num_rows == 0 or csr.nnz == 0:
+        return None
+    if mode == "auto" and csr.nnz < _SMALL_NNZ and csr.nnz // max(csr.num_rows, 1) < 64 and _no_hubs_cheaply(csr):
         return None
     split = int(os.environ.get("MGX_SPLIT", 256))  # 256 measured best on MI355X (1024: +5..10 %)
     want_cluster = mode == "cluster" or (mode == "auto" and csr.nnz >= _CLUSTER_MIN_NNZ)

@@ -71,7 +71,10 @@ class CsrView(object):
 
     def degrees(self):
         if self._deg is None:
-            self._deg = backend_for(self.indptr).degrees(self)
+            if self.indptr.is_cuda:
+                self._deg = backend_for(self.indptr).degrees(self)
+            else:  # integer graph preparation on the host, like the reference (bit-exact either way)
+                self._deg = self.indptr[1:] - self.indptr[:-1]
         return self._deg
 
     def inv_degrees(self):
