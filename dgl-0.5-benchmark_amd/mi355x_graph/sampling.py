@@ -31,6 +31,15 @@ def sample_neighbors(g, nodes, fanout, edge_dir="in", prob=None, replace=False, 
     csc = idx.csc()
     dev = csc.device
     nodes = torch.as_tensor(nodes, device=dev).long()
+    if nodes.is_cuda and fanout is not None and 1 <= fanout <= 64:
+        # device path: mgx_sample_neighbors (one thread per seed, Floyd's algorithm); the torch formulation below
+        # sorts every candidate edge (12 M for a 25 k-node reddit frontier) and is kept for CPU graphs
+        from . import sparse
+        rng_seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator).item()) if (generator is None or generator.device.type == "cpu") \
+            else int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=generator.device).item())
+        src, eid, counts = sparse.backend_for(csc.indptr).sample_neighbors(csc, nodes.to(csc.indptr.dtype), fanout, rng_seed)
+        dst = torch.repeat_interleave(nodes, counts)
+        return src.long(), dst, eid.long()
     indptr = csc.indptr.long()
     beg = indptr[nodes]
     deg = indptr[nodes + 1] - beg

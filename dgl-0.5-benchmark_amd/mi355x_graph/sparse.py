@@ -301,6 +301,23 @@ class HipBackend(object):
             _lib.check(_lib.lib().mgx_segment_reduce(n, _ptr(offsets), x2d.shape[1], REDUCE[reduce], _ptr(x2d), _ptr(out), _ptr(arg), _stream(dev)))
         return out, arg
 
+    def sample_neighbors(self, csr, seeds, fanout, rng_seed):
+        """seeds: graph-idtype tensor on the device.  Returns (src, eid, counts) with the picks of seed i at
+        [offsets[i], offsets[i+1])."""
+        dev = self._check_dev(csr.indptr, seeds)
+        deg = (csr.indptr[seeds.long() + 1] - csr.indptr[seeds.long()]).long()
+        counts = torch.clamp(deg, max=fanout)
+        offsets = torch.zeros(seeds.shape[0] + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=offsets[1:])
+        total = int(offsets[-1].item())
+        src = torch.empty(total, dtype=csr.indptr.dtype, device=dev)
+        eid = torch.empty(total, dtype=csr.indptr.dtype, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_sample_neighbors(ctypes.byref(csr.c_struct()), seeds.shape[0], _ptr(seeds), int(fanout),
+                                                       ctypes.c_uint64(rng_seed & (2 ** 64 - 1)), _ptr(offsets), _ptr(src),
+                                                       _ptr(eid), _stream(dev)))
+        return src, eid, counts
+
     def gather_rows(self, x2d, idx):
         dev = self._check_dev(x2d, idx)
         out = torch.empty((idx.shape[0], x2d.shape[1]), dtype=torch.float32, device=dev)

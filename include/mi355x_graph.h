@@ -209,6 +209,18 @@ int32_t mgx_gather_rows(int64_t n, const void* idx, int32_t idx_bits, int64_t D,
 int32_t mgx_scatter_add_rows(int64_t n, const void* idx, int32_t idx_bits, int64_t D,
                              const float* in, float* x, void* stream);
 
+/* ------------------------------------------------------------------ neighbor sampling
+ * Replaces the CPU-side sampling of dgl.dataloading.MultiLayerNeighborSampler / dgl.sampling.sample_neighbors
+ * (end_to_end/sampling/node-classification/reddit/ns-sage-dgl.py:132-141): for every seed v (a row of the in-CSR)
+ * keep all in-edges when in_degree(v) <= fanout, else `fanout` distinct in-edges drawn uniformly (Floyd's
+ * algorithm, counter-based generator: the same rng_seed gives the same sample).  The caller computes
+ * out_offsets = exclusive cumsum of min(in_degree, fanout) ([num_seeds+1], int64) and allocates out_src / out_eid
+ * (graph index width, out_offsets[num_seeds] entries).  Picks of one seed are written in CSR order.
+ * fanout in [1, 64]. */
+int32_t mgx_sample_neighbors(const mgx_csr* csr, int64_t num_seeds, const void* seeds, int32_t fanout,
+                             uint64_t rng_seed, const int64_t* out_offsets, void* out_src, void* out_eid,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

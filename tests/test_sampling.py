@@ -118,3 +118,38 @@ def test_block_kernels_and_minibatch_step_on_gpu(oracle):
     # GATConv accepts blocks too
     conv = GATConv(32, 8, 2, allow_zero_in_degree=True).to(dev)
     assert conv(blocks[0], x).shape == (blocks[0].number_of_dst_nodes(), 2, 8)
+
+
+@pytest.mark.gpu
+def test_device_sampler_invariants_and_uniformity():
+    """mgx_sample_neighbors (HIP): same invariants as the torch formulation, reproducible per seed, uniform."""
+    dev = "cuda:0"
+    g, s, d = make_graph(n=3000, m=60000, device=dev)
+    g = g.int()
+    n = g.number_of_nodes()
+    s, d = s.to(dev), d.to(dev)
+    deg = torch.bincount(d, minlength=n)
+    seeds = torch.randperm(n, device=dev)[:700]
+    for fanout in (1, 7, 25, 64):
+        gen = torch.Generator().manual_seed(fanout)
+        src, dst, eid = sampling.sample_neighbors(g, seeds, fanout, generator=gen)
+        assert torch.equal(s[eid], src) and torch.equal(d[eid], dst)
+        cnt = torch.bincount(dst, minlength=n)
+        assert torch.equal(cnt[seeds], torch.clamp(deg[seeds], max=fanout))
+        assert eid.unique().numel() == eid.numel()
+        # grouped by seed in seed order, CSR positions ascending inside a seed
+        seg = torch.repeat_interleave(torch.arange(seeds.numel(), device=dev), cnt[seeds])
+        assert torch.equal(dst, seeds[seg])
+        src2, dst2, eid2 = sampling.sample_neighbors(g, seeds, fanout, generator=torch.Generator().manual_seed(fanout))
+        assert torch.equal(eid, eid2)  # same generator state -> same sample
+    hub = int(torch.argmax(deg))
+    in_edges = torch.nonzero(d == hub).flatten()
+    picks = torch.zeros(n * 0 + int(s.numel()), device=dev)
+    draws = 2000
+    hub_t = torch.full((draws,), hub, device=dev)  # the same seed many times in one call: independent draws per slot
+    _, _, e = sampling.sample_neighbors(g, hub_t, 10)
+    picks.index_add_(0, e, torch.ones(e.numel(), device=dev))
+    p = picks[in_edges]
+    expect = draws * 10 / float(deg[hub])
+    assert float(p.sum()) == draws * 10 and float(picks.sum()) == draws * 10
+    assert float((p - expect).abs().max()) < 6 * np.sqrt(expect)  # binomial spread; a biased sampler fails this
