@@ -31,8 +31,9 @@ for _p in (ROOT, PKG):
         sys.path.insert(0, _p)
 
 # Dense layers of the (unmodified) model are rocBLAS/hipBLASLt GEMMs; their default heuristics pick 3 ms kernels for
-# the tall-skinny weight-gradient shapes (K = 2.45 M).  PyTorch's TunableOp selections for exactly these shapes were
-# recorded once on MI355X (dgl-0.5-benchmark_amd/tunableop_products0.csv, 7 min of tuning) and are only LOADED here
+# the tall-skinny weight-gradient shapes (K = 2.45 M).  PyTorch's TunableOp selections for exactly these shapes --
+# the full graph and the per-rank owned-row counts of the deterministic P = 2, 4, 8 partitions -- were recorded once on
+# MI355X by experiments/tune_dense.py (dgl-0.5-benchmark_amd/tunableop_products<device>.csv) and are only LOADED here
 # (tuning off), which is a user-level PyTorch setting, not part of the message-passing library.
 if os.environ.get("MGX_BENCH_TUNABLEOP", "1") == "1":
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
