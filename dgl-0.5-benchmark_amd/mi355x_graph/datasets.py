@@ -117,7 +117,10 @@ class NodeData(object):
 
 
 def RedditDataset(self_loop=False, **kw):
-    d = NodeData("reddit-small" if kw.pop("small", False) else "reddit", **kw)
+    from . import diskio
+    d = diskio.find_dataset("reddit")  # the real files when MGX_DATA_ROOT holds them
+    if d is None:
+        d = NodeData("reddit-small" if kw.pop("small", False) else "reddit", **kw)
     if self_loop:
         d.graph = transform.add_self_loop(d.graph)
     return d

@@ -392,3 +392,22 @@ def test_spmm_accumulate_and_scales(oracle):
     i2 = oracle.coo_to_csr(n_dst, d2, s2)
     ref = (oracle.spmm(*i1, "copy_lhs", "sum", X * ss[:, None], None) + oracle.spmm(*i2, "copy_lhs", "sum", Y, None)) * ds[:, None]
     assert rel(out.cpu(), ref) < RTOL
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a C ABI: a C program (no Python, no torch) builds against include/mi355x_graph.h, links
+    libmi355x_graph.so and gets the hand-computed answers."""
+    import shutil
+    import subprocess
+    from mi355x_graph import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("gcc / ROCm headers not available")
+    here = os.path.dirname(os.path.abspath(__file__))
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.check_call([gcc, "-std=c99", "-D__HIP_PLATFORM_AMD__", os.path.join(here, "abi_c", "abi_smoke.c"), "-o", exe,
+                           "-I", os.path.dirname(_lib.HEADER_PATH), "-I", "/opt/rocm/include", "-L", _lib.CSRC_DIR,
+                           "-lmi355x_graph", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + _lib.CSRC_DIR, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "abi_smoke ok" in out.stdout, out.stdout + out.stderr
