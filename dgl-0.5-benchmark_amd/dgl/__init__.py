@@ -6,7 +6,7 @@ from mi355x_graph import DGLError, DGLGraph, DGLHeteroGraph, graph, create_block
 from mi355x_graph.transform import (to_bidirected, add_self_loop, remove_self_loop, add_reverse_edges,  # noqa: F401
                                     reverse, from_networkx, from_scipy, batch, unbatch)
 from mi355x_graph import function, ops  # noqa: F401
-from . import nn, data, dataloading, utils, sampling  # noqa: F401
+from . import nn, data, dataloading, utils, sampling, transform, backend  # noqa: F401
 from mi355x_graph.sampling import to_block, NID, EID  # noqa: F401
 from mi355x_graph.ops import edge_softmax  # noqa: F401
 

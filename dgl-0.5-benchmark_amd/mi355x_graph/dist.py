@@ -83,7 +83,8 @@ def partition_nodes(src, dst, num_nodes, num_parts, rounds=5, clusters=None):
             part[c] = best
             load[best] += weight[c]
     assign = torch.from_numpy(part).to(dev)[inv]
-    assign = _refine(assign, src.long(), dst.long(), node_w, num_parts, 1.03)
+    if num_nodes * num_parts <= 200_000_000:  # the refinement keeps a dense [N, P] neighbour-count table
+        assign = _refine(assign, src.long(), dst.long(), node_w, num_parts, 1.03)
     cut = float((assign[src.long()] != assign[dst.long()]).float().mean().item()) if src.numel() else 0.0
     return assign, {"edge_cut": cut, "num_clusters": int(uniq.shape[0])}
 

@@ -431,6 +431,27 @@ class DGLGraph(object):
     def set_batch_num_edges(self, val):
         self._batch_num_edges = torch.as_tensor(val, dtype=torch.int64, device=self.device)
 
+    def in_degree(self, v):
+        return int(self.in_degrees(torch.as_tensor([v]))[0])
+
+    def out_degree(self, u):
+        return int(self.out_degrees(torch.as_tensor([u]))[0])
+
+    def find_edges(self, eid, etype=None):
+        src, dst = self._index.coo()
+        e = torch.as_tensor(eid, device=src.device).long().view(-1)
+        if e.numel() and (int(e.max()) >= src.shape[0] or int(e.min()) < 0):
+            raise DGLError("find_edges: edge id out of range")
+        return src[e], dst[e]
+
+    def has_edges_between(self, u, v):
+        src, dst = self._index.coo()
+        n = max(self._index.num_dst, 1)
+        key = torch.sort(src.long() * n + dst.long())[0]
+        q = torch.as_tensor(u, device=src.device).long() * n + torch.as_tensor(v, device=src.device).long()
+        pos = torch.searchsorted(key, q).clamp(max=max(key.shape[0] - 1, 0))
+        return key[pos] == q if key.numel() else torch.zeros_like(q, dtype=torch.bool)
+
     def subgraph(self, nodes, **kwargs):
         from .sampling import node_subgraph
         return node_subgraph(self, nodes)

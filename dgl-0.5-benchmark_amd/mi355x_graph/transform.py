@@ -143,3 +143,29 @@ def unbatch(g):
         out.append(sub)
         no, eo = no + n, eo + e
     return out
+
+
+def metis_partition_assignment(g, k, balance_ntypes=None, balance_edges=False):
+    """k-way edge-cut node partition -> [N] part ids.  The role of dgl.transform.metis_partition_assignment
+    (end_to_end/sampling/link-prediction/dgl_cluster_sampler.py:24); METIS itself is not available offline, the
+    partitioner is the label-propagation + greedy placement + refinement of mi355x_graph/dist.py."""
+    from .dist import partition_nodes
+    src, dst = g.edges()
+    assign, _ = partition_nodes(src.long(), dst.long(), g.number_of_nodes(), int(k))
+    return assign
+
+
+def metis_partition(g, k, extra_cached_hops=0, reshuffle=False, balance_ntypes=None, balance_edges=False):
+    """dict part_id -> induced subgraph carrying ndata[dgl.NID]
+    (cluster-sage/dgl/partition_utils.py:9-16: `for k, val in metis_partition(g, psize).items(): val.ndata[dgl.NID]`)."""
+    if extra_cached_hops:
+        raise DGLError("metis_partition: extra_cached_hops is not supported")
+    assign = metis_partition_assignment(g, k)
+    order = torch.sort(assign, stable=True)[1]
+    counts = torch.bincount(assign, minlength=int(k)).tolist()
+    parts, off = {}, 0
+    for i, c in enumerate(counts):
+        if c:
+            parts[i] = g.subgraph(order[off:off + c])
+        off += c
+    return parts

@@ -214,3 +214,35 @@ def test_rccl_api_path_single_rank():
         assert torch.allclose(generic_path(g, feats).cpu(), ref_gen, rtol=1e-4, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_metis_partition_api_for_cluster_gcn():
+    """dgl.transform.metis_partition(g, psize) as cluster-sage/dgl/partition_utils.py:9-16 uses it,
+    plus subgraph_collate_fn's g.subgraph(nids) (sampler.py:63-71)."""
+    import dgl
+    from dgl.transform import metis_partition
+    from dgl import backend as F
+    from mi355x_graph.datasets import synthetic_edges
+    n = 6000
+    src, dst = synthetic_edges(n, 60000, 300, seed=2, symmetric=True)
+    g = dgl.graph((src, dst), num_nodes=n)
+    g.ndata["feat"] = torch.rand(n, 4)
+    parts = metis_partition(g, 50)
+    nids = [F.asnumpy(val.ndata[dgl.NID]) for k, val in parts.items()]
+    allids = np.concatenate(nids)
+    assert len(allids) == n and len(np.unique(allids)) == n            # a partition of the node set
+    sizes = np.array([len(x) for x in nids])
+    assert sizes.max() < 6 * sizes.mean()
+    intra = sum(val.number_of_edges() for val in parts.values()) / g.number_of_edges()
+    rnd = torch.randint(0, 50, (n,))
+    assert intra > 3 * float((rnd[src] == rnd[dst]).float().mean())    # far fewer cut edges than a random split
+    batch = np.concatenate(nids[:5]).astype(np.int64)                    # ClusterIter batch -> subgraph_collate_fn
+    g1 = g.subgraph(batch)
+    nid = g1.ndata[dgl.NID]
+    assert torch.equal(nid, torch.from_numpy(batch)) and torch.equal(g1.ndata["feat"], g.ndata["feat"][nid])
+    s1, d1 = g1.edges()
+    assert bool(g.has_edges_between(nid[s1.long()], nid[d1.long()]).all())
+    g1.create_formats_()
+    assert g.in_degree(0) == int((dst == 0).sum()) and g.out_degree(0) == int((src == 0).sum())
+    fs, fd = g.find_edges(0)
+    assert int(fs[0]) == int(src[0]) and int(fd[0]) == int(dst[0])
