@@ -211,6 +211,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         mdist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        lt = torch.tensor([loss], dtype=torch.float64, device=device)  # each rank holds its share of the global mean
+        mdist.all_reduce(lt, op=dist.ReduceOp.SUM)
+        loss = float(lt.item())
 
     # ---- roofline of the dominant kernel: copy_u g-SpMM at D = hidden (4 of the 5 launches per epoch)
     D = cfg["hidden"]

@@ -1,4 +1,5 @@
-"""A/B: legacy row loop vs software-pipelined row-per-wave kernel, by graph / D / schedule."""
+"""A/B of kernel variants selected by environment variables (default: 64-bit row-per-wave kernel vs the lean 32-bit one),
+by graph / D / schedule."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dgl-0.5-benchmark_amd"))
 import torch
@@ -9,7 +10,7 @@ from mi355x_graph.datasets import SHAPES, synthetic_edges
 dev = torch.device("cuda:0")
 names = sys.argv[1].split(",")
 Ds = [int(x) for x in sys.argv[2].split(",")]
-envs = [e for e in (sys.argv[3] if len(sys.argv) > 3 else "MGX_SPMM_LEGACY=1;").split(";")]
+envs = [e for e in (sys.argv[3] if len(sys.argv) > 3 else "MGX_SPMM_V1=1;").split(";")]
 
 def make(name):
     if name == "banded":
