@@ -41,6 +41,9 @@ SIGNATURES = {
     "mgx_last_error": (ctypes.c_char_p, []),
     "mgx_abi_version": (_i32, []),
     "mgx_device_info": (_i32, [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32]),
+    "mgx_spmm_plan_workspace": (_i64, [_i64]),
+    "mgx_spmm_plan_count": (_i32, [_csr_p, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "mgx_spmm_plan_fill": (_i32, [_csr_p, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mgx_spmm_csr": (_i32, [_csr_p, _vp, _i32, _i32, _fp, _fp, _i64, _i64, _i64, _vp, _vp, _fp, _fp, _fp, _vp, _vp,
                             _fp, _i32, _vp]),
     "mgx_sddmm_coo": (_i32, [_i64, _i64, _i64, _vp, _vp, _i32, _i32, _fp, _fp, _i32, _i32, _i64, _i64, _i64, _i64,

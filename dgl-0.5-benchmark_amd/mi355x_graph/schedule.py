@@ -117,7 +117,35 @@ def locality_order(csr, rounds=5):
     return order
 
 
+def _build_plan_device(csr, order, split, order_kind):
+    """mgx_spmm_plan_count / _fill: the tables are built by the library (csrc/plan.hip); one host read of the totals."""
+    import ctypes
+    from . import _lib
+    from .sparse import _ptr, _stream
+    dev, n, idt = csr.device, csr.num_rows, csr.indptr.dtype
+    L = _lib.lib()
+    with torch.cuda.device(dev):
+        ws_bytes = L.mgx_spmm_plan_workspace(n)
+        if ws_bytes < 0:
+            _lib.check(3)
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+        totals = torch.empty(3, dtype=torch.int64, device=dev)
+        ordr = None if order is None else order.to(idt).contiguous()
+        _lib.check(L.mgx_spmm_plan_count(ctypes.byref(csr.c_struct()), split, _ptr(ordr), _ptr(totals), _ptr(ws), ws_bytes, _stream(dev)))
+        items, hubs, slots = [int(v) for v in totals.tolist()]
+        i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=dev)[:k]
+        item_row, item_node = i32(items), i32(items)
+        item_beg = torch.empty(items, dtype=idt, device=dev)
+        item_end = torch.empty(items, dtype=idt, device=dev)
+        hub_row, hub_ptr, slot_item = i32(hubs), torch.zeros(hubs + 1, dtype=torch.int32, device=dev), i32(slots)
+        _lib.check(L.mgx_spmm_plan_fill(ctypes.byref(csr.c_struct()), split, _ptr(ordr), _ptr(item_row), _ptr(item_beg), _ptr(item_end),
+                                        _ptr(item_node), _ptr(hub_row), _ptr(hub_ptr), _ptr(slot_item), _ptr(ws), ws_bytes, _stream(dev)))
+    return SpmmPlan(item_row, item_beg, item_end, hub_row, hub_ptr, slots, order_kind, slot_item, item_node)
+
+
 def build_plan(csr, order=None, split=1024, order_kind="natural"):
+    if csr.indptr.is_cuda and os.environ.get("MGX_PLAN_BUILDER", "device") == "device":
+        return _build_plan_device(csr, order, split, order_kind)
     dev = csr.device
     n = csr.num_rows
     if n >= 2 ** 31:

@@ -96,6 +96,21 @@ typedef struct mgx_spmm_plan {
   const int32_t* item_node;     /* [num_items] the row of EVERY item (direct or split); used by mgx_sddmm_csr */
 } mgx_spmm_plan;
 
+/* Device-side construction of the plan tables (hub-row splitting over an optional row order; NULL = natural order).
+ *   ws      = mgx_spmm_plan_workspace(num_rows) bytes, passed UNCHANGED from _count to _fill (it carries the scans);
+ *   _count  writes {num_items, num_hubs, num_slots} to `totals` (device int64[3]); the caller reads them, allocates
+ *           item_row/item_node [num_items] (int32), item_beg/item_end [num_items] (graph index width),
+ *           hub_row [num_hubs], hub_slot_ptr [num_hubs+1], slot_item [num_slots] (int32) and calls
+ *   _fill   with the same csr / split / row_order.
+ * The locality-aware row order itself is computed by the host layer (mi355x_graph/schedule.py). */
+int64_t mgx_spmm_plan_workspace(int64_t num_rows);
+int32_t mgx_spmm_plan_count(const mgx_csr* csr, int64_t split, const void* row_order, int64_t* totals,
+                            void* workspace, int64_t workspace_bytes, void* stream);
+int32_t mgx_spmm_plan_fill(const mgx_csr* csr, int64_t split, const void* row_order,
+                           int32_t* item_row, void* item_beg, void* item_end, int32_t* item_node,
+                           int32_t* hub_row, int32_t* hub_slot_ptr, int32_t* slot_item,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------ misc */
 const char* mgx_last_error(void);
 /* ABI version, bumped on any signature change. */

@@ -411,3 +411,25 @@ def test_c_abi_from_plain_c(tmp_path):
                            "-Wl,-rpath," + _lib.CSRC_DIR, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "abi_smoke ok" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+def test_device_plan_builder_bit_exact(idtype, monkeypatch):
+    """mgx_spmm_plan_count/_fill (csrc/plan.hip) against the torch formulation of schedule.build_plan."""
+    from mi355x_graph import schedule
+    n, nnz = 5000, 300000
+    src, dst = random_graph(n, n, nnz, seed=99)
+    csc = mk(n, n, src, dst, idtype)._index.csc()
+    order = torch.randperm(n, device=DEV)
+    for ordr in (None, order):
+        for split in (64, 256):
+            monkeypatch.setenv("MGX_PLAN_BUILDER", "device")
+            a = schedule.build_plan(csc, ordr, split)
+            monkeypatch.setenv("MGX_PLAN_BUILDER", "torch")
+            b = schedule.build_plan(csc, ordr, split)
+            assert a.num_items == b.num_items and a.num_hubs == b.num_hubs and a.num_slots == b.num_slots
+            assert a.num_hubs > 0
+            for x, y in ((a.item_row, b.item_row), (a.item_beg, b.item_beg), (a.item_end, b.item_end),
+                         (a.item_node, b.item_node), (a.hub_row, b.hub_row), (a.hub_slot_ptr, b.hub_slot_ptr),
+                         (a.slot_item, b.slot_item)):
+                assert torch.equal(x, y)
