@@ -40,6 +40,10 @@ void set_error(const char* fmt, ...);
     }                                                                               \
   } while (0)
 
+// First statement of every device entry point: drops a stale (sticky) error left by the CALLER's earlier HIP calls so
+// that MGX_CHECK_LAUNCH reports only this library's launches.
+#define MGX_ENTER() (void)hipGetLastError()
+
 // Called after every kernel launch: reports launch-configuration errors without synchronising.
 #define MGX_CHECK_LAUNCH() MGX_CHECK_HIP(hipGetLastError())
 

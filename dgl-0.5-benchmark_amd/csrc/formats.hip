@@ -91,6 +91,7 @@ static int32_t coo_to_csr_impl(int64_t n_rows, int64_t nnz, const Idx* row, cons
 
 extern "C" int64_t mgx_coo_to_csr_workspace(int64_t num_rows, int64_t nnz, int32_t idx_bits) {
   using namespace mgx;
+  MGX_ENTER();
   if (nnz <= 0) return 0;
   const int end_bit = ilog2_ceil(num_rows > 1 ? num_rows : 2);
   size_t temp = 0;
@@ -107,6 +108,7 @@ extern "C" int32_t mgx_coo_to_csr(int64_t num_rows, int64_t nnz, const void* row
                                   void* indptr, void* indices, void* eids, void* workspace, int64_t workspace_bytes,
                                   void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_coo_to_csr: idx_bits must be 32 or 64");
   MGX_CHECK_ARG(num_rows >= 0 && nnz >= 0, "mgx_coo_to_csr: negative sizes");
   MGX_CHECK_ARG(indptr != nullptr, "mgx_coo_to_csr: indptr is NULL");
@@ -121,6 +123,7 @@ extern "C" int32_t mgx_coo_to_csr(int64_t num_rows, int64_t nnz, const void* row
 
 extern "C" int32_t mgx_csr_degrees(int64_t num_rows, const void* indptr, int32_t idx_bits, void* deg, void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_csr_degrees: idx_bits must be 32 or 64");
   MGX_CHECK_ARG(num_rows >= 0, "mgx_csr_degrees: negative size");
   if (num_rows == 0) return MGX_OK;
@@ -134,6 +137,7 @@ extern "C" int32_t mgx_csr_degrees(int64_t num_rows, const void* indptr, int32_t
 
 extern "C" int32_t mgx_csr_inv_degrees(int64_t num_rows, const void* indptr, int32_t idx_bits, float* inv_deg, void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_csr_inv_degrees: idx_bits must be 32 or 64");
   MGX_CHECK_ARG(num_rows >= 0, "mgx_csr_inv_degrees: negative size");
   if (num_rows == 0) return MGX_OK;

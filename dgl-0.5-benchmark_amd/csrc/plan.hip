@@ -118,6 +118,7 @@ static inline unsigned plan_grid(int64_t n) {
 
 extern "C" int64_t mgx_spmm_plan_workspace(int64_t num_rows) {
   using namespace mgx;
+  MGX_ENTER();
   if (num_rows < 0) return -1;
   size_t temp = 0;
   if (scan_temp_bytes(num_rows + 1, &temp) != hipSuccess) {
@@ -130,6 +131,7 @@ extern "C" int64_t mgx_spmm_plan_workspace(int64_t num_rows) {
 extern "C" int32_t mgx_spmm_plan_count(const mgx_csr* csr, int64_t split, const void* row_order, int64_t* totals,
                                        void* workspace, int64_t workspace_bytes, void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(csr != nullptr && totals != nullptr, "mgx_spmm_plan_count: NULL argument");
   MGX_CHECK_ARG(csr->idx_bits == 32 || csr->idx_bits == 64, "mgx_spmm_plan_count: idx_bits must be 32 or 64");
   MGX_CHECK_ARG(split >= 1, "mgx_spmm_plan_count: split must be >= 1");
@@ -161,6 +163,7 @@ extern "C" int32_t mgx_spmm_plan_fill(const mgx_csr* csr, int64_t split, const v
                                       int32_t* hub_slot_ptr, int32_t* slot_item, void* workspace, int64_t workspace_bytes,
                                       void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(csr != nullptr, "mgx_spmm_plan_fill: csr is NULL");
   MGX_CHECK_ARG(csr->idx_bits == 32 || csr->idx_bits == 64, "mgx_spmm_plan_fill: idx_bits must be 32 or 64");
   MGX_CHECK_ARG(split >= 1, "mgx_spmm_plan_fill: split must be >= 1");

@@ -44,6 +44,7 @@ static int32_t rows_launch(int64_t n, const void* idx, int64_t D, const float* i
 extern "C" int32_t mgx_gather_rows(int64_t n, const void* idx, int32_t idx_bits, int64_t D, const float* x, float* out,
                                    void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_gather_rows: idx_bits must be 32 or 64");
   MGX_CHECK_ARG(n >= 0 && D >= 0, "mgx_gather_rows: negative sizes");
   MGX_CHECK_ARG(n == 0 || D == 0 || (idx && x && out), "mgx_gather_rows: NULL pointer");
@@ -54,6 +55,7 @@ extern "C" int32_t mgx_gather_rows(int64_t n, const void* idx, int32_t idx_bits,
 extern "C" int32_t mgx_scatter_add_rows(int64_t n, const void* idx, int32_t idx_bits, int64_t D, const float* in,
                                         float* x, void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_scatter_add_rows: idx_bits must be 32 or 64");
   MGX_CHECK_ARG(n >= 0 && D >= 0, "mgx_scatter_add_rows: negative sizes");
   MGX_CHECK_ARG(n == 0 || D == 0 || (idx && x && in), "mgx_scatter_add_rows: NULL pointer");

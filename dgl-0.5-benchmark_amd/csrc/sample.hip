@@ -63,6 +63,7 @@ extern "C" int32_t mgx_sample_neighbors(const mgx_csr* csr, int64_t num_seeds, c
                                         uint64_t rng_seed, const int64_t* out_offsets, void* out_src, void* out_eid,
                                         void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(csr != nullptr, "mgx_sample_neighbors: csr is NULL");
   MGX_CHECK_ARG(csr->idx_bits == 32 || csr->idx_bits == 64, "mgx_sample_neighbors: idx_bits must be 32 or 64");
   MGX_CHECK_ARG(num_seeds >= 0, "mgx_sample_neighbors: negative num_seeds");

@@ -339,6 +339,7 @@ extern "C" int32_t mgx_sddmm_coo(int64_t num_src, int64_t num_dst, int64_t nnz, 
                                  int64_t out_len, int64_t reduce_size, const int64_t* l_off, const int64_t* r_off,
                                  float* out, void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   (void)num_src; (void)num_dst;
   MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_sddmm_coo: idx_bits must be 32 or 64, got %d", idx_bits);
   MGX_CHECK_ARG(nnz >= 0, "mgx_sddmm_coo: negative nnz");
@@ -358,6 +359,7 @@ extern "C" int32_t mgx_sddmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, 
                                  int64_t out_len, int64_t reduce_size, const int64_t* l_off, const int64_t* r_off,
                                  float* out, void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(csr != nullptr, "mgx_sddmm_csr: csr is NULL");
   MGX_CHECK_ARG(csr->idx_bits == 32 || csr->idx_bits == 64, "mgx_sddmm_csr: idx_bits must be 32 or 64");
   MGX_CHECK_ARG(csr->nnz == 0 || (csr->indptr && csr->indices), "mgx_sddmm_csr: indptr/indices is NULL");

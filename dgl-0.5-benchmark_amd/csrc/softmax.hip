@@ -284,6 +284,7 @@ static int32_t softmax_check(const mgx_csr* csr, int64_t H) {
 extern "C" int32_t mgx_edge_softmax_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, const float* z,
                                         float* a, float* ws, void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   int32_t st = softmax_check(csr, H);
   if (st != MGX_OK) return st;
   MGX_CHECK_ARG(csr->nnz == 0 || H == 0 || (z && a), "mgx_edge_softmax_fwd: z/a is NULL");
@@ -294,6 +295,7 @@ extern "C" int32_t mgx_edge_softmax_fwd(const mgx_csr* csr, const mgx_spmm_plan*
 extern "C" int32_t mgx_edge_softmax_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, const float* a,
                                         const float* da, float* dz, float* ws, void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   int32_t st = softmax_check(csr, H);
   if (st != MGX_OK) return st;
   MGX_CHECK_ARG(csr->nnz == 0 || H == 0 || (a && da && dz), "mgx_edge_softmax_bwd: a/da/dz is NULL");

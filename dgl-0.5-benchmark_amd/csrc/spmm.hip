@@ -715,6 +715,7 @@ extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, i
                                 const float* dst_scale, float* out, void* arg_u, void* arg_e, float* partial_ws,
                                 int32_t flags, void* stream) {
   using namespace mgx;
+  MGX_ENTER();
   MGX_CHECK_ARG(csr != nullptr, "mgx_spmm_csr: csr is NULL");
   MGX_CHECK_ARG(csr->idx_bits == 32 || csr->idx_bits == 64, "mgx_spmm_csr: idx_bits must be 32 or 64, got %d", csr->idx_bits);
   MGX_CHECK_ARG(csr->num_rows >= 0 && csr->nnz >= 0, "mgx_spmm_csr: negative sizes");

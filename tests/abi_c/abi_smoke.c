@@ -17,7 +17,7 @@
 static void* dev_copy(const void* host, size_t bytes) {
   void* d = NULL;
   if (hipMalloc(&d, bytes ? bytes : 4) != hipSuccess) return NULL;
-  if (bytes) hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+  if (bytes && host) hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
   return d;
 }
 
