@@ -100,8 +100,11 @@ class GATConv(nn.Module):
             # e and a are internal to the module: keep them in in-CSR (destination-major) edge order so that
             # u_add_v, edge_softmax and u_mul_e/sum stream them instead of gathering by edge id
             cidx, perm = graph._index.canonical()
-            e = self.leaky_relu(ops.gsddmm(cidx, "add", el, er, "u", "v"))
-            a = self.attn_drop(ops.edge_softmax(cidx, e))
+            if int(el.shape[1]) <= 64:  # fused u_add_v -> leaky_relu -> edge_softmax: the logits are never materialised
+                a = self.attn_drop(ops.gat_attention(cidx, el, er, self.leaky_relu.negative_slope))
+            else:
+                e = self.leaky_relu(ops.gsddmm(cidx, "add", el, er, "u", "v"))
+                a = self.attn_drop(ops.edge_softmax(cidx, e))
             rst = ops.gspmm(cidx, "mul", "sum", feat_src, a)
             if self.res_fc is not None:
                 resval = self.res_fc(h_dst).view(h_dst.shape[0], -1, self._out_feats)

@@ -273,6 +273,27 @@ class HipBackend(object):
                                                        _ptr(ws), _stream(dev)))
         return a
 
+    def gat_attention_fwd(self, csr, el2d, er2d, slope):
+        dev = self._check_dev(csr.indptr, el2d, er2d)
+        H = el2d.shape[1]
+        a = torch.empty((csr.nnz, H), dtype=torch.float32, device=dev)
+        plan, ws = self._softmax_plan(csr, H, dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_gat_attention_fwd(ctypes.byref(csr.c_struct()), plan, H, _ptr(el2d), _ptr(er2d),
+                                                        ctypes.c_float(slope), _ptr(a), _ptr(ws), _stream(dev)))
+        return a
+
+    def gat_attention_bwd(self, csr, el2d, er2d, slope, a2d, da2d):
+        dev = self._check_dev(csr.indptr, el2d, er2d, a2d, da2d)
+        H = el2d.shape[1]
+        de = torch.empty_like(a2d)
+        plan, ws = self._softmax_plan(csr, H, dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_gat_attention_bwd(ctypes.byref(csr.c_struct()), plan, H, _ptr(el2d), _ptr(er2d),
+                                                        ctypes.c_float(slope), _ptr(a2d), _ptr(da2d), _ptr(de), _ptr(ws),
+                                                        _stream(dev)))
+        return de
+
     @staticmethod
     def _softmax_plan(csr, H, dev):
         plan = csr.plan()

@@ -185,6 +185,18 @@ int32_t mgx_edge_softmax_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* ma
 int32_t mgx_edge_softmax_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int64_t H,
                              const float* a, const float* da, float* dz, float* ws, void* stream);
 
+/* GAT attention with the logits fused in (GATConv, main_dgl_reddit_gat.py:31-55):
+ *   fwd: a[e,h]  = softmax_{e->v}( leaky_relu(el[u(e),h] + er[v(e),h], negative_slope) )
+ *        = apply_edges(fn.u_add_v) -> leaky_relu -> edge_softmax in ONE launch; the [nnz, H] logits are never written.
+ *   bwd: de[e,h] = (a*da - a*sum_{e'->v}(a*da)) * leaky_relu'(el[u]+er[v])   (gradient w.r.t. the pre-activation sum;
+ *        the caller reduces it over out-edges / in-edges with copy_e g-SpMMs to get d el / d er).
+ * el: [num_cols, H], er: [num_rows, H]; a, da, de: [nnz, H] by edge id.  plan / ws as for mgx_edge_softmax_*. */
+int32_t mgx_gat_attention_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int64_t H,
+                              const float* el, const float* er, float negative_slope, float* a, float* ws, void* stream);
+int32_t mgx_gat_attention_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int64_t H,
+                              const float* el, const float* er, float negative_slope,
+                              const float* a, const float* da, float* de, float* ws, void* stream);
+
 /* ------------------------------------------------------------------ segment reduce
  * Replaces dgl.nn.AvgPooling / dgl.ops.segment_reduce (main_dgl_molhiv_gcn.py:75,93).
  * offsets: int64 [num_segments+1] (cumsum of batch_num_nodes).  reduce: SUM, MEAN, MAX, MIN.

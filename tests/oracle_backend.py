@@ -89,6 +89,27 @@ class OracleBackend(object):
     def edge_softmax_bwd(self, csr, a2d, da2d):
         return torch.from_numpy(orc.edge_softmax_bwd(_np(csr.indptr), _np(csr.eids), _np(a2d), _np(da2d)))
 
+    def _gat_logits(self, csr, el2d, er2d, slope):
+        rows = torch.repeat_interleave(torch.arange(csr.num_rows), (csr.indptr[1:] - csr.indptr[:-1]).long())
+        t = el2d[csr.indices.long()] + er2d[rows]          # CSR-position order
+        z = torch.where(t > 0, t, t * slope)
+        if csr.eids is not None:                           # back to edge-id order
+            out = torch.empty_like(z)
+            out[csr.eids.long()] = z
+            z, tt = out, torch.empty_like(t)
+            tt[csr.eids.long()] = t
+            t = tt
+        return z.contiguous(), t
+
+    def gat_attention_fwd(self, csr, el2d, er2d, slope):
+        z, _ = self._gat_logits(csr, el2d, er2d, slope)
+        return self.edge_softmax_fwd(csr, z)
+
+    def gat_attention_bwd(self, csr, el2d, er2d, slope, a2d, da2d):
+        _, t = self._gat_logits(csr, el2d, er2d, slope)
+        dz = self.edge_softmax_bwd(csr, a2d, da2d)
+        return dz * torch.where(t > 0, torch.ones_like(t), torch.full_like(t, slope))
+
     def segment_reduce(self, offsets, x2d, reduce, want_arg):
         return torch.from_numpy(orc.segment_reduce(_np(offsets), _np(x2d), reduce)), None
 

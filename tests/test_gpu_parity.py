@@ -433,3 +433,35 @@ def test_device_plan_builder_bit_exact(idtype, monkeypatch):
                          (a.item_node, b.item_node), (a.hub_row, b.hub_row), (a.hub_slot_ptr, b.hub_slot_ptr),
                          (a.slot_item, b.slot_item)):
                 assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("H", [1, 3, 8])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_fused_gat_attention_matches_composition(oracle, H, canonical):
+    """mgx_gat_attention_fwd/bwd == apply_edges(u_add_v) -> leaky_relu -> edge_softmax (and its autograd), also on hub
+    rows (chunked path) and in canonical edge order."""
+    import torch.nn.functional as F
+    n, nnz = 900, 60000
+    src, dst = random_graph(n, n, nnz, seed=H + 40)
+    g = mk(n, n, src, dst)
+    gi = g._index.canonical()[0] if canonical else g._index
+    rng = np.random.default_rng(H)
+    el0 = T((rng.standard_normal((n, H, 1)) * 2).astype(np.float32))
+    er0 = T((rng.standard_normal((n, H, 1)) * 2).astype(np.float32))
+    w = torch.rand(nnz, H, 1, device=DEV)
+    el1, er1 = el0.clone().requires_grad_(True), er0.clone().requires_grad_(True)
+    el2, er2 = el0.clone().requires_grad_(True), er0.clone().requires_grad_(True)
+    a_f = ops.gat_attention(gi, el1, er1, 0.2)
+    a_u = ops.edge_softmax(gi, F.leaky_relu(ops.gsddmm(gi, "add", el2, er2, "u", "v"), 0.2))
+    assert a_f.shape == (nnz, H, 1)
+    assert float((a_f - a_u).abs().max()) < 1e-6
+    (a_f * w).sum().backward()
+    (a_u * w).sum().backward()
+    for x, y in ((el1.grad, el2.grad), (er1.grad, er2.grad)):
+        assert float((x - y).abs().max() / y.abs().max().clamp(min=1e-12)) < 1e-4
+    if not canonical:  # against the CPU oracle
+        ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+        z = oracle.sddmm(src, dst, "add", el0.cpu().numpy(), er0.cpu().numpy())
+        z = np.where(z > 0, z, 0.2 * z).astype(np.float32)
+        ref = oracle.edge_softmax_fwd(ip, ei, z.reshape(nnz, H))
+        assert rel(a_f.detach().cpu().view(nnz, H), ref) < RTOL
