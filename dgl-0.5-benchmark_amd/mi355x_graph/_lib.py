@@ -53,6 +53,9 @@ SIGNATURES = {
     "mgx_edge_softmax_bwd": (_i32, [_csr_p, _vp, _i64, _fp, _fp, _fp, _fp, _vp]),
     "mgx_gat_attention_fwd": (_i32, [_csr_p, _vp, _i64, _fp, _fp, ctypes.c_float, _fp, _fp, _vp]),
     "mgx_gat_attention_bwd": (_i32, [_csr_p, _vp, _i64, _fp, _fp, ctypes.c_float, _fp, _fp, _fp, _fp, _vp]),
+    "mgx_head_dot_fwd": (_i32, [_i64, _i64, _i64, _fp, _fp, _fp, _fp, _fp, _vp]),
+    "mgx_head_dot_bwd_workspace": (_i64, [_i64, _i64]),
+    "mgx_head_dot_bwd": (_i32, [_i64, _i64, _i64, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),
     "mgx_segment_reduce": (_i32, [_i64, _vp, _i64, _i32, _fp, _fp, _vp, _vp]),
     "mgx_coo_to_csr_workspace": (_i64, [_i64, _i64, _i32]),
     "mgx_coo_to_csr": (_i32, [_i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),

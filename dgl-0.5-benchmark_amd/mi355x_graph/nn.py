@@ -95,8 +95,15 @@ class GATConv(nn.Module):
                 if graph.is_block:
                     feat_dst = feat_src[:graph.number_of_dst_nodes()]
                     h_dst = h_dst[:graph.number_of_dst_nodes()]
-            el = (feat_src * self.attn_l).sum(dim=-1).unsqueeze(-1)
-            er = (feat_dst * self.attn_r).sum(dim=-1).unsqueeze(-1)
+            if ops.head_dot_supported(feat_src):  # one pass over feat instead of product + last-dim reduction
+                if feat_dst is feat_src:
+                    el, er = ops.head_dot(feat_src, self.attn_l, self.attn_r)
+                else:
+                    el, er = ops.head_dot(feat_src, self.attn_l), ops.head_dot(feat_dst, self.attn_r)
+                el, er = el.unsqueeze(-1), er.unsqueeze(-1)
+            else:
+                el = (feat_src * self.attn_l).sum(dim=-1).unsqueeze(-1)
+                er = (feat_dst * self.attn_r).sum(dim=-1).unsqueeze(-1)
             # e and a are internal to the module: keep them in in-CSR (destination-major) edge order so that
             # u_add_v, edge_softmax and u_mul_e/sum stream them instead of gathering by edge id
             cidx, perm = graph._index.canonical()

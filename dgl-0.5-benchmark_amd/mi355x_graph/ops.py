@@ -242,6 +242,48 @@ def gat_attention(graph, el, er, negative_slope=0.2):
     return GATAttention.apply(_gidx(graph), el, er, negative_slope)
 
 
+class HeadDot(torch.autograd.Function):
+    """(out_a, out_b)[n, h] = <feat[n, h, :], attn_{a,b}[h, :]>: one pass over feat forward, one pass backward."""
+
+    @staticmethod
+    def forward(ctx, feat, attn_a, attn_b):
+        feat = feat.contiguous()
+        H, F = feat.shape[1], feat.shape[2]
+        a2 = attn_a.contiguous().view(H, F)
+        b2 = attn_b.contiguous().view(H, F) if attn_b is not None else None
+        out_a, out_b = sparse.backend_for(feat).head_dot_fwd(feat, a2, b2)
+        ctx.save_for_backward(feat, a2, b2)
+        ctx.attn_shape = attn_a.shape
+        if out_b is None:  # autograd Functions return tensors only: an empty placeholder that carries no gradient
+            out_b = feat.new_empty(0)
+            ctx.mark_non_differentiable(out_b)
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, d_a, d_b):
+        feat, a2, b2 = ctx.saved_tensors
+        if d_a is None:
+            d_a = torch.zeros(feat.shape[:2], dtype=feat.dtype, device=feat.device)
+        if b2 is not None and d_b is None:
+            d_b = torch.zeros(feat.shape[:2], dtype=feat.dtype, device=feat.device)
+        d_feat, g_a, g_b = sparse.backend_for(feat).head_dot_bwd(
+            feat, a2, b2, d_a.contiguous(), d_b.contiguous() if b2 is not None else None, ctx.needs_input_grad[0])
+        return d_feat, g_a.view(ctx.attn_shape), (g_b.view(ctx.attn_shape) if g_b is not None else None)
+
+
+def head_dot_supported(feat):
+    return feat.dim() == 3 and feat.dtype == torch.float32 and sparse.backend_for(feat).head_dot_supported(
+        int(feat.shape[1]), int(feat.shape[2]))
+
+
+def head_dot(feat, attn_a, attn_b=None):
+    """GATConv's `(feat * attn).sum(-1)`: feat (n, H, F), attn (1, H, F) -> (n, H); with attn_b both terms in one pass."""
+    if feat.dtype != torch.float32:
+        raise DGLError("head_dot expects float32 features")
+    out_a, out_b = HeadDot.apply(feat, attn_a, attn_b)
+    return out_a if attn_b is None else (out_a, out_b)
+
+
 class SegmentReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, op, x, offsets):

@@ -295,6 +295,33 @@ class HipBackend(object):
         return de
 
     @staticmethod
+    def head_dot_supported(H, F):
+        return H * F <= 256 and (F <= 64 or F in (128, 256))
+
+    def head_dot_fwd(self, feat3d, attn_a, attn_b):
+        """feat3d [n, H, F], attn_a/attn_b [H, F] (attn_b may be None) -> (out_a [n, H], out_b [n, H] | None)."""
+        dev = self._check_dev(feat3d, attn_a, attn_b)
+        n, H, F = feat3d.shape
+        out_a = torch.empty((n, H), dtype=torch.float32, device=dev)
+        out_b = torch.empty((n, H), dtype=torch.float32, device=dev) if attn_b is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_head_dot_fwd(n, H, F, _ptr(feat3d), _ptr(attn_a), _ptr(attn_b), _ptr(out_a), _ptr(out_b),
+                                                   _stream(dev)))
+        return out_a, out_b
+
+    def head_dot_bwd(self, feat3d, attn_a, attn_b, d_a, d_b, need_feat_grad):
+        dev = self._check_dev(feat3d, attn_a, attn_b, d_a, d_b)
+        n, H, F = feat3d.shape
+        d_feat = torch.empty_like(feat3d) if need_feat_grad else None
+        g_a = torch.empty_like(attn_a)
+        g_b = torch.empty_like(attn_b) if attn_b is not None else None
+        ws = torch.empty(_lib.lib().mgx_head_dot_bwd_workspace(H, F) // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_head_dot_bwd(n, H, F, _ptr(feat3d), _ptr(attn_a), _ptr(attn_b), _ptr(d_a), _ptr(d_b),
+                                                   _ptr(d_feat), _ptr(g_a), _ptr(g_b), _ptr(ws), _stream(dev)))
+        return d_feat, g_a, g_b
+
+    @staticmethod
     def _softmax_plan(csr, H, dev):
         plan = csr.plan()
         if plan is None:

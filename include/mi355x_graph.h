@@ -197,6 +197,19 @@ int32_t mgx_gat_attention_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* m
                               const float* el, const float* er, float negative_slope,
                               const float* a, const float* da, float* de, float* ws, void* stream);
 
+/* ------------------------------------------------------------------ GAT attention terms
+ * el[n,h] = sum_f feat[n,h,f] * attn[h,f] -- GATConv's `(feat * attn_l).sum(-1)` (main_dgl_reddit_gat.py:10, UPSTREAM
+ * dgl.nn.pytorch.GATConv.forward), one pass; attn_b/out_b (may be NULL) apply a second attention vector to the same
+ * feat in that pass (full-graph GAT: el and er share feat).  Needs H*F <= 256 and F <= 64 or F in {128, 256}
+ * (else MGX_ERR_UNSUPPORTED).  Backward: d_feat = d_out_a*attn_a (+ d_out_b*attn_b) written once (d_feat may be NULL),
+ * d_attn = column sums of d_out*feat, two-stage in fixed order; workspace of mgx_head_dot_bwd_workspace(H, F) bytes. */
+int32_t mgx_head_dot_fwd(int64_t n, int64_t H, int64_t F, const float* feat, const float* attn_a,
+                         const float* attn_b, float* out_a, float* out_b, void* stream);
+int64_t mgx_head_dot_bwd_workspace(int64_t H, int64_t F);
+int32_t mgx_head_dot_bwd(int64_t n, int64_t H, int64_t F, const float* feat, const float* attn_a,
+                         const float* attn_b, const float* d_out_a, const float* d_out_b, float* d_feat,
+                         float* d_attn_a, float* d_attn_b, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------ segment reduce
  * Replaces dgl.nn.AvgPooling / dgl.ops.segment_reduce (main_dgl_molhiv_gcn.py:75,93).
  * offsets: int64 [num_segments+1] (cumsum of batch_num_nodes).  reduce: SUM, MEAN, MAX, MIN.

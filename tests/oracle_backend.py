@@ -110,6 +110,25 @@ class OracleBackend(object):
         dz = self.edge_softmax_bwd(csr, a2d, da2d)
         return dz * torch.where(t > 0, torch.ones_like(t), torch.full_like(t, slope))
 
+    @staticmethod
+    def head_dot_supported(H, F):
+        return True
+
+    def head_dot_fwd(self, feat3d, attn_a, attn_b):
+        out_a = (feat3d.double() * attn_a.double()).sum(-1).float()
+        out_b = (feat3d.double() * attn_b.double()).sum(-1).float() if attn_b is not None else None
+        return out_a, out_b
+
+    def head_dot_bwd(self, feat3d, attn_a, attn_b, d_a, d_b, need_feat_grad):
+        x = feat3d.double()
+        d_feat = d_a.double().unsqueeze(-1) * attn_a.double()
+        g_a = (d_a.double().unsqueeze(-1) * x).sum(0).float()
+        g_b = None
+        if attn_b is not None:
+            d_feat = d_feat + d_b.double().unsqueeze(-1) * attn_b.double()
+            g_b = (d_b.double().unsqueeze(-1) * x).sum(0).float()
+        return (d_feat.float() if need_feat_grad else None), g_a, g_b
+
     def segment_reduce(self, offsets, x2d, reduce, want_arg):
         return torch.from_numpy(orc.segment_reduce(_np(offsets), _np(x2d), reduce)), None
 

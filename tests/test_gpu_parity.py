@@ -465,3 +465,39 @@ def test_fused_gat_attention_matches_composition(oracle, H, canonical):
         z = np.where(z > 0, z, 0.2 * z).astype(np.float32)
         ref = oracle.edge_softmax_fwd(ip, ei, z.reshape(nnz, H))
         assert rel(a_f.detach().cpu().view(nnz, H), ref) < RTOL
+
+
+@pytest.mark.parametrize("n,H,F", [(1, 1, 4), (777, 1, 16), (5000, 8, 16), (3001, 4, 32), (2000, 2, 128), (300, 1, 256), (64, 8, 4), (4000, 1, 41), (500, 3, 7), (100, 200, 1)])
+@pytest.mark.parametrize("both", [False, True])
+def test_head_dot_matches_fp64(n, H, F, both):
+    """mgx_head_dot_fwd/bwd == (feat * attn).sum(-1) and its autograd (fp64 reference), one or two attention vectors."""
+    rng = np.random.default_rng(n + H + F)
+    x0 = T(rng.standard_normal((n, H, F)).astype(np.float32))
+    a0 = T(rng.standard_normal((1, H, F)).astype(np.float32))
+    b0 = T(rng.standard_normal((1, H, F)).astype(np.float32))
+    wa, wb = torch.rand(n, H, device=DEV), torch.rand(n, H, device=DEV)
+    x1, a1, b1 = (t.clone().requires_grad_(True) for t in (x0, a0, b0))
+    x2, a2, b2 = (t.double().clone().requires_grad_(True) for t in (x0, a0, b0))
+    assert ops.head_dot_supported(x1)
+    if both:
+        el, er = ops.head_dot(x1, a1, b1)
+        ((el * wa).sum() + (er * wb).sum()).backward()
+        rl, rr = (x2 * a2).sum(-1), (x2 * b2).sum(-1)
+        ((rl * wa.double()).sum() + (rr * wb.double()).sum()).backward()
+        pairs = [(el, rl), (er, rr), (x1.grad, x2.grad), (a1.grad, a2.grad), (b1.grad, b2.grad)]
+    else:
+        el = ops.head_dot(x1, a1)
+        (el * wa).sum().backward()
+        rl = (x2 * a2).sum(-1)
+        (rl * wa.double()).sum().backward()
+        pairs = [(el, rl), (x1.grad, x2.grad), (a1.grad, a2.grad)]
+    for got, ref in pairs:
+        assert got.shape == ref.shape
+        assert float((got.double() - ref).abs().max() / ref.abs().max().clamp(min=1e-12)) < 1e-5
+
+
+def test_head_dot_rejects_unsupported_shapes():
+    x = torch.zeros(10, 1, 100, device=DEV)
+    assert not ops.head_dot_supported(x)
+    with pytest.raises(mg.DGLError, match="mgx_head_dot"):
+        ops.head_dot(x, torch.zeros(1, 1, 100, device=DEV))
