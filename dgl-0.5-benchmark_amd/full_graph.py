@@ -23,7 +23,7 @@ import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dgl  # noqa: E402
 import dgl.function as fn  # noqa: E402
-from dgl.nn.pytorch import GATConv  # noqa: E402
+from dgl.nn.pytorch import GATConv, Linear  # noqa: E402
 from dgl.utils import expand_as_pair  # noqa: E402
 
 
@@ -34,8 +34,8 @@ class SAGEConv(nn.Module):
     def __init__(self, in_feats, out_feats, self_bias=False, neigh_bias=True):
         super(SAGEConv, self).__init__()
         self._in_src_feats, self._in_dst_feats = expand_as_pair(in_feats)
-        self.fc_self = nn.Linear(self._in_dst_feats, out_feats, bias=self_bias)
-        self.fc_neigh = nn.Linear(self._in_src_feats, out_feats, bias=neigh_bias)
+        self.fc_self = Linear(self._in_dst_feats, out_feats, bias=self_bias)
+        self.fc_neigh = Linear(self._in_src_feats, out_feats, bias=neigh_bias)
         self.reset_parameters()
 
     def reset_parameters(self):

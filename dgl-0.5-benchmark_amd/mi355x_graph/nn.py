@@ -16,6 +16,13 @@ from . import ops
 from .utils import expand_as_pair
 
 
+class Linear(nn.Linear):
+    """torch.nn.Linear (same parameters, init and state_dict) whose bias gradient runs in the library's column-sum kernel."""
+
+    def forward(self, input):
+        return ops.linear(input, self.weight, self.bias)
+
+
 class Identity(nn.Module):
     def forward(self, x):
         return x
@@ -117,7 +124,7 @@ class GATConv(nn.Module):
                 resval = self.res_fc(h_dst).view(h_dst.shape[0], -1, self._out_feats)
                 rst = rst + resval
             if self.bias is not None:
-                rst = rst + self.bias.view(1, self._num_heads, self._out_feats)
+                rst = ops.bias_add(rst, self.bias)
             if self.activation:
                 rst = self.activation(rst)
             if get_attention:
@@ -141,10 +148,10 @@ class SAGEConv(nn.Module):
         self.feat_drop = nn.Dropout(feat_drop)
         self.activation = activation
         if aggregator_type == "pool":
-            self.fc_pool = nn.Linear(self._in_src_feats, self._in_src_feats)
+            self.fc_pool = Linear(self._in_src_feats, self._in_src_feats)
         if aggregator_type != "gcn":
-            self.fc_self = nn.Linear(self._in_dst_feats, out_feats, bias=bias)
-        self.fc_neigh = nn.Linear(self._in_src_feats, out_feats, bias=bias)
+            self.fc_self = Linear(self._in_dst_feats, out_feats, bias=bias)
+        self.fc_neigh = Linear(self._in_src_feats, out_feats, bias=bias)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -255,7 +262,7 @@ class GraphConv(nn.Module):
                 norm = torch.pow(degs, -0.5) if self._norm == "both" else 1.0 / degs
                 rst = rst * norm.view((-1,) + (1,) * (feat_dst.dim() - 1))
             if self.bias is not None:
-                rst = rst + self.bias
+                rst = ops.bias_add(rst, self.bias)
             if self._activation is not None:
                 rst = self._activation(rst)
             return rst

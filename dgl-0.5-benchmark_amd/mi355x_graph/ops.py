@@ -284,6 +284,63 @@ def head_dot(feat, attn_a, attn_b=None):
     return out_a if attn_b is None else (out_a, out_b)
 
 
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b with the library's GEMMs; the bias gradient (column sum of dY over all N rows) runs in
+    mgx_column_sum -- PyTorch's generic reduction needs 19 ms for a [2.4M, 47] column sum on MI355X, 40 % of a products epoch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ weight).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = dy2.t() @ x.reshape(-1, x.shape[-1])
+        if ctx.needs_input_grad[2]:
+            db = sparse.backend_for(dy2).column_sum(dy2.contiguous())
+        return dx, dw, db
+
+
+class BiasAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias):
+        ctx.bias_shape = bias.shape
+        return x + bias
+
+    @staticmethod
+    def backward(ctx, dy):
+        db = None
+        if ctx.needs_input_grad[1]:
+            C = 1
+            for d in ctx.bias_shape:
+                C *= int(d)
+            db = sparse.backend_for(dy).column_sum(dy.contiguous().view(-1, C)).view(ctx.bias_shape)
+        return dy, db
+
+
+def bias_add(x, bias):
+    """x + bias (bias broadcast over the leading dimension of x) with the bias gradient computed by mgx_column_sum."""
+    C = bias.numel()
+    if (not bias.requires_grad or x.dtype != torch.float32 or x.device.type not in sparse._BACKENDS or x.dim() < 2
+            or x[0].numel() != C or C > sparse.backend_for(x).COLUMN_SUM_MAX):
+        return x + bias
+    return BiasAdd.apply(x, bias.view((1,) + tuple(x.shape[1:])))
+
+
+def linear(x, weight, bias=None):
+    """torch.nn.functional.linear whose bias gradient is computed by the library (float32 HIP tensors, <= 256 outputs)."""
+    if (bias is None or not bias.requires_grad or x.dtype != torch.float32 or x.device.type not in sparse._BACKENDS
+            or weight.shape[0] > sparse.backend_for(x).COLUMN_SUM_MAX):
+        return torch.nn.functional.linear(x, weight, bias)
+    return LinearFn.apply(x, weight, bias)
+
+
 class SegmentReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, op, x, offsets):

@@ -349,6 +349,17 @@ class HipBackend(object):
             _lib.check(_lib.lib().mgx_segment_reduce(n, _ptr(offsets), x2d.shape[1], REDUCE[reduce], _ptr(x2d), _ptr(out), _ptr(arg), _stream(dev)))
         return out, arg
 
+    COLUMN_SUM_MAX = 256
+
+    def column_sum(self, x2d):
+        dev = self._check_dev(x2d)
+        n, C = x2d.shape
+        out = torch.empty(C, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.lib().mgx_column_sum_workspace(C) // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_column_sum(n, C, _ptr(x2d), _ptr(out), _ptr(ws), _stream(dev)))
+        return out
+
     def sample_neighbors(self, csr, seeds, fanout, rng_seed):
         """seeds: graph-idtype tensor on the device.  Returns (src, eid, counts) with the picks of seed i at
         [offsets[i], offsets[i+1])."""

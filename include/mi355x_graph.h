@@ -217,6 +217,13 @@ int32_t mgx_head_dot_bwd(int64_t n, int64_t H, int64_t F, const float* feat, con
 int32_t mgx_segment_reduce(int64_t num_segments, const int64_t* offsets, int64_t D, int32_t reduce,
                            const float* x, float* out, int64_t* arg, void* stream);
 
+/* Column sum out[c] = sum_r x[r, c] of a row-major [n, C] matrix, C <= 256: the single-segment case of the readout
+ * above (a segment of millions of rows has no row parallelism), used for the bias gradient of the dense layer that
+ * follows every aggregation (`nn.Linear` in SAGEConv, main_dgl_product_sage.py:31-33).  Two stages in fixed order
+ * (deterministic); workspace of mgx_column_sum_workspace(C) bytes. */
+int64_t mgx_column_sum_workspace(int64_t C);
+int32_t mgx_column_sum(int64_t n, int64_t C, const float* x, float* out, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------ formats (integer, bit-exact)
  * Replace the lazy COO->CSR/CSC construction behind g.formats(...)/first kernel call
  * (main_dgl_product_sage.py:158, kernel/dgl-new.py:63) and g.in_degrees()

@@ -129,6 +129,11 @@ class OracleBackend(object):
             g_b = (d_b.double().unsqueeze(-1) * x).sum(0).float()
         return (d_feat.float() if need_feat_grad else None), g_a, g_b
 
+    COLUMN_SUM_MAX = 256
+
+    def column_sum(self, x2d):
+        return x2d.double().sum(0).float()
+
     def segment_reduce(self, offsets, x2d, reduce, want_arg):
         return torch.from_numpy(orc.segment_reduce(_np(offsets), _np(x2d), reduce)), None
 

@@ -501,3 +501,34 @@ def test_head_dot_rejects_unsupported_shapes():
     assert not ops.head_dot_supported(x)
     with pytest.raises(mg.DGLError, match="mgx_head_dot"):
         ops.head_dot(x, torch.zeros(1, 1, 100, device=DEV))
+
+
+@pytest.mark.parametrize("n,C", [(0, 5), (1, 1), (1000, 47), (100003, 47), (70001, 64), (5000, 256), (3, 200), (40000, 7)])
+def test_column_sum_and_linear_bias_grad(n, C):
+    """mgx_column_sum == x.sum(0) (fp64 reference); nn.Linear / bias_add built on it give autograd's gradients."""
+    rng = np.random.default_rng(n + C)
+    x = T(rng.standard_normal((n, C)).astype(np.float32))
+    got = sparse.backend_for(x).column_sum(x)
+    ref = x.double().sum(0)
+    assert got.shape == (C,)
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(x.abs().sum(0).max())) if n else float(got.abs().max()) == 0
+    if n == 0:
+        return
+    from mi355x_graph.nn import Linear
+    lin = Linear(13, C).to(DEV)
+    ref_lin = torch.nn.Linear(13, C).to(DEV)
+    ref_lin.load_state_dict(lin.state_dict())
+    inp = torch.rand(n, 13, device=DEV)
+    i1, i2 = inp.clone().requires_grad_(True), inp.clone().requires_grad_(True)
+    w = torch.rand(n, C, device=DEV)
+    y1, y2 = lin(i1), ref_lin(i2)
+    assert torch.equal(y1, y2)
+    (y1 * w).sum().backward()
+    (y2 * w).sum().backward()
+    for a, b in ((i1.grad, i2.grad), (lin.weight.grad, ref_lin.weight.grad), (lin.bias.grad, ref_lin.bias.grad)):
+        assert float((a - b).abs().max() / b.abs().max().clamp(min=1e-12)) < 1e-4
+    b1 = torch.zeros(C, device=DEV, requires_grad=True)
+    b2 = torch.zeros(C, device=DEV, requires_grad=True)
+    (ops.bias_add(x, b1) * w).sum().backward()
+    ((x + b2) * w).sum().backward()
+    assert float((b1.grad - b2.grad).abs().max() / b2.grad.abs().max().clamp(min=1e-12)) < 1e-4
