@@ -17,6 +17,7 @@ the P-way run computes the same mean loss as the 1-GPU run (main_dgl_product_sag
 """
 import torch
 import torch.distributed as dist
+import torch.nn as nn
 
 from ._lib import DGLError
 from . import core, schedule, sparse
@@ -473,3 +474,89 @@ def allreduce_gradients(model, group=None):
 def broadcast_parameters(model, src=0, group=None):
     for p in list(model.parameters()) + list(model.buffers()):
         broadcast(p.data, src, group=group)
+
+
+# ----------------------------------------------------------------------------- BatchNorm over a partitioned node set
+class _GlobalBatchNormFn(torch.autograd.Function):
+    """Training-mode batch normalisation whose statistics span every rank's rows (the arxiv model's
+    BatchNorm1d, main_dgl_arxiv_sage.py:70-77, must see the whole node set).  One all_reduce of
+    [sum, sum of squares, count] forward, one of [sum dy, sum dy*xhat] backward -- 2C+1 floats each."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        C = x.shape[1]
+        stats = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        xd = x.double()
+        stats[:C] = xd.sum(0)
+        stats[C:2 * C] = (xd * xd).sum(0)
+        stats[2 * C] = x.shape[0]
+        all_reduce(stats, group=group)
+        n = stats[2 * C]
+        mean = stats[:C] / n
+        var = (stats[C:2 * C] / n - mean * mean).clamp(min=0.0)  # biased, as BatchNorm normalises with
+        invstd = torch.rsqrt(var + eps)
+        xhat = ((xd - mean) * invstd).to(x.dtype)
+        ctx.save_for_backward(xhat, weight, invstd.to(x.dtype))
+        ctx.group, ctx.count = group, n
+        y = xhat * weight + bias if weight is not None else xhat
+        ctx.mark_non_differentiable(mean, var, n)
+        return y, mean, var, n
+
+    @staticmethod
+    def backward(ctx, dy, _dm, _dv, _dn):
+        xhat, weight, invstd = ctx.saved_tensors
+        C = dy.shape[1]
+        red = torch.empty(2 * C, dtype=torch.float64, device=dy.device)
+        dyd = dy.double()
+        red[:C] = dyd.sum(0)
+        red[C:] = (dyd * xhat.double()).sum(0)
+        all_reduce(red, group=ctx.group)
+        sum_dy, sum_dy_xhat = red[:C], red[C:]
+        g = weight.double() * invstd.double() if weight is not None else invstd.double()
+        dx = (g * (dyd - sum_dy / ctx.count - xhat.double() * (sum_dy_xhat / ctx.count))).to(dy.dtype)
+        dw = db = None
+        if weight is not None:
+            # LOCAL contributions: the caller's gradient all_reduce (allreduce_gradients) sums them over ranks
+            dw = (dyd * xhat.double()).sum(0).to(weight.dtype)
+            db = dyd.sum(0).to(weight.dtype)
+        return dx, dw, db, None, None
+
+
+class GlobalBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d over rows that are partitioned across ranks: same parameters, buffers and state_dict;
+    training-mode statistics (and the running estimates) are those of the union of all ranks' rows."""
+
+    def __init__(self, *args, **kwargs):
+        self.process_group = kwargs.pop("process_group", None)
+        super(GlobalBatchNorm1d, self).__init__(*args, **kwargs)
+
+    def forward(self, x):
+        use_batch = self.training or not self.track_running_stats
+        if not use_batch or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.process_group) == 1:
+            return super(GlobalBatchNorm1d, self).forward(x)
+        if x.dim() != 2:
+            raise DGLError("GlobalBatchNorm1d expects (rows, channels) input")
+        y, mean, var, n = _GlobalBatchNormFn.apply(x, self.weight, self.bias, self.eps, self.process_group)
+        if self.training and self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                unbiased = var * (n / (n - 1).clamp(min=1.0))
+                self.running_mean.mul_(1 - m).add_(mean.to(self.running_mean.dtype), alpha=m)
+                self.running_var.mul_(1 - m).add_(unbiased.to(self.running_var.dtype), alpha=m)
+        return y
+
+
+def convert_batchnorm(module, process_group=None):
+    """Replaces every nn.BatchNorm1d under `module` by a GlobalBatchNorm1d carrying the same state (the counterpart
+    of nn.SyncBatchNorm.convert_sync_batchnorm for node sets that are partitioned, not replicated)."""
+    out = module
+    if isinstance(module, nn.BatchNorm1d) and not isinstance(module, GlobalBatchNorm1d):
+        out = GlobalBatchNorm1d(module.num_features, module.eps, module.momentum, module.affine,
+                                module.track_running_stats, process_group=process_group)
+        out.load_state_dict(module.state_dict())
+        out.to(next(iter(module.state_dict().values())).device if module.state_dict() else "cpu")
+        out.train(module.training)
+    for name, child in module.named_children():
+        out.add_module(name, convert_batchnorm(child, process_group))
+    return out

@@ -29,22 +29,23 @@ def make_problem():
     return n, src, dst, feats, labels, train
 
 
-def build_model():
+def build_model(batch_norm=False):
     sys.path.insert(0, PKG)
     import full_graph
     torch.manual_seed(1)
-    return full_graph.GraphSAGE(12, 8, 5, 3, dropout=0.0)
+    return full_graph.GraphSAGE(12, 8, 5, 3, dropout=0.0, batch_norm=batch_norm)
 
 
-def single_process_reference(device="cpu"):
+def single_process_reference(device="cpu", batch_norm=False):
     import torch.nn.functional as F
     n, src, dst, feats, labels, train = [t.to(device) if isinstance(t, torch.Tensor) else t for t in make_problem()]
     g = mg.graph((src, dst), num_nodes=n).int()
-    model = build_model().to(device)
+    model = build_model(batch_norm).to(device)
     out = model(g, feats)
     loss = F.nll_loss(out[train], labels[train])
     loss.backward()
-    return out.detach().cpu(), loss.item(), [p.grad.cpu().clone() for p in model.parameters()], generic_path(g, feats).cpu()
+    return (out.detach().cpu(), loss.item(), [p.grad.cpu().clone() for p in model.parameters()], generic_path(g, feats).cpu(),
+            [b.cpu().clone() for b in model.buffers()])
 
 
 def generic_path(g, x):
@@ -59,7 +60,7 @@ def generic_path(g, x):
     return g.ndata["o"]
 
 
-def _worker(rank, world, port, q, device="cpu"):
+def _worker(rank, world, port, q, device="cpu", batch_norm=False):
     import torch.nn.functional as F
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -69,7 +70,9 @@ def _worker(rank, world, port, q, device="cpu"):
     assign, stats = mdist.partition_nodes(src, dst, n, world)
     block, plan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
     g = mdist.DistGraph(block, plan)
-    model = build_model().to(device)
+    model = build_model(batch_norm).to(device)
+    if batch_norm:  # statistics over the union of both ranks' rows
+        model = mdist.convert_batchnorm(model)
     if device == "cpu":
         mdist.broadcast_parameters(model)  # same seed => same init; exercised on the CPU run only
     x, y, m = feats[own], labels[own], train[own]
@@ -85,22 +88,23 @@ def _worker(rank, world, port, q, device="cpu"):
     dist.all_reduce(lsum)
     q.put((rank, own.cpu().numpy(), out.detach().cpu().numpy(), float(lsum),
            [p.grad.cpu().numpy() for p in model.parameters()], stats, plan.n_halo, sum(plan.send_splits),
-           generic_path(g, x).cpu().numpy()))
+           generic_path(g, x).cpu().numpy(), [b.cpu().numpy() for b in model.buffers()]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run_two_way(device):
+def _run_two_way(device, batch_norm=False):
     if device == "cpu":
         oracle_backend.install()
     try:
-        ref_out, ref_loss, ref_grads, ref_generic = single_process_reference(device)
+        ref_out, ref_loss, ref_grads, ref_generic, ref_buffers = single_process_reference(device, batch_norm)
     finally:
         oracle_backend.uninstall()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000 + (7 if device != "cpu" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, device)) for r in range(2)]
+    port += 11 if batch_norm else 0
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, device, batch_norm)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(2)]
@@ -110,7 +114,10 @@ def _run_two_way(device):
     got = torch.zeros_like(ref_out)
     got_generic = torch.zeros_like(ref_generic)
     seen = np.zeros(ref_out.shape[0], bool)
-    for rank, own, out, lsum, grads, stats, n_halo, n_send, gen in res:
+    for rank, own, out, lsum, grads, stats, n_halo, n_send, gen, buffers in res:
+        assert len(buffers) == len(ref_buffers) and (len(buffers) > 0) == batch_norm
+        for b, r in zip(buffers, ref_buffers):  # running_mean / running_var / num_batches_tracked
+            assert np.allclose(b, r.numpy(), rtol=1e-4, atol=1e-6)
         got[own] = torch.from_numpy(out)
         got_generic[own] = torch.from_numpy(gen)
         assert not seen[own].any()
@@ -127,6 +134,13 @@ def _run_two_way(device):
 @pytest.mark.timeout(300)
 def test_two_way_partition_matches_single_process():
     _run_two_way("cpu")
+
+
+@pytest.mark.timeout(300)
+def test_two_way_partition_with_batchnorm_matches_single_process():
+    """arxiv-style model (BatchNorm1d between layers): GlobalBatchNorm1d reproduces the 1-process statistics,
+    outputs, gradients and running estimates."""
+    _run_two_way("cpu", batch_norm=True)
 
 
 @pytest.mark.gpu
