@@ -16,9 +16,19 @@ import os
 import sys
 import time
 
-import torch
-import torch.nn as nn
-import torch.nn.functional as F
+# GEMM selections recorded once on MI355X for the dense layers of the products model (experiments/tune_dense.py) are
+# loaded, never tuned, here -- hipBLASLt's default heuristics pick 3 ms kernels for the K = 2.45 M weight-gradient
+# shapes.  Other shapes fall through to the default.  MGX_BENCH_TUNABLEOP=0 turns it off (same switch as bench.py).
+if os.environ.get("MGX_BENCH_TUNABLEOP", "1") == "1":
+    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_RECORD_UNTUNED", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME",
+                          os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_products.csv"))
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dgl  # noqa: E402
@@ -136,6 +146,8 @@ SAGE_CONFIGS = {
                   bidirect=True, neigh_bias=False),      # main_dgl_arxiv_sage.py:141-148,162
     "cora": dict(dataset="cora", num_layers=2, hidden=16, dropout=0.5, lr=0.01, batch_norm=False,
                  bidirect=False, neigh_bias=True),       # main_dgl_citation_sage.py:100-101,139
+    "pubmed": dict(dataset="pubmed", num_layers=2, hidden=16, dropout=0.5, lr=0.01, batch_norm=False,
+                   bidirect=False, neigh_bias=True),
     "reddit": dict(dataset="reddit-small", num_layers=2, hidden=16, dropout=0.5, lr=0.01, batch_norm=False,
                    bidirect=False, neigh_bias=True),
 }

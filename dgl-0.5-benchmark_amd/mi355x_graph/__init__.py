@@ -6,6 +6,7 @@ through the C ABI of include/mi355x_graph.h.
 """
 from ._lib import DGLError, LIB_PATH  # noqa: F401
 from . import function, ops, sparse  # noqa: F401
-from .graph import DGLGraph, DGLHeteroGraph, GraphIndex, graph, create_block, ALL  # noqa: F401
+from .graph import DGLGraph, GraphIndex, graph, create_block, ALL  # noqa: F401
+from .heterograph import DGLHeteroGraph, heterograph, bipartite, hetero_from_relations  # noqa: F401
 
 __version__ = "0.1.0"

@@ -121,3 +121,48 @@ def find_dataset(name):
         if os.path.exists(folder + ".npz"):
             return load_npz(folder + ".npz")
     return None
+
+
+# ----------------------------------------------------------------------------- dgl.data.utils file helpers
+def get_download_dir():
+    """dgl.data.utils.get_download_dir (gcmc_dgl/data.py:19): $DGL_DOWNLOAD_DIR, else $MGX_DATA_ROOT, else ~/.dgl."""
+    d = os.environ.get("DGL_DOWNLOAD_DIR") or os.environ.get("MGX_DATA_ROOT") or os.path.join(os.path.expanduser("~"), ".dgl")
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def download(url, path=None, overwrite=False, sha1_hash=None, retries=5, verify_ssl=True, log=True):
+    """dgl.data.utils.download.  The GPU boxes have no network: an archive (or its extracted directory) that is already in
+    place is accepted, anything else is an error that says where to put the file."""
+    fname = path if path is not None else url.split("/")[-1]
+    if os.path.isdir(fname):
+        fname = os.path.join(fname, url.split("/")[-1])
+    extracted = fname[:-4] if fname.endswith(".zip") else fname
+    if os.path.exists(fname) or os.path.isdir(extracted):
+        return fname
+    raise IOError("cannot download %s: no network on this machine; place the archive at %s or its extracted contents at %s"
+                  % (url, fname, extracted))
+
+
+def extract_archive(file, target_dir, overwrite=False):
+    """dgl.data.utils.extract_archive: .zip / .tar(.gz) / .gz; a target directory that already holds files is kept."""
+    if os.path.isdir(target_dir) and os.listdir(target_dir) and not overwrite:
+        return
+    if not os.path.exists(file):
+        raise IOError("archive %s not found and %s is empty" % (file, target_dir))
+    os.makedirs(target_dir, exist_ok=True)
+    if file.endswith(".zip"):
+        import zipfile
+        with zipfile.ZipFile(file) as z:
+            z.extractall(target_dir)
+    elif file.endswith((".tar.gz", ".tgz", ".tar")):
+        import tarfile
+        with tarfile.open(file) as t:
+            t.extractall(target_dir)
+    elif file.endswith(".gz"):
+        import gzip
+        import shutil
+        with gzip.open(file, "rb") as src, open(os.path.join(target_dir, os.path.basename(file)[:-3]), "wb") as dst:
+            shutil.copyfileobj(src, dst)
+    else:
+        raise IOError("Unrecognized file type: " + file)

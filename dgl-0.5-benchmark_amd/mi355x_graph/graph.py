@@ -260,11 +260,12 @@ class DGLGraph(object):
         self._edge_frame = edge_frame if edge_frame is not None else Frame(index.num_edges(), kind="edge")
         self._batch_num_nodes = None
         self._batch_num_edges = None
+        self._unibipartite = False  # relation view of a heterograph: two node sets, not a message-flow block
 
     # -- structure queries
     @property
     def is_block(self):
-        return self._is_block
+        return self._is_block and not getattr(self, "_unibipartite", False)
 
     @property
     def idtype(self):
@@ -276,6 +277,11 @@ class DGLGraph(object):
 
     def number_of_nodes(self, ntype=None):
         if self._is_block:
+            types = getattr(self, "_ntypes", None)
+            if ntype is not None and types is not None:
+                if ntype not in types:
+                    raise DGLError('Node type "%s" does not exist.' % ntype)
+                return self._index.num_src if ntype == types[0] else self._index.num_dst
             return self._index.num_src + self._index.num_dst
         return self._index.num_src
 
@@ -336,7 +342,7 @@ class DGLGraph(object):
     @property
     def ndata(self):
         if self._is_block:
-            raise DGLError("ndata is ambiguous on a block; use srcdata/dstdata")
+            raise DGLError("ndata is ambiguous on a graph with two node sets; use srcdata/dstdata")
         return self._src_frame
 
     @property
@@ -363,6 +369,7 @@ class DGLGraph(object):
             g._src_frame, g._dst_frame, g._edge_frame = frames
         g._batch_num_nodes = self._batch_num_nodes
         g._batch_num_edges = self._batch_num_edges
+        g._unibipartite = getattr(self, "_unibipartite", False)
         return g
 
     def local_var(self):
@@ -474,8 +481,6 @@ class DGLGraph(object):
         return "Graph(num_nodes=%d, num_edges=%d,\n      ndata_schemes=%r\n      edata_schemes=%r)" % (
             self.number_of_nodes(), self.number_of_edges(), self._src_frame, self._edge_frame)
 
-
-DGLHeteroGraph = DGLGraph
 
 
 def _to_index_tensor(x, idtype):

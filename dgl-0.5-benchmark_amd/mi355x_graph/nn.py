@@ -268,6 +268,57 @@ class GraphConv(nn.Module):
             return rst
 
 
+def _hetero_aggregate(name):
+    if callable(name):
+        return name
+    if name == "stack":
+        return lambda xs, dsttype: torch.stack(xs, dim=1) if xs else None
+    fns = {"sum": lambda t: t.sum(0), "mean": lambda t: t.mean(0), "max": lambda t: t.max(0)[0], "min": lambda t: t.min(0)[0]}
+    if name not in fns:
+        raise DGLError('Invalid cross type aggregator. Must be one of "sum", "max", "min", "mean" or "stack". But got "%s"' % name)
+    return lambda xs, dsttype: fns[name](torch.stack(xs, dim=0)) if xs else None
+
+
+class HeteroGraphConv(nn.Module):
+    """dglnn.HeteroGraphConv (gcmc_dgl/model.py:205): one sub-module per relation, each run on the relation's own
+    graph view (its own in-CSR and execution plan), results combined per destination type by `aggregate`."""
+
+    def __init__(self, mods, aggregate="sum"):
+        super(HeteroGraphConv, self).__init__()
+        self.mods = nn.ModuleDict(mods)
+        for _, v in self.mods.items():  # isolated destinations are expected inside a single relation
+            set_allow = getattr(v, "set_allow_zero_in_degree", None)
+            if callable(set_allow):
+                set_allow(True)
+        self.agg_fn = _hetero_aggregate(aggregate)
+
+    def forward(self, g, inputs, mod_args=None, mod_kwargs=None):
+        mod_args = mod_args or {}
+        mod_kwargs = mod_kwargs or {}
+        outputs = {nty: [] for nty in g.dsttypes}
+        if isinstance(inputs, tuple):
+            src_inputs, dst_inputs = inputs
+        elif g.is_block:
+            src_inputs = inputs
+            dst_inputs = {k: v[:g.number_of_dst_nodes(k)] for k, v in inputs.items()}
+        else:
+            src_inputs = dst_inputs = inputs
+        for stype, etype, dtype in g.canonical_etypes:
+            rel_graph = g[stype, etype, dtype]
+            if rel_graph.number_of_edges() == 0:
+                continue
+            if stype not in src_inputs or dtype not in dst_inputs:
+                continue
+            dstdata = self.mods[etype](rel_graph, (src_inputs[stype], dst_inputs[dtype]), *mod_args.get(etype, ()),
+                                       **mod_kwargs.get(etype, {}))
+            outputs[dtype].append(dstdata)
+        rsts = {}
+        for nty, alist in outputs.items():
+            if len(alist) != 0:
+                rsts[nty] = self.agg_fn(alist, nty)
+        return rsts
+
+
 class _Pooling(nn.Module):
     _op = "sum"
 

@@ -221,7 +221,7 @@ def test_rccl_api_path_single_rank():
         loss = F.nll_loss(out[train], labels[train])
         loss.backward()
         mdist.allreduce_gradients(model)
-        ref_out, ref_loss, ref_grads, ref_gen = single_process_reference("cuda:0")
+        ref_out, ref_loss, ref_grads, ref_gen, _ = single_process_reference("cuda:0")
         assert torch.allclose(out.detach().cpu(), ref_out, rtol=1e-4, atol=1e-6)
         for p, r in zip(model.parameters(), ref_grads):
             assert torch.allclose(p.grad.cpu(), r, rtol=1e-4, atol=1e-6)

@@ -32,15 +32,22 @@ SCRIPTS = [
     ("node_classification/main_dgl_arxiv_sage_nn.py", ["--epochs", "5", "--runs", "1"]),
     ("node_classification/main_dgl_proteins_rgcn_for.py", ["--epochs", "4", "--runs", "1"]),
     ("graph_classification/main_dgl_molhiv_gcn.py", ["--epochs", "2", "--runs", "1", "--batch_size", "16", "--num_workers", "0"]),
+    ("node_classification/main_dgl_citation_sage_nn.py", ["--dataset", "cora", "--epochs", "5", "--runs", "1"]),
+    ("node_classification/main_dgl_reddit_gat.py", ["--epochs", "5", "--runs", "1"]),
+    ("node_classification/main_dgl_reddit_sage.py", ["--epochs", "5", "--runs", "1"]),
+    ("node_classification/main_dgl_reddit_sage_nn.py", ["--epochs", "5", "--runs", "1"]),
+    ("graph_classification/main_dgl_enzymes_gcn.py", ["--epochs", "2", "--runs", "1"]),
+    ("graph_classification/main_dgl_enzymes_gcn_nn.py", ["--epochs", "2", "--runs", "1"]),
+    ("graph_classification/main_dgl_ppa_gcn.py", ["--epochs", "2", "--runs", "1", "--num_workers", "0", "--emb_dim", "32"]),
 ]
 
 
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("script,args", SCRIPTS, ids=[s[0].split("/")[-1] + ("-" + s[1][-1].strip("-") if s[1][-1].startswith("--") else "") for s in SCRIPTS])
 def test_reference_script_runs_unmodified(script, args):
-    out = run(script, *args)
+    out = run(script, *args, MGX_DATASET_SCALE="0.01" if "reddit" in script else "1")
     times = re.findall(r"Training time/epoch ([0-9.eE+-]+)", out)
-    if "molhiv" not in script:
+    if "graph_classification" not in script:  # those scripts print only a tqdm loss line
         assert times, out[-1500:]
 
 
@@ -51,3 +58,40 @@ def test_neighbor_sampling_script_runs_unmodified():
     out = run("reddit/ns-sage-dgl.py", "--gpu", "-1", "--num-epochs", "7", "--num-workers", "0", "--eval-every", "5",
               "--batch-size", "256", root=REF_SAMPLING, MGX_DATASET_SCALE="0.01")
     assert "Avg epoch time" in out and "Test Acc" in out, out[-1500:]
+
+
+def _write_movielens_100k_like(root, n_user=60, n_movie=40, n_rating=900, seed=11):
+    """Files in the ml-100k layout (u.user, u.item, u1.base, u1.test) with synthetic content."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    d = os.path.join(root, "ml-100k", "ml-100k")
+    os.makedirs(d, exist_ok=True)
+    jobs = ["artist", "doctor", "engineer", "student", "writer"]
+    with open(os.path.join(d, "u.user"), "w") as f:
+        for u in range(1, n_user + 1):
+            f.write("%d|%d|%s|%s|%05d\n" % (u, rng.integers(18, 70), "MF"[rng.integers(0, 2)], jobs[rng.integers(0, 5)], rng.integers(0, 99999)))
+    with open(os.path.join(d, "u.item"), "w", encoding="latin-1") as f:
+        for m in range(1, n_movie + 1):
+            genres = "|".join(str(int(x)) for x in rng.integers(0, 2, 19))
+            f.write("%d|Movie %d (%d)|01-Jan-%d||http://example/%d|%s\n" % (m, m, 1990 + m % 9, 1990 + m % 9, m, genres))
+    pairs = set()
+    while len(pairs) < n_rating:
+        pairs.add((int(rng.integers(1, n_user + 1)), int(rng.integers(1, n_movie + 1))))
+    pairs = sorted(pairs)
+    rows = ["%d\t%d\t%d\t%d\n" % (u, m, rng.integers(1, 6), 880000000 + i) for i, (u, m) in enumerate(pairs)]
+    cut = int(0.8 * len(rows))
+    with open(os.path.join(d, "u1.base"), "w") as f:
+        f.writelines(rows[:cut])
+    with open(os.path.join(d, "u1.test"), "w") as f:
+        f.writelines(rows[cut:])
+
+
+@pytest.mark.timeout(900)
+def test_gcmc_script_runs_unmodified(tmp_path):
+    """gcmc_dgl/train.py (dgl.bipartite + hetero_from_relations, graph[etype], nodes[ntype].data,
+    dglnn.HeteroGraphConv over 2 x 5 rating relations, u_dot_v decoder) on an ml-100k-shaped stand-in."""
+    _write_movielens_100k_like(str(tmp_path))
+    out = run("link_prediction/gcmc_dgl/train.py", "--data_name", "ml-100k", "--use_one_hot_fea", "--gcn_agg_accum", "stack",
+              "--train_max_iter", "8", "--gcn_agg_units", "50", "--gcn_out_units", "10", "--save_dir", str(tmp_path / "log"),
+              "--device", "-1", DGL_DOWNLOAD_DIR=str(tmp_path))
+    assert "Best Iter Idx" in out and "Val RMSE" in out, out[-1500:]
