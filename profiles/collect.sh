@@ -10,6 +10,7 @@ O=$R/gpurun_out
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_bench_trace -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_trace.log 2>&1
+python $R/experiments/epoch_timeline.py $O/${TAG}_bench_trace > $O/${TAG}_epoch_timeline.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_bench_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_bench_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/${TAG}_bench_l2 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_l2.log 2>&1
