@@ -15,6 +15,8 @@ OWNED nodes) so the model classes of full_graph.py run unmodified on a partition
 gradients are summed with one flat all_reduce; the loss is normalised by the global train count so
 the P-way run computes the same mean loss as the 1-GPU run (main_dgl_product_sage.py:105-106).
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -230,8 +232,10 @@ class _Comm(object):
 
     def __init__(self, group=None):
         self.group = group
+        self.n_exchanges = 0
 
     def all_to_all(self, out, inp, out_splits, in_splits):
+        self.n_exchanges += 1
         if dist.get_backend(self.group) == "gloo":  # tests: pairwise isend/irecv staged through host memory
             world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
             outs = list(out.split(out_splits, 0))
@@ -260,6 +264,7 @@ class _Comm(object):
         if dist.get_backend(self.group) == "gloo":
             self.all_to_all(out, inp, out_splits, in_splits)
             return _Done()
+        self.n_exchanges += 1
         return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
 
 
@@ -275,15 +280,24 @@ class DistCopyU(torch.autograd.Function):
                 -> wait -> g-SpMM over halo sources accumulating into the same output
       backward  g-SpMM^T producing halo-row gradients -> all_to_all (async) || g-SpMM^T over owned rows
                 -> wait -> add received rows into their owners (per peer, fixed order)
-    Both halves write through dst_scale = 1/max(deg,1) for `mean` (deg = full in-degree)."""
+    Both halves write through dst_scale = 1/max(deg,1) for `mean` (deg = full in-degree).
+    `static_cache` (a dict, or None): halo rows of a CONSTANT input (the node features of layer 1: a leaf that needs no
+    gradient) stay resident on the receiving rank after the first exchange -- keyed by the tensor's storage, shape and
+    version counter, so an in-place update or a different tensor exchanges again.  The aggregation itself always runs."""
 
     @staticmethod
-    def forward(ctx, x, plan, comm, reduce):
+    def forward(ctx, x, plan, comm, reduce, static_cache=None):
         x = x.contiguous()
         feat = tuple(x.shape[1:])
-        send = sparse.gather_rows_raw(x, plan.send_idx)
-        recv = torch.empty((plan.n_halo,) + feat, dtype=x.dtype, device=x.device)
-        work = comm.all_to_all_async(recv, send, plan.recv_splits, plan.send_splits)
+        key = (x.data_ptr(), x._version, tuple(x.shape))
+        if static_cache is not None and static_cache.get("key") == key:
+            recv, work = static_cache["recv"], _Done()
+        else:
+            send = sparse.gather_rows_raw(x, plan.send_idx)
+            recv = torch.empty((plan.n_halo,) + feat, dtype=x.dtype, device=x.device)
+            work = comm.all_to_all_async(recv, send, plan.recv_splits, plan.send_splits)
+            if static_cache is not None:
+                static_cache["key"], static_cache["recv"] = key, recv
         scale = plan.inv_deg if reduce == "mean" else None
         out, _, _ = sparse.gspmm_raw(plan.loc.csc(), "copy_lhs", "sum", x, None, dst_scale=scale)
         work.wait()
@@ -310,7 +324,7 @@ class DistCopyU(torch.autograd.Function):
         for (a, b) in plan.send_ranges:
             if b > a:
                 sparse.scatter_add_rows_raw(gx, plan.send_idx[a:b], back[a:b])
-        return gx, None, None, None
+        return gx, None, None, None, None
 
 
 class HaloExchange(torch.autograd.Function):
@@ -354,10 +368,12 @@ class DistGraph(DGLGraph):
         self._edge_frame = Frame(block.number_of_edges(), kind="edge")
         self._batch_num_nodes = None
         self._batch_num_edges = None
+        self._static_halo = {}  # halo rows of the constant input features (see DistCopyU); shared by local_var() clones
 
     def _clone(self, index=None, frames=None):
         g = DistGraph.__new__(DistGraph)
         g._block, g._plan, g._comm = self._block, self._plan, self._comm
+        g._static_halo = self._static_halo
         g._index, g._is_block = self._index, False
         if frames is None:
             g._src_frame = self._src_frame.clone()
@@ -420,7 +436,10 @@ class DistGraph(DGLGraph):
                 and reduce_func.msg_field == message_func.out_field and self._plan.loc is not None
                 and apply_node_func is None):
             x = self._src_frame[message_func.in_field]
-            self._dst_frame[reduce_func.out_field] = DistCopyU.apply(x, self._plan, self._comm, reduce_func.name)
+            # a leaf without gradient inside a training forward = constant input features: their halo rows stay resident
+            static = self._static_halo if (torch.is_grad_enabled() and not x.requires_grad and x.is_leaf
+                                           and os.environ.get("MGX_STATIC_HALO", "1") == "1") else None
+            self._dst_frame[reduce_func.out_field] = DistCopyU.apply(x, self._plan, self._comm, reduce_func.name, static)
             return
         blk = self._local(self._u_fields(message_func))
         core.update_all(blk, message_func, reduce_func, apply_node_func)

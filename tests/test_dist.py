@@ -89,6 +89,16 @@ def _worker(rank, world, port, q, device="cpu", batch_norm=False):
     q.put((rank, own.cpu().numpy(), out.detach().cpu().numpy(), float(lsum),
            [p.grad.cpu().numpy() for p in model.parameters()], stats, plan.n_halo, sum(plan.send_splits),
            generic_path(g, x).cpu().numpy(), [b.cpu().numpy() for b in model.buffers()]))
+    # second training forward: the halo rows of the constant input features are resident, hidden layers exchange again
+    n_before = g._comm.n_exchanges
+    out2 = model(g, x)
+    n_layers = len(model.layers)
+    assert g._comm.n_exchanges - n_before == n_layers - 1, (n_before, g._comm.n_exchanges)
+    assert torch.equal(out2, out) or torch.allclose(out2, out, rtol=1e-6, atol=1e-7)
+    x.add_(0.0)  # an in-place write bumps the version counter: the cache must not be trusted any more
+    n_before = g._comm.n_exchanges
+    model(g, x)
+    assert g._comm.n_exchanges - n_before == n_layers
     dist.barrier()
     dist.destroy_process_group()
 
