@@ -44,6 +44,25 @@ __global__ __launch_bounds__(kBlock) void degrees_kernel(const Idx* indptr, int6
   }
 }
 
+// COO in EDGE-ID order from a CSR: edge e = eids[p] (or p) gets its row (binary search in indptr, L2-resident) and its
+// column.  eids must be a permutation of [0, nnz): an id outside that range is dropped instead of written.
+template <typename Idx>
+__global__ __launch_bounds__(kBlock) void csr_to_coo_by_eid_kernel(const Idx* indptr, const Idx* indices, const Idx* eids,
+                                                                   int64_t n_rows, int64_t nnz, Idx* rows_e, Idx* cols_e) {
+  for (int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * kBlock) {
+    int64_t lo = 0, hi = n_rows;  // invariant: indptr[lo] <= p < indptr[hi]
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)indptr[mid] <= p) lo = mid; else hi = mid;
+    }
+    const int64_t e = eids ? (int64_t)eids[p] : p;
+    if ((uint64_t)e < (uint64_t)nnz) {
+      rows_e[e] = (Idx)lo;
+      cols_e[e] = indices[p];
+    }
+  }
+}
+
 static inline unsigned grid_for(int64_t n) {
   int64_t b = (n + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -87,7 +106,49 @@ static int32_t coo_to_csr_impl(int64_t n_rows, int64_t nnz, const Idx* row, cons
   return MGX_OK;
 }
 
+template <typename Idx>
+static int32_t csr_transpose_impl(const mgx_csr* c, Idx* indptr_t, Idx* indices_t, Idx* eids_t, void* ws, int64_t ws_bytes,
+                                  hipStream_t s) {
+  const int64_t nnz = c->nnz;
+  if (nnz == 0) {
+    MGX_CHECK_HIP(hipMemsetAsync(indptr_t, 0, sizeof(Idx) * (c->num_cols + 1), s));
+    return MGX_OK;
+  }
+  const size_t arr = align256(sizeof(Idx) * (size_t)nnz);
+  MGX_CHECK_ARG((size_t)ws_bytes > 2 * arr, "mgx_csr_transpose: workspace too small");
+  Idx* rows_e = (Idx*)ws;
+  Idx* cols_e = (Idx*)((char*)ws + arr);
+  hipLaunchKernelGGL((csr_to_coo_by_eid_kernel<Idx>), dim3(grid_for(nnz)), dim3(kBlock), 0, s, (const Idx*)c->indptr,
+                     (const Idx*)c->indices, (const Idx*)c->eids, c->num_rows, nnz, rows_e, cols_e);
+  MGX_CHECK_LAUNCH();
+  // the edge list in edge-id order, sorted stably by column: exactly what mgx_coo_to_csr builds from the COO
+  return coo_to_csr_impl<Idx>(c->num_cols, nnz, (const Idx*)cols_e, (const Idx*)rows_e, indptr_t, indices_t, eids_t,
+                              (char*)ws + 2 * arr, ws_bytes - (int64_t)(2 * arr), s);
+}
+
 }  // namespace mgx
+
+extern "C" int64_t mgx_csr_transpose_workspace(int64_t num_cols, int64_t nnz, int32_t idx_bits) {
+  if (nnz <= 0) return 0;
+  const int64_t inner = mgx_coo_to_csr_workspace(num_cols, nnz, idx_bits);
+  if (inner < 0) return inner;
+  return inner + 2 * (int64_t)mgx::align256((size_t)(idx_bits / 8) * (size_t)nnz);
+}
+
+extern "C" int32_t mgx_csr_transpose(const mgx_csr* csr, void* indptr_t, void* indices_t, void* eids_t, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(csr != nullptr && indptr_t != nullptr, "mgx_csr_transpose: NULL pointer");
+  MGX_CHECK_ARG(csr->idx_bits == 32 || csr->idx_bits == 64, "mgx_csr_transpose: idx_bits must be 32 or 64");
+  MGX_CHECK_ARG(csr->num_rows >= 0 && csr->num_cols >= 0 && csr->nnz >= 0, "mgx_csr_transpose: negative sizes");
+  MGX_CHECK_ARG(csr->nnz == 0 || (csr->indptr && csr->indices && indices_t && eids_t && workspace), "mgx_csr_transpose: NULL pointer");
+  if (csr->idx_bits == 32)
+    return csr_transpose_impl<int32_t>(csr, (int32_t*)indptr_t, (int32_t*)indices_t, (int32_t*)eids_t, workspace, workspace_bytes,
+                                       (hipStream_t)stream);
+  return csr_transpose_impl<int64_t>(csr, (int64_t*)indptr_t, (int64_t*)indices_t, (int64_t*)eids_t, workspace, workspace_bytes,
+                                     (hipStream_t)stream);
+}
 
 extern "C" int64_t mgx_coo_to_csr_workspace(int64_t num_rows, int64_t nnz, int32_t idx_bits) {
   using namespace mgx;

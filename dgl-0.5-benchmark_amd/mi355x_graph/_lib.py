@@ -61,6 +61,8 @@ SIGNATURES = {
     "mgx_column_sum": (_i32, [_i64, _i64, _fp, _fp, _vp, _vp]),
     "mgx_coo_to_csr_workspace": (_i64, [_i64, _i64, _i32]),
     "mgx_coo_to_csr": (_i32, [_i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mgx_csr_transpose_workspace": (_i64, [_i64, _i64, _i32]),
+    "mgx_csr_transpose": (_i32, [_csr_p, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mgx_csr_degrees": (_i32, [_i64, _vp, _i32, _vp, _vp]),
     "mgx_csr_inv_degrees": (_i32, [_i64, _vp, _i32, _fp, _vp]),
     "mgx_coo_to_csr_host": (_i32, [_i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),

@@ -98,8 +98,12 @@ class GraphIndex(object):
             return self._csc
         if self._hidden_csc is not None:
             return self._hidden_csc
-        src, dst = self.coo()
-        view = sparse.coo_to_csr(self.num_dst, self.num_src, dst, src)
+        other = self._csr if self._csr is not None else self._hidden_csr
+        if self._coo is None and other is not None and other.indptr.is_cuda:
+            view = sparse.csr_transpose(other)  # no COO round trip: transpose the out-CSR on the device
+        else:
+            src, dst = self.coo()
+            view = sparse.coo_to_csr(self.num_dst, self.num_src, dst, src)
         view.dst_is_src_prefix = self.dst_is_src_prefix
         if self.allowed("csc"):
             self._csc = view
@@ -113,8 +117,12 @@ class GraphIndex(object):
             return self._csr
         if self._hidden_csr is not None:
             return self._hidden_csr
-        src, dst = self.coo()
-        view = sparse.coo_to_csr(self.num_src, self.num_dst, src, dst)
+        other = self._csc if self._csc is not None else self._hidden_csc
+        if self._coo is None and other is not None and other.indptr.is_cuda:
+            view = sparse.csr_transpose(other)
+        else:
+            src, dst = self.coo()
+            view = sparse.coo_to_csr(self.num_src, self.num_dst, src, dst)
         if self.allowed("csr"):
             self._csr = view
         else:

@@ -191,6 +191,22 @@ class HipBackend(object):
                                         _ptr(eids), _ptr(ws), ws_bytes, _stream(dev)))
         return CsrView(num_rows, num_cols, indptr, indices, eids)
 
+    def csr_transpose(self, csr):
+        dev = self._check_dev(csr.indptr, csr.indices, csr.eids)
+        L = _lib.lib()
+        dt = csr.indptr.dtype
+        indptr = torch.empty(csr.num_cols + 1, dtype=dt, device=dev)
+        indices = torch.empty(csr.nnz, dtype=dt, device=dev)
+        eids = torch.empty(csr.nnz, dtype=dt, device=dev)
+        with torch.cuda.device(dev):
+            ws_bytes = L.mgx_csr_transpose_workspace(csr.num_cols, csr.nnz, csr.idx_bits)
+            if ws_bytes < 0:
+                _lib.check(3)
+            ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+            _lib.check(L.mgx_csr_transpose(ctypes.byref(csr.c_struct()), _ptr(indptr), _ptr(indices), _ptr(eids), _ptr(ws), ws_bytes,
+                                           _stream(dev)))
+        return CsrView(csr.num_cols, csr.num_rows, indptr, indices, eids)
+
     def degrees(self, csr):
         dev = csr.device
         deg = torch.empty(csr.num_rows, dtype=csr.indptr.dtype, device=dev)
@@ -420,6 +436,11 @@ def coo_to_csr_host(num_rows, num_cols, row, col):
     eids = torch.empty(nnz, dtype=row.dtype)
     _lib.check(_lib.lib().mgx_coo_to_csr_host(num_rows, nnz, _ptr(row), _ptr(col), bits, _ptr(indptr), _ptr(indices), _ptr(eids)))
     return CsrView(num_rows, num_cols, indptr, indices, eids)
+
+
+def csr_transpose(csr):
+    """Device CSR -> its transpose (same edge ids); rows ordered by the positions in `csr`."""
+    return backend_for(csr.indptr).csr_transpose(csr)
 
 
 def coo_to_csr(num_rows, num_cols, row, col):

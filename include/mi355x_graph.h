@@ -236,6 +236,14 @@ int64_t mgx_coo_to_csr_workspace(int64_t num_rows, int64_t nnz, int32_t idx_bits
 int32_t mgx_coo_to_csr(int64_t num_rows, int64_t nnz, const void* row, const void* col, int32_t idx_bits,
                        void* indptr, void* indices, void* eids,
                        void* workspace, int64_t workspace_bytes, void* stream);
+/* Transpose of a CSR (the out-CSR from the in-CSR or back; UPSTREAM aten::CSRTranspose behind g.formats / the reversed
+ * graph of every SpMM backward): rows of the result = columns of `csr`, entries of a row in EDGE-ID order -- bit-identical
+ * to mgx_coo_to_csr on the graph's COO, so both formats address the same edge tensors and reduce in the same order.
+ * csr->eids must be a permutation of [0, nnz) or NULL (= positions).  Outputs indptr_t[num_cols+1], indices_t[nnz],
+ * eids_t[nnz]; workspace of mgx_csr_transpose_workspace() bytes. */
+int64_t mgx_csr_transpose_workspace(int64_t num_cols, int64_t nnz, int32_t idx_bits);
+int32_t mgx_csr_transpose(const mgx_csr* csr, void* indptr_t, void* indices_t, void* eids_t,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 /* in_degrees / out_degrees from a CSR: deg[v] = indptr[v+1]-indptr[v] (graph index width). */
 int32_t mgx_csr_degrees(int64_t num_rows, const void* indptr, int32_t idx_bits, void* deg, void* stream);
 /* inv_deg[v] = 1 / max(deg,1) as fp32 (the factor of fn.mean and of its backward). */

@@ -532,3 +532,37 @@ def test_column_sum_and_linear_bias_grad(n, C):
     (ops.bias_add(x, b1) * w).sum().backward()
     ((x + b2) * w).sum().backward()
     assert float((b1.grad - b2.grad).abs().max() / b2.grad.abs().max().clamp(min=1e-12)) < 1e-4
+
+
+@pytest.mark.parametrize("idtype", [torch.int32, torch.int64])
+@pytest.mark.parametrize("shape", [(1, 1, 0), (7, 5, 3), (1000, 1000, 30000), (5000, 300, 200000), (300, 5000, 20000)])
+def test_csr_transpose_bit_exact(oracle, idtype, shape):
+    """mgx_csr_transpose: the out-CSR from the in-CSR without a COO round trip, bit-identical to the COO-built one (oracle:
+    stable sort of the edge list by source).  Transposing twice restores the input, and a graph that holds only one
+    compressed format computes the same aggregation as one built from COO."""
+    n_src, n_dst, nnz = shape
+    src, dst = random_graph(n_src, n_dst, nnz, seed=nnz + 5)
+    g = mk(n_src, n_dst, src, dst, idtype)
+    csc = g._index.csc()                                   # rows = dst, indices = src, eids -> edge id
+    t = sparse.csr_transpose(csc)                          # rows = src, indices = dst
+    rp, rx, re = oracle.coo_to_csr(n_src, src, dst)
+    assert t.num_rows == n_src and t.num_cols == n_dst and t.indptr.dtype == idtype
+    assert np.array_equal(t.indptr.cpu().numpy(), rp) and np.array_equal(t.indices.cpu().numpy(), rx)
+    assert np.array_equal(t.eids.cpu().numpy(), re)
+    # canonical in-CSR (eids = NULL): edge ids are the positions, rows ordered by position
+    ip, ix = csc.indptr.cpu().numpy(), csc.indices.cpu().numpy()
+    order = np.argsort(ix, kind="stable")
+    tc = sparse.csr_transpose(sparse.CsrView(csc.num_rows, csc.num_cols, csc.indptr, csc.indices, None))
+    assert np.array_equal(tc.eids.cpu().numpy(), order)
+    assert np.array_equal(tc.indices.cpu().numpy(), np.repeat(np.arange(n_dst), np.diff(ip))[order])
+    tt = sparse.csr_transpose(t)
+    assert torch.equal(tt.indptr, csc.indptr) and torch.equal(tt.indices, csc.indices) and torch.equal(tt.eids, csc.eids)
+    if nnz:
+        # a graph restricted to csc has no COO: its out-CSR now comes from the transpose; backward must still be right
+        g2 = mg.DGLGraph(mg.GraphIndex(n_src, n_dst, csc=csc, formats=("csr", "csc")), is_block=True)
+        x1 = torch.rand(n_src, 6, device=DEV, requires_grad=True)
+        x2 = x1.detach().clone().requires_grad_(True)
+        w = torch.rand(n_dst, 6, device=DEV)
+        (ops.gspmm(g2, "copy_lhs", "sum", x1, None) * w).sum().backward()
+        (ops.gspmm(g, "copy_lhs", "sum", x2, None) * w).sum().backward()
+        assert float((x1.grad - x2.grad).abs().max()) <= 1e-4 * float(x2.grad.abs().max() + 1e-12)
