@@ -15,6 +15,8 @@
 // In both, the ids of 64 edges arrive by ONE coalesced load (lane j <- edge j) and are handed to
 // the lane groups with ds_bpermute; the next 64 are requested before the current gathers issue.
 // `dot` keeps kUn edges in flight and reduces inside the lane group with xor-shuffles.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mgx {
@@ -33,6 +35,7 @@ struct SddmmArgs {
   const Idx* item_end;
   int64_t n_items;
   int64_t n_rows;
+  int64_t n_cols;
   int64_t nblocks;
   int64_t nnz;
   const float* L;
@@ -225,6 +228,124 @@ __global__ __launch_bounds__(kBlock) void sddmm_csr_kernel(const SddmmArgs<Idx> 
 }
 
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Head-wise dot on the in-CSR with one operand constant along the row: out[e, h] = <gat[indices[p], h, :], rowc[row, h, :]>
+// -- the edge gradient of u_mul_e/sum (GATConv backward: X[u] . dZ[v] per head) and u_dot_v on a CSR-only graph.
+// Same shape as the summing g-SpMM: lanes along the WHOLE feature row (G lanes x 16 bytes, all heads at once), the
+// row-constant operand is loaded once per work item, lane j turns its neighbour id into a 32-bit byte offset once per 64
+// edges and hands it over with ds_bpermute, 64/G edges per gather instruction and kUn of them in flight; the F/4 lanes of
+// a head combine by xor-shuffle.  (The generic body re-gathers a 4*F-byte slice per head and reloads rowc for every edge.)
+template <int G, int LPH>
+__global__ __launch_bounds__(kBlock) void sddmm_csr_headdot_kernel(const SddmmArgs<int32_t> a, const float* gat, const float* rowc) {
+  constexpr int NB = kWave / G;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int sub = lane / G, l = lane % G;
+  const int D = (int)a.l_len, H = (int)a.out_len;
+  const int f = l * 4;
+  const bool factive = f < D;
+  const bool writer = factive && (l % LPH) == 0;
+  const int head = l / LPH;
+  const uint32_t rowbytes = (uint32_t)D * 4u;
+  const uint32_t f4 = factive ? (uint32_t)f * 4u : 0u;  // idle feature lanes re-read the row start; never stored
+  const char* __restrict__ gatb = reinterpret_cast<const char*>(gat);
+  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * kCsrItems;
+  for (int r = wave; r < kCsrItems; r += kWavesPerBlock) {
+    const int64_t item = item_base + r;
+    if (item >= a.n_items) break;
+    int64_t row;
+    int32_t beg, end;
+    if (a.item_node) {
+      row = (int64_t)a.item_node[item];
+      beg = a.item_beg[item];
+      end = a.item_end[item];
+    } else {
+      row = item;
+      beg = a.indptr[item];
+      end = a.indptr[item + 1];
+    }
+    if (beg >= end) continue;
+    const v4f rv = factive ? *reinterpret_cast<const v4f*>(rowc + row * D + f) : (v4f)(0.f);
+    auto load_ids = [&](int32_t base, uint32_t& goff, int32_t& me) {
+      const int32_t q = base + lane;
+      goff = 0;
+      me = 0;
+      if (q < end) {
+        goff = (uint32_t)a.indices[q] * rowbytes;
+        me = a.eids ? a.eids[q] : q;
+      }
+    };
+    uint32_t goff, ngoff = 0;
+    int32_t me, nme = 0;
+    load_ids(beg, goff, me);
+    for (int32_t base = beg; base < end; base += kWave) {
+      if (base + kWave < end) load_ids(base + kWave, ngoff, nme);
+      const int cnt = (end - base) < kWave ? (end - base) : kWave;
+      for (int k = 0; k < cnt; k += NB * kUn) {
+        v4f x[kUn];
+        int32_t ee[kUn];
+#pragma unroll
+        for (int i = 0; i < kUn; ++i) {
+          const int j = k + i * NB + sub;
+          const int bi = (j < cnt ? j : 0) * 4;  // lanes past the end re-read edge 0 (valid memory), never stored
+          const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)goff) + f4;
+          ee[i] = __builtin_amdgcn_ds_bpermute(bi, me);
+          x[i] = *reinterpret_cast<const v4f*>(gatb + off);
+        }
+#pragma unroll
+        for (int i = 0; i < kUn; ++i) {
+          float p = x[i].x * rv.x + x[i].y * rv.y + x[i].z * rv.z + x[i].w * rv.w;
+#pragma unroll
+          for (int off = 1; off < LPH; off <<= 1) p += __shfl_xor(p, off, kWave);
+          if (writer && k + i * NB + sub < cnt) a.out[(int64_t)ee[i] * H + head] = p;
+        }
+      }
+      goff = ngoff;
+      me = nme;
+    }
+  }
+}
+
+template <int G>
+static bool launch_headdot_lph(const SddmmArgs<int32_t>& a, const float* gat, const float* rowc, int lph, hipStream_t s) {
+  const dim3 grid((unsigned)a.nblocks), block(kBlock);
+  switch (lph) {
+#define MGX_HDOT(L) case L: if (L <= G) { hipLaunchKernelGGL((sddmm_csr_headdot_kernel<G, (L <= G ? L : G)>), grid, block, 0, s, a, gat, rowc); return true; } return false;
+    MGX_HDOT(1) MGX_HDOT(2) MGX_HDOT(4) MGX_HDOT(8) MGX_HDOT(16)
+#undef MGX_HDOT
+    default: return false;
+  }
+}
+
+// Returns true when the specialised kernel was launched.
+static bool try_headdot(const SddmmArgs<int32_t>& a, hipStream_t s) {
+  const int64_t RS = a.reduce_size, D = a.out_len * RS;
+  const bool uv = a.lhs_target == MGX_TARGET_U && a.rhs_target == MGX_TARGET_V;
+  const bool vu = a.lhs_target == MGX_TARGET_V && a.rhs_target == MGX_TARGET_U;
+  if (!(uv || vu) || a.l_off || a.r_off || a.l_len != D || a.r_len != D || RS % 4 != 0 || D > 256) return false;
+  const int64_t lph = RS / 4;
+  if ((lph & (lph - 1)) != 0 || lph > 16) return false;
+  if ((uintptr_t)a.L % 16 || (uintptr_t)a.R % 16) return false;
+  if (a.n_cols * D * 4 >= (int64_t(1) << 32) || a.nnz >= (int64_t(1) << 31)) return false;  // 32-bit byte offsets
+  const float* gat = uv ? a.L : a.R;
+  const float* rowc = uv ? a.R : a.L;
+  int G = 1;
+  while (G * 4 < D) G <<= 1;
+  switch (G) {
+    case 1: return launch_headdot_lph<1>(a, gat, rowc, (int)lph, s);
+    case 2: return launch_headdot_lph<2>(a, gat, rowc, (int)lph, s);
+    case 4: return launch_headdot_lph<4>(a, gat, rowc, (int)lph, s);
+    case 8: return launch_headdot_lph<8>(a, gat, rowc, (int)lph, s);
+    case 16: return launch_headdot_lph<16>(a, gat, rowc, (int)lph, s);
+    case 32: return launch_headdot_lph<32>(a, gat, rowc, (int)lph, s);
+    default: return launch_headdot_lph<64>(a, gat, rowc, (int)lph, s);
+  }
+}
+template <typename Idx> static bool try_headdot_any(const SddmmArgs<Idx>&, hipStream_t) { return false; }
+template <> bool try_headdot_any<int32_t>(const SddmmArgs<int32_t>& a, hipStream_t s) {
+  return getenv("MGX_SDDMM_GENERIC_DOT") == nullptr && try_headdot(a, s);
+}
+
 template <typename Idx, int VEC, int G, bool CSR, bool DIRECT, bool DOT>
 static void launch_one(const SddmmArgs<Idx>& a, hipStream_t s) {
   const unsigned gy = DOT ? 1u : (unsigned)((a.out_len + G * VEC - 1) / (G * VEC));
@@ -271,6 +392,10 @@ static int32_t sddmm_impl(SddmmArgs<Idx>& a, hipStream_t s) {
     const int64_t RS = a.reduce_size;
     MGX_CHECK_ARG(RS >= 1, "mgx_sddmm: dot needs reduce_size >= 1");
     MGX_CHECK_ARG(a.L && a.R, "mgx_sddmm: dot needs both operands");
+    if (CSR && try_headdot_any<Idx>(a, s)) {
+      MGX_CHECK_LAUNCH();
+      return MGX_OK;
+    }
     if (RS % 4 == 0 && a.l_len % 4 == 0 && a.r_len % 4 == 0 && aligned(16)) launch_g<Idx, 4, CSR, true, true>(a, s);
     else if (RS % 2 == 0 && a.l_len % 2 == 0 && a.r_len % 2 == 0 && aligned(8)) launch_g<Idx, 2, CSR, true, true>(a, s);
     else launch_g<Idx, 1, CSR, true, true>(a, s);
@@ -320,7 +445,7 @@ static int32_t run_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t op
                        const int64_t* l_off, const int64_t* r_off, float* out, hipStream_t s) {
   SddmmArgs<Idx> a{};
   a.indptr = (const Idx*)csr->indptr; a.indices = (const Idx*)csr->indices; a.eids = (const Idx*)csr->eids;
-  a.n_rows = csr->num_rows; a.n_items = csr->num_rows; a.nnz = csr->nnz; a.L = lhs; a.R = rhs;
+  a.n_rows = csr->num_rows; a.n_cols = csr->num_cols; a.n_items = csr->num_rows; a.nnz = csr->nnz; a.L = lhs; a.R = rhs;
   a.l_off = l_off; a.r_off = r_off; a.out = out; a.l_len = l_len; a.r_len = r_len; a.out_len = out_len;
   a.reduce_size = reduce_size; a.op = op; a.lhs_target = lt; a.rhs_target = rt;
   if (plan && plan->item_node) {

@@ -41,9 +41,8 @@ def _reduce_grad(grad, shape):
     return grad.view((-1,) + tuple(shape[1:]))
 
 
-def _need_reduce_last_dim(ufeat, efeat):
+def _need_reduce_last_dim(ushp, eshp):
     """(N,H,F) x (E,H,1): the edge gradient is a per-head dot product."""
-    ushp, eshp = ufeat.shape, efeat.shape
     return ushp[1:-1] == eshp[1:-1] and eshp[-1] == 1 and ushp[-1] > 1
 
 
@@ -92,7 +91,7 @@ class GSpMM(torch.autograd.Function):
                 dX = _reduce_grad(dX, ctx.x_shape)
             if op != "copy_lhs" and ctx.needs_input_grad[4]:
                 if op == "mul":
-                    if _need_reduce_last_dim(X, Y):
+                    if _need_reduce_last_dim(ctx.x_shape, ctx.y_shape):
                         dY = sparse.gsddmm_raw(gidx, "dot", X, dZs, "u", "v")
                     else:
                         dY = sparse.gsddmm_raw(gidx, "mul", X, dZs, "u", "v")

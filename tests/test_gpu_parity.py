@@ -566,3 +566,32 @@ def test_csr_transpose_bit_exact(oracle, idtype, shape):
         (ops.gspmm(g2, "copy_lhs", "sum", x1, None) * w).sum().backward()
         (ops.gspmm(g, "copy_lhs", "sum", x2, None) * w).sum().backward()
         assert float((x1.grad - x2.grad).abs().max()) <= 1e-4 * float(x2.grad.abs().max() + 1e-12)
+
+
+@pytest.mark.parametrize("H,F", [(1, 4), (1, 16), (1, 64), (8, 8), (8, 16), (4, 32), (3, 4), (12, 4), (2, 128), (1, 256)])
+@pytest.mark.parametrize("canonical", [False, True])
+def test_head_dot_sddmm_on_csr_walk(oracle, H, F, canonical):
+    """u_dot_v per head on a CSR-only graph (the specialised row-constant kernel; (2,128)/(1,256) exceed its lane-group
+    limits and take the generic body): both target orders, hub rows, canonical edge order, against the oracle; and the
+    u_mul_e/sum edge gradient that reaches it through autograd."""
+    n_src, n_dst, nnz = 700, 500, 40000
+    src, dst = random_graph(n_src, n_dst, nnz, seed=H * 100 + F)
+    rng = np.random.default_rng(H + F)
+    U = (rng.random((n_src, H, F), dtype=np.float32) - 0.5)
+    V = (rng.random((n_dst, H, F), dtype=np.float32) - 0.5)
+    g = mk(n_src, n_dst, src, dst, formats=["csr", "csc"])
+    gi = g._index.canonical()[0] if canonical else g._index
+    perm = g._index.canonical()[1]
+    ref = oracle.sddmm(src, dst, "dot", U, V)                                   # (E, H, 1) in edge-id order
+    if canonical and perm is not None:
+        ref = ref[perm.cpu().numpy()]
+    scale = float(np.abs(ref).max())
+    out = ops.gsddmm(gi, "dot", T(U), T(V), "u", "v")
+    assert out.shape == ref.shape and float(np.abs(out.cpu().numpy() - ref).max()) < RTOL * scale
+    out = ops.gsddmm(gi, "dot", T(V), T(U), "v", "u")
+    assert float(np.abs(out.cpu().numpy() - ref).max()) < RTOL * scale
+    # edge gradient of u_mul_e/sum: d a[e, h] = <X[u, h, :], dZ[v, h, :]>
+    a = torch.rand(nnz, H, 1, device=DEV, requires_grad=True)
+    z = ops.gspmm(gi, "mul", "sum", T(U), a)
+    (z * T(V)).sum().backward()
+    assert float((a.grad.cpu() - torch.from_numpy(ref)).abs().max()) < RTOL * scale
