@@ -151,6 +151,7 @@ class GraphIndex(object):
                 inv[perm.long()] = torch.arange(perm.shape[0], dtype=perm.dtype, device=perm.device)
                 c_csc = sparse.CsrView(csc.num_rows, csc.num_cols, csc.indptr, csc.indices, None)
                 c_csc._plan = csc.plan()  # same rows and edge ranges: the schedule carries over
+                c_csc._row_order = csc._row_order
                 c_csc.dst_is_src_prefix = csc.dst_is_src_prefix
                 csr = self.csr()
                 c_csr = sparse.CsrView(csr.num_rows, csr.num_cols, csr.indptr, csr.indices, inv[csr.eids.long()])

@@ -200,20 +200,25 @@ def _no_hubs_cheaply(csr):
     return int(deg.max().item()) <= int(os.environ.get("MGX_SPLIT", 256))
 
 
-def plan_for(csr):
+def plan_for(csr, split=None):
     """Default policy: always split hubs; cluster the row order only for big square graphs.
-    MGX_SCHEDULE=natural|cluster|none overrides (none: no plan at all)."""
+    MGX_SCHEDULE=natural|cluster|none overrides (none: no plan at all).  `split` overrides the hub threshold (the row
+    order computed for the first plan of a CSR is reused)."""
     mode = os.environ.get("MGX_SCHEDULE", "auto")
     if mode == "none" or csr.num_rows == 0 or csr.nnz == 0:
         return None
     if mode == "auto" and csr.nnz < _SMALL_NNZ and csr.nnz // max(csr.num_rows, 1) < 64 and _no_hubs_cheaply(csr):
         return None
-    split = int(os.environ.get("MGX_SPLIT", 256))  # 256 measured best on MI355X (1024: +5..10 %)
+    if split is None:
+        split = int(os.environ.get("MGX_SPLIT", 256))  # 256 measured best on MI355X (1024: +5..10 %)
     want_cluster = mode == "cluster" or (mode == "auto" and csr.nnz >= _CLUSTER_MIN_NNZ)
-    order, kind = None, "natural"
-    square_like = csr.num_rows == csr.num_cols or getattr(csr, "dst_is_src_prefix", False)
-    if want_cluster and square_like and csr.indices.numel():
-        order, kind = locality_order(csr), "cluster"
+    order, kind = csr._row_order
+    if kind is None:
+        order, kind = None, "natural"
+        square_like = csr.num_rows == csr.num_cols or getattr(csr, "dst_is_src_prefix", False)
+        if want_cluster and square_like and csr.indices.numel():
+            order, kind = locality_order(csr), "cluster"
+        csr._row_order = (order, kind)
     plan = build_plan(csr, order, split, kind)
     if kind == "natural" and plan.num_hubs == 0:
         return None  # natural order, nothing split: the plan-free path is identical and leaner

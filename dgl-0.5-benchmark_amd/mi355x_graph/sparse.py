@@ -8,6 +8,7 @@ tensors -- message-passing arithmetic on CPU tensors raises DGLError.  (tests/ r
 backend for multi-process gloo tests; the product never does.)
 """
 import ctypes
+import os
 import functools
 
 import numpy as np
@@ -38,8 +39,8 @@ def _prod(shape):
 class CsrView(object):
     """An immutable CSR over torch tensors (in-CSR: rows = destination nodes)."""
 
-    __slots__ = ("num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan",
-                 "dst_is_src_prefix")
+    __slots__ = ("num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan", "_sm_plan",
+                 "_row_order", "dst_is_src_prefix")
 
     def __init__(self, num_rows, num_cols, indptr, indices, eids):
         self.num_rows, self.num_cols = int(num_rows), int(num_cols)
@@ -48,6 +49,8 @@ class CsrView(object):
         self._deg = None
         self._inv_deg = None
         self._plan = False  # False = not built yet; None = run without a plan
+        self._sm_plan = False
+        self._row_order = (None, None)  # (row order, kind) computed with the first plan
         self.dst_is_src_prefix = False  # block graphs whose destination nodes are the first source nodes
 
     @property
@@ -89,6 +92,18 @@ class CsrView(object):
             from . import schedule
             self._plan = schedule.plan_for(self) if self.indptr.is_cuda else None
         return self._plan
+
+    def softmax_plan(self):
+        """Schedule of the edge-softmax / fused attention kernels: the g-SpMM plan unless MGX_SOFTMAX_SPLIT asks for a
+        different hub threshold (rows up to that length then stay on the single-wave path)."""
+        want = os.environ.get("MGX_SOFTMAX_SPLIT")
+        if not want or not self.indptr.is_cuda:
+            return self.plan()
+        if self._sm_plan is False:
+            from . import schedule
+            self.plan()  # computes (and caches) the row order first
+            self._sm_plan = schedule.plan_for(self, split=int(want))
+        return self._sm_plan
 
     def to(self, device):
         return CsrView(self.num_rows, self.num_cols, self.indptr.to(device), self.indices.to(device),
@@ -339,7 +354,7 @@ class HipBackend(object):
 
     @staticmethod
     def _softmax_plan(csr, H, dev):
-        plan = csr.plan()
+        plan = csr.softmax_plan()
         if plan is None:
             return None, None
         ws = None
