@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastAr
       if (MODE == MODE_COPY_RHS) {
         gid = a.eids ? a.eids[q] : q;
       } else {
-        gid = a.indices[q];
+        gid = __builtin_nontemporal_load(&a.indices[q]);  // streamed once: keep L2 for the gathered rows
         if (MODE == MODE_MUL_EDGE) {
           eid = a.eids ? a.eids[q] : q;
           if (WMODE == 1) sc = a.w[eid];
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastAr
         if (a.dst_scale) acc = acc * a.dst_scale[row];
         float* op = a.out + row * (int64_t)a.D + f;
         if (a.accum) acc += *reinterpret_cast<const V*>(op);
-        *reinterpret_cast<V*>(op) = acc;
+        __builtin_nontemporal_store(acc, reinterpret_cast<V*>(op));
       } else {
         *reinterpret_cast<V*>(a.partial + (-(row + 1)) * (int64_t)a.D + f) = acc;
       }
