@@ -6,7 +6,7 @@ They run on whatever device holds the index tensors (the scripts call them on th
 import torch
 
 from ._lib import DGLError
-from .graph import DGLGraph, GraphIndex, Frame, graph
+from .graph import DGLGraph, GraphIndex, graph
 
 
 def to_bidirected(g, copy_ndata=False, readonly=None):
