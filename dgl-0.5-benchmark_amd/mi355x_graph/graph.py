@@ -472,6 +472,18 @@ class DGLGraph(object):
         from .sampling import node_subgraph
         return node_subgraph(self, nodes)
 
+    def add_self_loop(self, etype=None):
+        from .transform import add_self_loop
+        return add_self_loop(self)
+
+    def remove_self_loop(self, etype=None):
+        from .transform import remove_self_loop
+        return remove_self_loop(self)
+
+    def reverse(self, copy_ndata=True, copy_edata=False):
+        from .transform import reverse
+        return reverse(self, copy_ndata=copy_ndata, copy_edata=copy_edata)
+
     # -- message passing (implemented in core.py to keep this file structural)
     def update_all(self, message_func, reduce_func, apply_node_func=None, etype=None):
         from . import core

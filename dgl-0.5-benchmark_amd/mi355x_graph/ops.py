@@ -326,10 +326,12 @@ class BiasAdd(torch.autograd.Function):
 def bias_add(x, bias):
     """x + bias (bias broadcast over the leading dimension of x) with the bias gradient computed by mgx_column_sum."""
     C = bias.numel()
+    if x.dim() >= 2 and x[0].numel() == C:
+        bias = bias.view((1,) + tuple(x.shape[1:]))
     if (not bias.requires_grad or x.dtype != torch.float32 or x.device.type not in sparse._BACKENDS or x.dim() < 2
             or x[0].numel() != C or C > sparse.backend_for(x).COLUMN_SUM_MAX):
         return x + bias
-    return BiasAdd.apply(x, bias.view((1,) + tuple(x.shape[1:])))
+    return BiasAdd.apply(x, bias)
 
 
 def linear(x, weight, bias=None):

@@ -154,3 +154,26 @@ def test_molhiv_gcn_batched_udf_and_readout():
     assert torch.equal(bg.in_degrees().long(), torch.bincount(d, minlength=n))
     parts = dgl.unbatch(bg.to("cpu"))
     assert [p.number_of_nodes() for p in parts] == bg.batch_num_nodes().tolist()
+
+
+def test_gatconv_wide_heads_bias_and_grad():
+    """heads * out_feats > 256 (8 x 41, reddit/ns-gat-dgl.py's output layer): the bias gradient leaves the column-sum
+    kernel's range and must fall back to the plain broadcast add with the (1, H, F) bias shape."""
+    import mi355x_graph as mg
+    from mi355x_graph.nn import GATConv
+    from conftest import random_graph
+    n, nnz, H, F = 300, 4000, 8, 41
+    src, dst = random_graph(n, n, nnz, seed=4)
+    g = mg.add_self_loop(mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n)).int().to("cuda:0")
+    conv = GATConv(20, F, H).to("cuda:0")
+    torch.nn.init.normal_(conv.bias)
+    x = torch.rand(n, 20, device="cuda:0")
+    out = conv(g, x)
+    assert out.shape == (n, H, F)
+    conv.bias.data.zero_()
+    out0 = conv(g, x)
+    torch.nn.init.normal_(conv.bias)
+    out1 = conv(g, x)
+    assert torch.allclose(out1 - out0, conv.bias.view(1, H, F).expand_as(out0), atol=1e-5)
+    out1.sum().backward()
+    assert torch.allclose(conv.bias.grad, torch.full_like(conv.bias, float(n)), rtol=1e-5)

@@ -87,6 +87,18 @@ def _write_movielens_100k_like(root, n_user=60, n_movie=40, n_rating=900, seed=1
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("script,args", [
+    ("reddit/ns-gat-dgl.py", ["--batch-size", "256"]),               # 8-head GATConv on blocks (BASELINE config 3 shape)
+    ("ogbn-product/ns-sage/ns-sage-dgl.py", ["--batch-size", "512"]),
+    ("ogbn-product/ns-gat/ns-gat-dgl.py", ["--batch-size", "512"]),  # graph.remove_self_loop().add_self_loop()
+], ids=["reddit-ns-gat", "products-ns-sage", "products-ns-gat"])
+def test_more_neighbor_sampling_scripts_run_unmodified(script, args):
+    out = run(script, "--gpu", "-1", "--num-epochs", "2", "--num-workers", "0", "--eval-every", "1", *args,
+              root=REF_SAMPLING, MGX_DATASET_SCALE="0.005")
+    assert "Avg epoch time" in out and "Eval Acc" in out, out[-1500:]
+
+
+@pytest.mark.timeout(900)
 def test_gcmc_script_runs_unmodified(tmp_path):
     """gcmc_dgl/train.py (dgl.bipartite + hetero_from_relations, graph[etype], nodes[ntype].data,
     dglnn.HeteroGraphConv over 2 x 5 rating relations, u_dot_v decoder) on an ml-100k-shaped stand-in."""
