@@ -164,7 +164,7 @@ def test_gatconv_wide_heads_bias_and_grad():
     from conftest import random_graph
     n, nnz, H, F = 300, 4000, 8, 41
     src, dst = random_graph(n, n, nnz, seed=4)
-    g = mg.add_self_loop(mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n)).int().to("cuda:0")
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).add_self_loop().int().to("cuda:0")
     conv = GATConv(20, F, H).to("cuda:0")
     torch.nn.init.normal_(conv.bias)
     x = torch.rand(n, 20, device="cuda:0")
