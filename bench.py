@@ -75,6 +75,7 @@ def cpu_baseline(g, feat_dim, hidden, budget_s=30.0):
     import numpy as np
     from oracle import oracle as orc
     orc.build()
+    native = orc.use_native_build()  # timed on this host: compile for its ISA (falls back to the shipped x86-64-v3 build)
     cores = host_cores()
     orc.set_num_threads(cores)
     csc, csr = g._index.csc(), g._index.csr()
@@ -102,7 +103,7 @@ def cpu_baseline(g, feat_dim, hidden, budget_s=30.0):
         spent += dt
         edges += nnz
         done.append("%s: %.2fs" % (label, dt))
-    out = {"value": edges / spent, "unit": "edges/s", "cores": cores, "kind": "port",
+    out = {"value": edges / spent, "unit": "edges/s", "cores": cores, "kind": "port", "isa": "native" if native else "x86-64-v3",
            "sample": "g-SpMM part only (no dense layers): %d of the epoch's 5 aggregations on the full graph "
                      "(N=%d, E=%d), OpenMP over rows; %s" % (len(done), n, nnz, "; ".join(done))}
     # independent second CPU number: PyTorch's own CSR SpMM on the same cores, one D=hidden aggregation

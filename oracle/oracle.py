@@ -34,6 +34,23 @@ def build(force=False):
 _lib = None
 
 
+def use_native_build():
+    """bench.py's cpu_baseline leg: recompile for the ISA of the host it is timed on (the shipped library targets
+    x86-64-v3 so that it loads anywhere).  Falls back to the shipped build when no compiler is available."""
+    global _lib
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), "liboracle_native_%d.so" % os.getuid())
+    try:
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c99", "-fno-fast-math", "-ffp-contract=off",
+                               "-fopenmp", "-shared", "-o", out, os.path.join(_HERE, "oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _lib = ctypes.CDLL(out)
+        _lib.orc_num_threads.restype = ctypes.c_int
+        return True
+    except (OSError, subprocess.CalledProcessError):
+        return False
+
+
 def lib():
     global _lib
     if _lib is None:
