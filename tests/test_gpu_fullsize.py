@@ -134,3 +134,31 @@ def test_reddit_shape_gat_pipeline_properties():
     # canonical (in-CSR) edge order gives the same layer output
     cidx, perm = g._index.canonical()
     assert rel(ops.gspmm(cidx, "mul", "sum", ft, a[perm.long()]), out) < 1e-6
+
+
+def test_reddit_shape_fused_attention_head_dot_and_transpose_properties():
+    """Full-size properties of the later kernels: fused GAT attention == the composed chain; the head-wise dot g-SDDMM is
+    the adjoint of u_mul_e/sum in its edge argument (<A(ft, a), dZ> = <a, dot(ft[u], dZ[v])>), also on a CSR-only graph;
+    mgx_csr_transpose of the in-CSR is bit-identical to the COO-built out-CSR; column sums against fp64."""
+    import torch.nn.functional as F_
+    spec = SHAPES["reddit-small"]
+    H, F = 8, 8
+    src, dst = synthetic_edges(spec["n"], spec["m"], spec["max_deg"], spec["seed"], DEV, symmetric=True)
+    g = transform.add_self_loop(mg.graph((src, dst), num_nodes=spec["n"])).int()
+    n, E = spec["n"], g.number_of_edges()
+    el, er = torch.randn(n, H, 1, device=DEV), torch.randn(n, H, 1, device=DEV)
+    fused = ops.gat_attention(g, el, er, 0.2)
+    chain = ops.edge_softmax(g, F_.leaky_relu(ops.gsddmm(g, "add", el, er), 0.2))
+    assert float((fused - chain).abs().max()) < 1e-6
+    ft, dz = torch.randn(n, H, F, device=DEV), torch.randn(n, H, F, device=DEV)
+    a = torch.rand(E, H, 1, device=DEV)
+    for graph in (g, g.formats(["csr", "csc"])):                      # COO walk, then the CSR-walk head-dot kernel
+        lhs = (ops.gspmm(graph, "mul", "sum", ft, a).double() * dz.double()).sum()
+        rhs = (a.double() * ops.gsddmm(graph, "dot", ft, dz).double()).sum()
+        assert abs(float(lhs - rhs)) < 1e-6 * float(lhs.abs().clamp(min=1.0)) * 10
+    csc, csr = g._index.csc(), g._index.csr()
+    t = sparse.csr_transpose(csc)
+    assert torch.equal(t.indptr, csr.indptr) and torch.equal(t.indices, csr.indices) and torch.equal(t.eids, csr.eids)
+    x = torch.rand(spec["n"] * 10, 47, device=DEV)                    # products-sized column sum (2.3 M x 47)
+    got = sparse.backend_for(x).column_sum(x)
+    assert rel(got.double(), x.double().sum(0)) < 1e-6
