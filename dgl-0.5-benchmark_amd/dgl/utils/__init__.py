@@ -1,1 +1,1 @@
-from mi355x_graph.utils import expand_as_pair  # noqa: F401
+from mi355x_graph.utils import expand_as_pair, GraphedStep  # noqa: F401

@@ -185,15 +185,25 @@ def main():
     p.add_argument("--num-layers", type=int, default=2)
     p.add_argument("--num-hidden", type=int, default=16)
     p.add_argument("--device", type=int, default=0)
+    p.add_argument("--hipgraph", action="store_true",
+                   help="capture the training step in a HIP graph and replay it (launch-bound small graphs)")
     args = p.parse_args()
     device = torch.device("cuda:%d" % args.device)
     dur = []
     if args.model == "sage":
         cfg, data, g, model, train_idx, opt = build_sage(args.dataset, device, args.scale)
         print(g)
+        if args.hipgraph:
+            from dgl.utils import GraphedStep
+            opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"], capturable=True)
+            model.train()
+            graphed = GraphedStep(lambda: F.nll_loss(model(g, data.features)[train_idx], data.labels[train_idx]), opt)
         for epoch in range(1, args.epochs + 1):
             t0 = time.time()
-            loss = sage_train_step(model, g, data.features, data.labels, train_idx, opt)
+            if args.hipgraph:
+                loss = graphed().item()
+            else:
+                loss = sage_train_step(model, g, data.features, data.labels, train_idx, opt)
             if epoch >= 3:
                 dur.append(time.time() - t0)
             print("epoch %d loss %.4f time %.4f" % (epoch, loss, time.time() - t0))
@@ -206,9 +216,18 @@ def main():
         model = GAT(g, args.num_layers, data.features.shape[1], args.num_hidden, data.num_classes, heads).to(device)
         opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=2.4e-5)
         loss_fcn = nn.CrossEntropyLoss()
+        if args.hipgraph:
+            from dgl.utils import GraphedStep
+            opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=2.4e-5, capturable=True)
+            train_idx = torch.nonzero(data.train_mask).flatten()  # boolean-mask indexing synchronises; an index does not
+            model.train()
+            graphed = GraphedStep(lambda: loss_fcn(model(data.features)[train_idx], data.labels[train_idx]), opt)
         for epoch in range(args.epochs):
             t0 = time.time()
-            loss = gat_train_step(model, data.features, data.labels, data.train_mask, opt, loss_fcn)
+            if args.hipgraph:
+                loss = graphed().item()
+            else:
+                loss = gat_train_step(model, data.features, data.labels, data.train_mask, opt, loss_fcn)
             if epoch >= 3:
                 dur.append(time.time() - t0)
             print("epoch %d loss %.4f time %.4f" % (epoch, loss, time.time() - t0))

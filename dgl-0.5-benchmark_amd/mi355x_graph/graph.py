@@ -210,6 +210,13 @@ class GraphIndex(object):
         _, dst = self.coo()
         return torch.bincount(dst.long(), minlength=self.num_dst).to(self.idtype)
 
+    def has_zero_in_degree(self):
+        """Cached (the structure is immutable): GATConv / GraphConv ask this on every forward; answering from the cache
+        keeps a host synchronisation out of the training step (and lets the step be captured in a HIP graph)."""
+        if getattr(self, "_zero_in_deg", None) is None:
+            self._zero_in_deg = bool((self.in_degrees() == 0).any()) if self.num_dst else False
+        return self._zero_in_deg
+
     def out_degrees(self):
         if self._csr is not None or self._hidden_csr is not None or self.device.type != "cpu":
             return self.csr().degrees()

@@ -16,6 +16,13 @@ from . import ops
 from .utils import expand_as_pair
 
 
+def _has_zero_in_degree(graph):
+    index = getattr(graph, "_index", None)
+    if index is not None and hasattr(index, "has_zero_in_degree"):
+        return index.has_zero_in_degree()
+    return bool((graph.in_degrees() == 0).any())
+
+
 class Linear(nn.Linear):
     """torch.nn.Linear (same parameters, init and state_dict) whose bias gradient runs in the library's column-sum kernel."""
 
@@ -80,7 +87,7 @@ class GATConv(nn.Module):
     def forward(self, graph, feat, get_attention=False):
         with graph.local_scope():
             if not self._allow_zero_in_degree:
-                if bool((graph.in_degrees() == 0).any()):
+                if _has_zero_in_degree(graph):
                     raise DGLError(
                         "There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
                         "This is harmful for some applications, causing silent performance regression. "
@@ -231,7 +238,7 @@ class GraphConv(nn.Module):
 
     def forward(self, graph, feat, weight=None):
         with graph.local_scope():
-            if not self._allow_zero_in_degree and bool((graph.in_degrees() == 0).any()):
+            if not self._allow_zero_in_degree and _has_zero_in_degree(graph):
                 raise DGLError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
                                "Adding self-loop on the input graph by calling `g = dgl.add_self_loop(g)` will "
                                "resolve the issue. Setting ``allow_zero_in_degree`` to be `True` when constructing "
