@@ -103,7 +103,7 @@ def _worker(rank, world, port, q, device="cpu", batch_norm=False):
     dist.destroy_process_group()
 
 
-def _run_two_way(device, batch_norm=False):
+def _run_two_way(device, batch_norm=False, world=2):
     if device == "cpu":
         oracle_backend.install()
     try:
@@ -114,10 +114,11 @@ def _run_two_way(device, batch_norm=False):
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000 + (7 if device != "cpu" else 0)
     port += 11 if batch_norm else 0
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, device, batch_norm)) for r in range(2)]
+    port += 23 * (world - 2)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, device, batch_norm)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=240) for _ in range(2)]
+    res = [q.get(timeout=240) for _ in range(world)]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -144,6 +145,12 @@ def _run_two_way(device, batch_norm=False):
 @pytest.mark.timeout(300)
 def test_two_way_partition_matches_single_process():
     _run_two_way("cpu")
+
+
+@pytest.mark.timeout(300)
+def test_three_way_partition_matches_single_process():
+    """world_size 3: uneven per-peer splits, peers with different halo sizes, the fixed per-peer scatter order."""
+    _run_two_way("cpu", world=3)
 
 
 @pytest.mark.timeout(300)
