@@ -1,0 +1,135 @@
+// xty.hip -- C[M, K] = A^T B for A [n, M], B [n, K] row-major with n in the millions and M, K <= 64 / 128: the weight
+// gradient dW = dY^T X of the dense layer that follows every aggregation (SAGEConv's fc_self / fc_neigh,
+// main_dgl_product_sage.py:31-33,64).  rocBLAS / hipBLASLt run these tall-skinny reductions (K-dim = 2.45 M) at 0.5-1.0 ms;
+// the operands only need to be streamed once (1.6 GB at 64 x 100), so the bound is HBM.
+//
+// fp32 MFMA 16x16x4: the "k" of the instruction runs over data rows.  Lane l supplies A[row0 + l/16][m0 + l%16] and
+// B[row0 + l/16][k0 + l%16] -- both row-major, i.e. operands are loaded straight from global memory in the layout the
+// instruction wants, no LDS staging and no transpose; a wave keeps the whole (M/16) x (K/16) grid of 16x16 accumulators
+// (<= 4 x 8 x 4 = 128 VGPRs) and walks 16 rows per trip.  Every wave writes its partial tile; a second launch adds the
+// partials in wave order (deterministic, no atomics).
+#include "common.h"
+
+namespace mgx {
+
+constexpr int kXtyBlocks = 512;                              // x 4 waves = 2048 partial tiles
+constexpr int kXtyWaves = kXtyBlocks * kWavesPerBlock;
+
+template <int MT, int KT>
+__global__ __launch_bounds__(kBlock) void xty_partial_kernel(int64_t n, int M, int K, const float* __restrict__ A,
+                                                             const float* __restrict__ B, float* __restrict__ part) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t gw = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int c = lane % 16, q = lane / 16;
+  v4f acc[MT][KT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < KT; ++j) acc[i][j] = (v4f)(0.f);
+  bool am[MT], bm[KT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) am[i] = i * 16 + c < M;
+#pragma unroll
+  for (int j = 0; j < KT; ++j) bm[j] = j * 16 + c < K;
+  for (int64_t r0 = gw * 16; r0 < n; r0 += (int64_t)kXtyWaves * 16) {
+    float a[4][MT], b[4][KT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int64_t row = r0 + s * 4 + q;
+      const bool ok = row < n;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[s][i] = (ok && am[i]) ? A[row * M + i * 16 + c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < KT; ++j) b[s][j] = (ok && bm[j]) ? B[row * K + j * 16 + c] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+  }
+  // D[4*(lane/16) + r][lane%16] of every tile -> partial [MT*16][KT*16]
+  float* p = part + gw * (int64_t)(MT * 16) * (KT * 16);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[(i * 16 + 4 * q + r) * (KT * 16) + j * 16 + c] = acc[i][j][r];
+}
+
+// 16 output elements x 16 slices of the partial list per workgroup; slices combined in slice order
+__global__ __launch_bounds__(kBlock) void xty_finish_kernel(int M, int K, int ldm /* KT*16 */, int tile /* MT*16*KT*16 */,
+                                                            const float* __restrict__ part, float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int e = threadIdx.x % 16, sl = threadIdx.x / 16;
+  const int idx = blockIdx.x * 16 + e;  // over M*K
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (idx < M * K) {
+    const int m = idx / K, k = idx % K;
+    const float* p = part + (int64_t)m * ldm + k;
+    constexpr int per = kXtyWaves / 16;
+    for (int w = sl * per; w < (sl + 1) * per; w += 4) {
+      s0 += p[(int64_t)w * tile];
+      s1 += p[(int64_t)(w + 1) * tile];
+      s2 += p[(int64_t)(w + 2) * tile];
+      s3 += p[(int64_t)(w + 3) * tile];
+    }
+  }
+  red[sl][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && idx < M * K) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i][e];
+    out[idx] = s;
+  }
+}
+
+template <int MT>
+static bool launch_xty_kt(int kt, int64_t n, int M, int K, const float* A, const float* B, float* part, hipStream_t s) {
+  switch (kt) {
+#define MGX_XTY(J) case J: hipLaunchKernelGGL((xty_partial_kernel<MT, J>), dim3(kXtyBlocks), dim3(kBlock), 0, s, n, M, K, A, B, part); return true;
+    MGX_XTY(1) MGX_XTY(2) MGX_XTY(3) MGX_XTY(4) MGX_XTY(5) MGX_XTY(6) MGX_XTY(7) MGX_XTY(8)
+#undef MGX_XTY
+    default: return false;
+  }
+}
+
+}  // namespace mgx
+
+extern "C" int64_t mgx_xty_workspace(int64_t M, int64_t K) {
+  const int64_t mt = (M + 15) / 16, kt = (K + 15) / 16;
+  if (M < 1 || K < 1 || mt > 4 || kt > 8) return -1;
+  return (int64_t)mgx::kXtyWaves * mt * 16 * kt * 16 * (int64_t)sizeof(float);
+}
+
+extern "C" int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, const float* b, float* out, void* workspace,
+                           void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(n >= 0 && M >= 1 && K >= 1, "mgx_xty: bad sizes");
+  const int mt = (int)((M + 15) / 16), kt = (int)((K + 15) / 16);
+  if (mt > 4 || kt > 8) MGX_UNSUPPORTED("mgx_xty: needs M <= 64 and K <= 128 (got %lld x %lld)", (long long)M, (long long)K);
+  MGX_CHECK_ARG(out != nullptr, "mgx_xty: out is NULL");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    MGX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)(M * K) * sizeof(float), s));
+    return MGX_OK;
+  }
+  MGX_CHECK_ARG(a && b && workspace, "mgx_xty: NULL pointer");
+  float* part = (float*)workspace;
+  bool ok = false;
+  switch (mt) {
+    case 1: ok = launch_xty_kt<1>(kt, n, (int)M, (int)K, a, b, part, s); break;
+    case 2: ok = launch_xty_kt<2>(kt, n, (int)M, (int)K, a, b, part, s); break;
+    case 3: ok = launch_xty_kt<3>(kt, n, (int)M, (int)K, a, b, part, s); break;
+    default: ok = launch_xty_kt<4>(kt, n, (int)M, (int)K, a, b, part, s); break;
+  }
+  MGX_CHECK_ARG(ok, "mgx_xty: no kernel for this tile shape");
+  MGX_CHECK_LAUNCH();
+  hipLaunchKernelGGL(xty_finish_kernel, dim3((unsigned)((M * K + 15) / 16)), dim3(kBlock), 0, s, (int)M, (int)K, kt * 16,
+                     mt * 16 * kt * 16, (const float*)part, out);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}

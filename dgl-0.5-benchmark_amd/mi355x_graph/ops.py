@@ -9,6 +9,8 @@ graph (out-CSR), dE is an SDDMM, etc.  `mean` is fused: the forward kernel divid
 max(in_degree, 1) and the backward SpMM scales the gathered rows by the same factor, instead of
 DGL's separate elementwise divide.
 """
+import os
+
 import torch
 
 from ._lib import DGLError
@@ -300,7 +302,13 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = (dy2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
-            dw = dy2.t() @ x.reshape(-1, x.shape[-1])
+            x2 = x.reshape(-1, x.shape[-1])
+            be = sparse.backend_for(dy2)
+            if (x2.shape[0] >= be.XTY_MIN_ROWS and dy2.shape[1] <= be.XTY_MAX[0] and x2.shape[1] <= be.XTY_MAX[1]
+                    and os.environ.get("MGX_LINEAR_XTY", "1") == "1"):
+                dw = be.xty(dy2.contiguous(), x2.contiguous())  # millions of rows, <= 64 x 128 outputs: streamed once
+            else:
+                dw = dy2.t() @ x2
         if ctx.needs_input_grad[2]:
             db = sparse.backend_for(dy2).column_sum(dy2.contiguous())
         return dx, dw, db
@@ -335,9 +343,10 @@ def bias_add(x, bias):
 
 
 def linear(x, weight, bias=None):
-    """torch.nn.functional.linear whose bias gradient is computed by the library (float32 HIP tensors, <= 256 outputs)."""
-    if (bias is None or not bias.requires_grad or x.dtype != torch.float32 or x.device.type not in sparse._BACKENDS
-            or weight.shape[0] > sparse.backend_for(x).COLUMN_SUM_MAX):
+    """torch.nn.functional.linear whose bias gradient (column sum) and tall-skinny weight gradient (dY^T X) are computed
+    by the library (float32 HIP tensors; <= 256 outputs with a bias)."""
+    if (x.dtype != torch.float32 or x.device.type not in sparse._BACKENDS or not torch.is_grad_enabled()
+            or (bias is not None and weight.shape[0] > sparse.backend_for(x).COLUMN_SUM_MAX)):
         return torch.nn.functional.linear(x, weight, bias)
     return LinearFn.apply(x, weight, bias)
 

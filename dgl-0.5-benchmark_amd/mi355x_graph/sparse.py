@@ -381,6 +381,19 @@ class HipBackend(object):
         return out, arg
 
     COLUMN_SUM_MAX = 256
+    XTY_MAX = (64, 128)       # mgx_xty: a^T b with a [n, M <= 64], b [n, K <= 128]
+    XTY_MIN_ROWS = 1 << 16    # shorter reductions stay with the GEMM library
+
+    def xty(self, a2d, b2d):
+        """a2d [n, M], b2d [n, K] -> a^T b [M, K] (the tall-skinny weight-gradient product)."""
+        dev = self._check_dev(a2d, b2d)
+        n, M = a2d.shape
+        K = b2d.shape[1]
+        out = torch.empty((M, K), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(_lib.lib().mgx_xty_workspace(M, K), 4) // 4, dtype=torch.float32, device=dev)  # < 0: the call reports why
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_xty(n, M, K, _ptr(a2d), _ptr(b2d), _ptr(out), _ptr(ws), _stream(dev)))
+        return out
 
     def column_sum(self, x2d):
         dev = self._check_dev(x2d)

@@ -224,6 +224,13 @@ int32_t mgx_segment_reduce(int64_t num_segments, const int64_t* offsets, int64_t
 int64_t mgx_column_sum_workspace(int64_t C);
 int32_t mgx_column_sum(int64_t n, int64_t C, const float* x, float* out, void* workspace, void* stream);
 
+/* out[M, K] = a^T b for a [n, M], b [n, K] row-major, M <= 64, K <= 128 (else MGX_ERR_UNSUPPORTED), n in the millions: the
+ * weight gradient dW = dY^T X of the dense layer after an aggregation (main_dgl_product_sage.py:31-33,64).  fp32 MFMA,
+ * operands streamed once, per-wave partial tiles added in fixed order (deterministic); workspace of
+ * mgx_xty_workspace(M, K) bytes (-1 if the shape is unsupported). */
+int64_t mgx_xty_workspace(int64_t M, int64_t K);
+int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, const float* b, float* out, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------ formats (integer, bit-exact)
  * Replace the lazy COO->CSR/CSC construction behind g.formats(...)/first kernel call
  * (main_dgl_product_sage.py:158, kernel/dgl-new.py:63) and g.in_degrees()

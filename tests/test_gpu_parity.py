@@ -595,3 +595,33 @@ def test_head_dot_sddmm_on_csr_walk(oracle, H, F, canonical):
     z = ops.gspmm(gi, "mul", "sum", T(U), a)
     (z * T(V)).sum().backward()
     assert float((a.grad.cpu() - torch.from_numpy(ref)).abs().max()) < RTOL * scale
+
+
+@pytest.mark.parametrize("n,M,K", [(0, 3, 5), (1, 1, 1), (5, 64, 128), (1000, 47, 64), (70001, 64, 100), (300000, 16, 7),
+                                    (123457, 33, 113), (65536, 64, 64)])
+def test_xty_matches_fp64(n, M, K):
+    """mgx_xty (dW = dY^T X with fp32 MFMA) against the fp64 product; every tile-count template and ragged edges."""
+    rng = np.random.default_rng(n + M + K)
+    a = T(rng.standard_normal((n, M)).astype(np.float32))
+    b = T(rng.standard_normal((n, K)).astype(np.float32))
+    got = sparse.backend_for(a).xty(a, b)
+    ref = a.double().t() @ b.double()
+    assert got.shape == (M, K)
+    scale = float((a.double().abs().t() @ b.double().abs()).max()) if n else 1.0
+    assert float((got.double() - ref).abs().max()) <= 1e-5 * max(scale, 1e-30)
+    with pytest.raises(mg.DGLError, match="mgx_xty"):
+        sparse.backend_for(a).xty(torch.zeros(4, 65, device=DEV), torch.zeros(4, 8, device=DEV))
+
+
+def test_linear_weight_grad_through_xty_matches_torch():
+    from mi355x_graph.nn import Linear
+    n = 70000  # >= XTY_MIN_ROWS: the weight gradient takes mgx_xty
+    lin = Linear(100, 47).to(DEV)
+    ref = torch.nn.Linear(100, 47).to(DEV)
+    ref.load_state_dict(lin.state_dict())
+    x = torch.rand(n, 100, device=DEV)
+    w = torch.randn(n, 47, device=DEV)
+    (lin(x) * w).sum().backward()
+    (ref(x) * w).sum().backward()
+    assert float((lin.weight.grad - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < 1e-4
+    assert float((lin.bias.grad - ref.bias.grad).abs().max() / ref.bias.grad.abs().max()) < 1e-4
