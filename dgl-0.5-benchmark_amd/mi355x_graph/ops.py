@@ -302,13 +302,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = (dy2 @ weight).view(x.shape)
         if ctx.needs_input_grad[1]:
-            x2 = x.reshape(-1, x.shape[-1])
-            be = sparse.backend_for(dy2)
-            if (x2.shape[0] >= be.XTY_MIN_ROWS and dy2.shape[1] <= be.XTY_MAX[0] and x2.shape[1] <= be.XTY_MAX[1]
-                    and os.environ.get("MGX_LINEAR_XTY", "1") == "1"):
-                dw = be.xty(dy2.contiguous(), x2.contiguous())  # millions of rows, <= 64 x 128 outputs: streamed once
-            else:
-                dw = dy2.t() @ x2
+            dw = _weight_grad(dy2, x.reshape(-1, x.shape[-1]))
         if ctx.needs_input_grad[2]:
             db = sparse.backend_for(dy2).column_sum(dy2.contiguous())
         return dx, dw, db
@@ -340,6 +334,45 @@ def bias_add(x, bias):
             or x[0].numel() != C or C > sparse.backend_for(x).COLUMN_SUM_MAX):
         return x + bias
     return BiasAdd.apply(x, bias)
+
+
+def _weight_grad(dy2, x2):
+    be = sparse.backend_for(dy2)
+    if (x2.shape[0] >= be.XTY_MIN_ROWS and dy2.shape[1] <= be.XTY_MAX[0] and x2.shape[1] <= be.XTY_MAX[1]
+            and os.environ.get("MGX_LINEAR_XTY", "1") == "1"):
+        return be.xty(dy2.contiguous(), x2.contiguous())  # millions of rows, <= 64 x 128 outputs: streamed once
+    return dy2.t() @ x2
+
+
+class LinearSumFn(torch.autograd.Function):
+    """y = x1 W1^T + x2 W2^T + b in two GEMMs, the second accumulating into the first's output (no separate add pass);
+    gradients as LinearFn.  SAGEConv's `fc_self(h) + fc_neigh(h_neigh)` (main_dgl_product_sage.py:64)."""
+
+    @staticmethod
+    def forward(ctx, x1, w1, x2, w2, bias):
+        ctx.save_for_backward(x1, w1, x2, w2)
+        y = torch.nn.functional.linear(x1, w1, bias)
+        return y.addmm_(x2, w2.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, w1, x2, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        dx1 = dy @ w1 if need[0] else None
+        dw1 = _weight_grad(dy, x1) if need[1] else None
+        dx2 = dy @ w2 if need[2] else None
+        dw2 = _weight_grad(dy, x2) if need[3] else None
+        db = sparse.backend_for(dy).column_sum(dy) if need[4] else None
+        return dx1, dw1, dx2, dw2, db
+
+
+def linear_sum(x1, weight1, x2, weight2, bias=None):
+    """x1 @ weight1.T + x2 @ weight2.T + bias for 2-D float32 HIP tensors (falls back to two F.linear calls otherwise)."""
+    if (x1.dim() != 2 or x2.dim() != 2 or x1.dtype != torch.float32 or x1.device.type not in sparse._BACKENDS
+            or not torch.is_grad_enabled() or (bias is not None and weight1.shape[0] > sparse.backend_for(x1).COLUMN_SUM_MAX)):
+        return torch.nn.functional.linear(x1, weight1) + torch.nn.functional.linear(x2, weight2, bias)
+    return LinearSumFn.apply(x1, weight1, x2, weight2, bias)
 
 
 def linear(x, weight, bias=None):

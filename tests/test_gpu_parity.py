@@ -625,3 +625,27 @@ def test_linear_weight_grad_through_xty_matches_torch():
     (ref(x) * w).sum().backward()
     assert float((lin.weight.grad - ref.weight.grad).abs().max() / ref.weight.grad.abs().max()) < 1e-4
     assert float((lin.bias.grad - ref.bias.grad).abs().max() / ref.bias.grad.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("n", [500, 70000])
+def test_linear_sum_matches_two_linears(n):
+    """ops.linear_sum (SAGEConv's fc_self(h) + fc_neigh(h_neigh) with the add folded into the second GEMM) == the two
+    nn.Linear calls, values and all five gradients (n >= 65536 takes mgx_xty for the weight gradients)."""
+    torch.manual_seed(n)
+    x1 = torch.rand(n, 40, device=DEV, requires_grad=True)
+    x2 = torch.rand(n, 24, device=DEV, requires_grad=True)
+    w1 = torch.randn(17, 40, device=DEV, requires_grad=True)
+    w2 = torch.randn(17, 24, device=DEV, requires_grad=True)
+    b = torch.randn(17, device=DEV, requires_grad=True)
+    g = torch.randn(n, 17, device=DEV)
+    y = ops.linear_sum(x1, w1, x2, w2, b)
+    ref = torch.nn.functional.linear(x1, w1) + torch.nn.functional.linear(x2, w2, b)
+    assert float((y - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    got = torch.autograd.grad((y * g).sum(), [x1, w1, x2, w2, b])
+    want = torch.autograd.grad((ref * g).sum(), [x1, w1, x2, w2, b])
+    for a_, b_ in zip(got, want):
+        assert float((a_ - b_).abs().max()) < 1e-4 * float(b_.abs().max())
+    # without a bias, and when an input needs no gradient
+    y2 = ops.linear_sum(x1.detach(), w1, x2, w2, None)
+    assert float((y2 - (ref - b)).abs().max()) < 1e-4 * float(ref.abs().max())
+    assert torch.autograd.grad(y2.sum(), [w1, x2])[0].shape == w1.shape
