@@ -1,0 +1,88 @@
+// elementwise.hip -- relu followed by (inverted) dropout in one pass each way.
+//
+// Between two aggregations GraphSAGE applies `x = F.relu(x); x = dropout(x)` (main_dgl_product_sage.py:93-95) on an
+// [N, hidden] activation: four PyTorch kernels per layer and direction-pair moving 38 bytes per element (relu r4 w4,
+// dropout r4 w4 + mask, masked_scale r4 r1 w4, threshold_backward r4 r4 w4).  Fused: forward reads x, writes y and 4 mask
+// bits per float4; backward reads dy and the bits, writes dx -- 16.5 bytes per element.  The mask holds relu AND keep, so
+// backward needs neither x nor y.  Random bits: counter-based (splitmix64 of seed and element index), reproducible for a
+// given (seed, offset) whatever the launch shape.
+#include "common.h"
+
+namespace mgx {
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kBlock) void relu_dropout_fwd_kernel(int64_t n4, const v4f* __restrict__ x, v4f* __restrict__ y,
+                                                                  uint8_t* __restrict__ mask, uint32_t drop_below, float scale,
+                                                                  uint64_t seed, uint64_t offset) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const v4f v = __builtin_nontemporal_load(&x[i]);
+    const uint64_t r0 = splitmix64(seed ^ ((offset + (uint64_t)i) * 2));
+    const uint64_t r1 = splitmix64(seed ^ ((offset + (uint64_t)i) * 2 + 1));
+    const bool k0 = (uint32_t)r0 >= drop_below && v.x > 0.f, k1 = (uint32_t)(r0 >> 32) >= drop_below && v.y > 0.f;
+    const bool k2 = (uint32_t)r1 >= drop_below && v.z > 0.f, k3 = (uint32_t)(r1 >> 32) >= drop_below && v.w > 0.f;
+    v4f o;
+    o.x = k0 ? v.x * scale : 0.f;
+    o.y = k1 ? v.y * scale : 0.f;
+    o.z = k2 ? v.z * scale : 0.f;
+    o.w = k3 ? v.w * scale : 0.f;
+    y[i] = o;
+    mask[i] = (uint8_t)((k0 ? 1 : 0) | (k1 ? 2 : 0) | (k2 ? 4 : 0) | (k3 ? 8 : 0));
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(int64_t n4, const v4f* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                                  v4f* __restrict__ dx, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const v4f g = __builtin_nontemporal_load(&dy[i]);
+    const uint8_t m = mask[i];
+    v4f o;
+    o.x = (m & 1) ? g.x * scale : 0.f;
+    o.y = (m & 2) ? g.y * scale : 0.f;
+    o.z = (m & 4) ? g.z * scale : 0.f;
+    o.w = (m & 8) ? g.w * scale : 0.f;
+    dx[i] = o;
+  }
+}
+
+static unsigned ew_grid(int64_t n4) {
+  int64_t b = (n4 + kBlock - 1) / kBlock;
+  if (b > 256 * 32) b = 256 * 32;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+}  // namespace mgx
+
+extern "C" int32_t mgx_relu_dropout_fwd(int64_t n, const float* x, float p, uint64_t seed, uint64_t offset, float* y,
+                                        uint8_t* mask, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(n >= 0 && n % 4 == 0, "mgx_relu_dropout_fwd: the element count must be a multiple of 4 (got %lld)", (long long)n);
+  MGX_CHECK_ARG(p >= 0.f && p < 1.f, "mgx_relu_dropout_fwd: p must be in [0, 1)");
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(x && y && mask && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "mgx_relu_dropout_fwd: NULL or unaligned pointer");
+  const double thr = (double)p * 4294967296.0;
+  const uint32_t drop_below = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+  hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)x, (v4f*)y,
+                     mask, drop_below, 1.f / (1.f - p), seed, offset);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_relu_dropout_bwd(int64_t n, const float* dy, const uint8_t* mask, float p, float* dx, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(n >= 0 && n % 4 == 0, "mgx_relu_dropout_bwd: the element count must be a multiple of 4");
+  MGX_CHECK_ARG(p >= 0.f && p < 1.f, "mgx_relu_dropout_bwd: p must be in [0, 1)");
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(dy && dx && mask && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0, "mgx_relu_dropout_bwd: NULL or unaligned pointer");
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)dy, mask,
+                     (v4f*)dx, 1.f / (1.f - p));
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}

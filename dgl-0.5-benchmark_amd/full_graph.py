@@ -88,8 +88,7 @@ class GraphSAGE(nn.Module):
             x = layer(g, x)
             if len(self.bns):
                 x = self.bns[i](x)
-            x = F.relu(x)
-            x = self.dropout(x)
+            x = ops.relu_dropout(x, self.dropout.p, self.training)  # F.relu + dropout, one pass each way on the device
         x = self.layers[-1](g, x)
         return x.log_softmax(dim=-1)
 

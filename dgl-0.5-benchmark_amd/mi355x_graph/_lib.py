@@ -57,6 +57,8 @@ SIGNATURES = {
     "mgx_head_dot_bwd_workspace": (_i64, [_i64, _i64]),
     "mgx_head_dot_bwd": (_i32, [_i64, _i64, _i64, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),
     "mgx_segment_reduce": (_i32, [_i64, _vp, _i64, _i32, _fp, _fp, _vp, _vp]),
+    "mgx_relu_dropout_fwd": (_i32, [_i64, _fp, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _fp, _vp, _vp]),
+    "mgx_relu_dropout_bwd": (_i32, [_i64, _fp, _vp, ctypes.c_float, _fp, _vp]),
     "mgx_xty_workspace": (_i64, [_i64, _i64]),
     "mgx_xty": (_i32, [_i64, _i64, _i64, _fp, _fp, _fp, _vp, _vp]),
     "mgx_column_sum_workspace": (_i64, [_i64]),

@@ -336,6 +336,35 @@ def bias_add(x, bias):
     return BiasAdd.apply(x, bias)
 
 
+class ReluDropout(torch.autograd.Function):
+    _calls = 0  # advances the counter-based generator: a new mask per call, reproducible after torch.manual_seed
+
+    @staticmethod
+    def forward(ctx, x, p):
+        x = x.contiguous()
+        seed = torch.initial_seed() & (2 ** 64 - 1)
+        offset = (ReluDropout._calls * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
+        ReluDropout._calls += 1
+        y, mask = sparse.backend_for(x).relu_dropout_fwd(x, float(p), seed, offset)
+        ctx.save_for_backward(mask)
+        ctx.p = float(p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        return sparse.backend_for(dy).relu_dropout_bwd(dy.contiguous(), mask, ctx.p), None
+
+
+def relu_dropout(x, p=0.5, training=True):
+    """dropout(relu(x), p) in one pass each way (float32 HIP tensors with numel % 4 == 0; anything else, evaluation mode
+    and HIP-graph capture -- whose replays must draw new masks -- take the two PyTorch ops)."""
+    if (not training or p <= 0.0 or p >= 1.0 or x.dtype != torch.float32 or x.device.type != "cuda" or x.numel() % 4
+            or x.device.type not in sparse._BACKENDS or torch.cuda.is_current_stream_capturing()):
+        return torch.nn.functional.dropout(torch.relu(x), p, training)
+    return ReluDropout.apply(x, p)
+
+
 def _weight_grad(dy2, x2):
     be = sparse.backend_for(dy2)
     if (x2.shape[0] >= be.XTY_MIN_ROWS and dy2.shape[1] <= be.XTY_MAX[0] and x2.shape[1] <= be.XTY_MAX[1]

@@ -380,6 +380,22 @@ class HipBackend(object):
             _lib.check(_lib.lib().mgx_segment_reduce(n, _ptr(offsets), x2d.shape[1], REDUCE[reduce], _ptr(x2d), _ptr(out), _ptr(arg), _stream(dev)))
         return out, arg
 
+    def relu_dropout_fwd(self, x, p, seed, offset):
+        dev = self._check_dev(x)
+        y = torch.empty_like(x)
+        mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_relu_dropout_fwd(x.numel(), _ptr(x), ctypes.c_float(p), ctypes.c_uint64(seed),
+                                                       ctypes.c_uint64(offset), _ptr(y), _ptr(mask), _stream(dev)))
+        return y, mask
+
+    def relu_dropout_bwd(self, dy, mask, p):
+        dev = self._check_dev(dy, mask)
+        dx = torch.empty_like(dy)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_relu_dropout_bwd(dy.numel(), _ptr(dy), _ptr(mask), ctypes.c_float(p), _ptr(dx), _stream(dev)))
+        return dx
+
     COLUMN_SUM_MAX = 256
     XTY_MAX = (64, 128)       # mgx_xty: a^T b with a [n, M <= 64], b [n, K <= 128]
     XTY_MIN_ROWS = 1 << 16    # shorter reductions stay with the GEMM library

@@ -231,6 +231,14 @@ int32_t mgx_column_sum(int64_t n, int64_t C, const float* x, float* out, void* w
 int64_t mgx_xty_workspace(int64_t M, int64_t K);
 int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, const float* b, float* out, void* workspace, void* stream);
 
+/* y = dropout_p(relu(x)) in one pass (inverted dropout: kept values scaled by 1/(1-p)); the activation between two
+ * aggregations (main_dgl_product_sage.py:93-95).  n elements, n % 4 == 0, 16-byte aligned; mask: n/4 bytes, 4 bits per
+ * float4 = (x > 0 AND kept), all that backward needs: dx = mask ? dy/(1-p) : 0.  Random bits are a counter-based function
+ * of (seed, offset + element index): the caller advances `offset` by n between calls. */
+int32_t mgx_relu_dropout_fwd(int64_t n, const float* x, float p, uint64_t seed, uint64_t offset, float* y, uint8_t* mask,
+                             void* stream);
+int32_t mgx_relu_dropout_bwd(int64_t n, const float* dy, const uint8_t* mask, float p, float* dx, void* stream);
+
 /* ------------------------------------------------------------------ formats (integer, bit-exact)
  * Replace the lazy COO->CSR/CSC construction behind g.formats(...)/first kernel call
  * (main_dgl_product_sage.py:158, kernel/dgl-new.py:63) and g.in_degrees()

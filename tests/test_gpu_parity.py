@@ -649,3 +649,34 @@ def test_linear_sum_matches_two_linears(n):
     y2 = ops.linear_sum(x1.detach(), w1, x2, w2, None)
     assert float((y2 - (ref - b)).abs().max()) < 1e-4 * float(ref.abs().max())
     assert torch.autograd.grad(y2.sum(), [w1, x2])[0].shape == w1.shape
+
+
+@pytest.mark.parametrize("p", [0.1, 0.5, 0.9])
+def test_relu_dropout_fused(p):
+    """mgx_relu_dropout_fwd/bwd: y is relu(x)/(1-p) on a kept subset and 0 elsewhere, the kept share of the positive
+    entries is 1-p (binomial bound), backward passes dy/(1-p) exactly where y != 0, consecutive calls draw different
+    masks, evaluation mode is plain relu."""
+    n, d = 40000, 64
+    x = torch.randn(n, d, device=DEV)
+    xr = x.clone().requires_grad_(True)
+    y = ops.relu_dropout(xr, p, True)
+    one = torch.tensor(1.0, dtype=torch.float32)
+    scale = float(one / (one - torch.tensor(p, dtype=torch.float32)))        # 1/(1-p) as the kernel rounds it
+    pos = x > 0
+    kept = y != 0
+    assert bool((kept <= pos).all())                                         # nothing negative survives
+    assert torch.equal(y[kept], x[kept] * scale)                             # kept values: exactly relu(x) / (1 - p)
+    share = float(kept.sum()) / float(pos.sum())
+    sigma = (p * (1 - p) / float(pos.sum())) ** 0.5
+    assert abs(share - (1 - p)) < 6 * sigma
+    # per-column shares too: no structure along either axis
+    col = kept.float().sum(0) / pos.float().sum(0).clamp(min=1)
+    assert float((col - (1 - p)).abs().max()) < 0.03
+    g = torch.randn(n, d, device=DEV)
+    (y * g).sum().backward()
+    assert torch.equal(xr.grad, torch.where(kept, g * scale, torch.zeros_like(g)))
+    y2 = ops.relu_dropout(x, p, True)
+    assert float(((y2 != 0) != kept).float().mean()) > 0.5 * min(p, 1 - p) * 0.5   # a fresh mask
+    assert torch.equal(ops.relu_dropout(x, p, False), torch.relu(x))
+    odd = torch.randn(7, 3, device=DEV)                                       # numel % 4 != 0: the PyTorch path
+    assert ops.relu_dropout(odd, p, True).shape == odd.shape
