@@ -18,6 +18,7 @@ the P-way run computes the same mean loss as the 1-GPU run (main_dgl_product_sag
 import os
 
 import torch
+from torch.autograd.function import once_differentiable
 import torch.distributed as dist
 import torch.nn as nn
 
@@ -307,6 +308,7 @@ class DistCopyU(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dZ):
         plan, comm = ctx.plan, ctx.comm
         dZ = dZ.contiguous()
@@ -342,6 +344,7 @@ class HaloExchange(torch.autograd.Function):
         return full
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, g):
         plan, comm = ctx.plan, ctx.comm
         g = g.contiguous()
@@ -522,6 +525,7 @@ class _GlobalBatchNormFn(torch.autograd.Function):
         return y, mean, var, n
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy, _dm, _dv, _dn):
         xhat, weight, invstd = ctx.saved_tensors
         C = dy.shape[1]

@@ -12,6 +12,7 @@ DGL's separate elementwise divide.
 import os
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from ._lib import DGLError
 from . import sparse
@@ -71,6 +72,7 @@ class GSpMM(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dZ):
         gidx, op, reduce_op = ctx.backward_cache
         X, Y, argX, argY = ctx.saved_tensors
@@ -150,6 +152,7 @@ class GSDDMM(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dZ):
         gidx, op, lt, rt = ctx.backward_cache
         X, Y = ctx.saved_tensors
@@ -200,6 +203,7 @@ class EdgeSoftmax(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, grad_out):
         view = ctx.backward_cache
         out, = ctx.saved_tensors
@@ -220,6 +224,7 @@ class GATAttention(torch.autograd.Function):
         return a.view((a.shape[0],) + tuple(shape))
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, da):
         gidx, slope, shape = ctx.backward_cache
         a, el2, er2 = ctx.saved_tensors
@@ -261,6 +266,7 @@ class HeadDot(torch.autograd.Function):
         return out_a, out_b
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, d_a, d_b):
         feat, a2, b2 = ctx.saved_tensors
         if d_a is None:
@@ -295,6 +301,7 @@ class LinearFn(torch.autograd.Function):
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
@@ -315,6 +322,7 @@ class BiasAdd(torch.autograd.Function):
         return x + bias
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy):
         db = None
         if ctx.needs_input_grad[1]:
@@ -351,6 +359,7 @@ class ReluDropout(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
         return sparse.backend_for(dy).relu_dropout_bwd(dy.contiguous(), mask, ctx.p), None
@@ -384,6 +393,7 @@ class LinearSumFn(torch.autograd.Function):
         return y.addmm_(x2, w2.t())
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy):
         x1, w1, x2, w2 = ctx.saved_tensors
         dy = dy.contiguous()
@@ -422,6 +432,7 @@ class SegmentReduce(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy):
         op, n = ctx.backward_cache
         arg, offsets = ctx.saved_tensors
