@@ -180,7 +180,7 @@ def main():
         total_train = float(train_idx.numel())
     else:
         if rank == 0:
-            assign, part_stats = mdist.partition_nodes(src, dst, n, world)
+            assign, part_stats = mdist.cached_partition(src, dst, n, world)
         else:
             assign = torch.empty(n, dtype=torch.int64, device=device)
         mdist.broadcast(assign, 0)
@@ -192,7 +192,9 @@ def main():
         total_train = float(train_mask.sum())
         mdist.broadcast_parameters(model)
         part_stats.update({"halo_rows": hplan.n_halo, "owned_rows": hplan.n_own, "send_rows": int(sum(hplan.send_splits)),
-                           "local_edges": block.number_of_edges()})
+                           "local_edges": block.number_of_edges(),
+                           "halo_bytes_per_exchange": {"D=%d" % d: hplan.n_halo * d * 4 for d in (spec["feat"], cfg["hidden"])},
+                           "exchanges_per_epoch": "2 forward (layer-1 input halo is resident) + 2 backward"})
     del src, dst
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
 
@@ -250,7 +252,9 @@ def main():
         roofline = {"bound": "hbm", "kernel": "mgx::spmm_rowwave32_kernel<4,16,copy_lhs> (copy_u/sum, D=%d)" % D,
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(avg * 1e3, 4),
+                    "algorithmic_bytes_per_launch": int(algo),
+                    "no_reuse_gather_bytes_per_launch": int(algo - 4 * r0["n_cols"] * D + 4 * r0["nnz"] * D),
+                    "avg_launch_ms": round(avg * 1e3, 4),
                     "launches_timed": len(durs), "rows": r0["n_rows"], "nnz": r0["nnz"]}
 
     epoch = elapsed / args.steps

@@ -93,6 +93,33 @@ def partition_nodes(src, dst, num_nodes, num_parts, rounds=5, clusters=None):
     return assign, {"edge_cut": cut, "num_clusters": int(uniq.shape[0])}
 
 
+def cached_partition(src, dst, num_nodes, num_parts, cache_dir=None, **kwargs):
+    """partition_nodes with the result kept on disk, as the reference caches its METIS partitions
+    (cluster-sage/dgl/sampler.py:34-41): `<cache_dir>/partition_n<N>_e<E>_p<P>_<fingerprint>.pt`.  The fingerprint is a
+    checksum of the edge list, so a different graph of the same size never reuses a stale file."""
+    cache_dir = cache_dir or os.environ.get("MGX_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "mi355x_graph")
+    mix = (src.long() * 1000003 + dst.long() * 7919) % 2147483629
+    finger = int(mix.sum().item()) % (1 << 61)
+    path = os.path.join(cache_dir, "partition_n%d_e%d_p%d_%x.pt" % (num_nodes, src.shape[0], num_parts, finger))
+    if os.path.exists(path):
+        try:
+            blob = torch.load(path, map_location=src.device)
+            if blob["assign"].shape[0] == num_nodes:
+                stats = dict(blob["stats"], cached=True)
+                return blob["assign"].to(src.device), stats
+        except Exception:  # unreadable cache: recompute
+            pass
+    assign, stats = partition_nodes(src, dst, num_nodes, num_parts, **kwargs)
+    try:
+        os.makedirs(cache_dir, exist_ok=True)
+        tmp = path + ".tmp%d" % os.getpid()
+        torch.save({"assign": assign.cpu(), "stats": stats}, tmp)
+        os.replace(tmp, path)
+    except OSError:
+        pass  # read-only location: run without the cache
+    return assign, dict(stats, cached=False)
+
+
 def _refine(assign, src, dst, node_w, num_parts, slack, sweeps=4):
     """Balanced label-propagation refinement at node level: a node moves to the part holding most of
     its neighbours when that reduces the cut and the target part has room (heaviest gains first)."""

@@ -277,3 +277,17 @@ def test_metis_partition_api_for_cluster_gcn():
     assert g.in_degree(0) == int((dst == 0).sum()) and g.out_degree(0) == int((src == 0).sum())
     fs, fd = g.find_edges(0)
     assert int(fs[0]) == int(src[0]) and int(fd[0]) == int(dst[0])
+
+
+def test_cached_partition_roundtrip(tmp_path):
+    """mdist.cached_partition: second call comes from disk and is identical; another graph of the same size does not."""
+    from mi355x_graph.datasets import synthetic_edges
+    n = 3000
+    src, dst = synthetic_edges(n, 20000, 100, seed=1, symmetric=True)
+    a1, s1 = mdist.cached_partition(src, dst, n, 4, cache_dir=str(tmp_path))
+    a2, s2 = mdist.cached_partition(src, dst, n, 4, cache_dir=str(tmp_path))
+    assert s1["cached"] is False and s2["cached"] is True and torch.equal(a1, a2)
+    assert abs(s1["edge_cut"] - s2["edge_cut"]) < 1e-12
+    src2, dst2 = synthetic_edges(n, 20000, 100, seed=2, symmetric=True)
+    _, s3 = mdist.cached_partition(src2[:src.shape[0]], dst2[:src.shape[0]], n, 4, cache_dir=str(tmp_path))
+    assert s3["cached"] is False
