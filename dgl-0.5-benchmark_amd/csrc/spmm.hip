@@ -606,8 +606,14 @@ static void launch_fast_v(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s
   while (G < lanes && G < kWave) G <<= 1;
   const int NB = kWave / G;
   const double avg_deg = a.n_rows > 0 ? (double)nnz / (double)a.n_rows : 0.0;
-  // One row per wave when rows are long enough to feed all NB lane groups, else one row per group.
-  const bool split = (NB == 1) || (avg_deg >= 2.0 * NB);
+  // One row per wave (lane groups share the row's edges) or one row per lane group.  The lean int32 kernel is faster
+  // than the row-per-group kernel at every degree measured (arxiv-shaped, avg in-degree 6.9: D = 64 187 -> 108 us, D = 8
+  // 148 -> 82 us; cora / pubmed 40-54 -> 22-26 us), so it is always taken when eligible; the 64-bit kernels keep the old
+  // rule (rows long enough to feed all NB lane groups).  MGX_SPLIT_FACTOR overrides the factor for A/B runs.
+  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.D * 4 < (int64_t(1) << 32) && getenv("MGX_SPMM_V1") == nullptr;
+  static const double env_factor = getenv("MGX_SPLIT_FACTOR") ? atof(getenv("MGX_SPLIT_FACTOR")) : -1.0;
+  const double split_factor = env_factor >= 0.0 ? env_factor : (lean ? 0.0 : 2.0);
+  const bool split = (NB == 1) || (avg_deg >= split_factor * NB);
   switch (G) {
     case 1: launch_fast_g<Idx, VEC, 1, MODE>(a, split, s); break;
     case 2: launch_fast_g<Idx, VEC, 2, MODE>(a, split, s); break;
