@@ -28,6 +28,7 @@ RUNS = [  # name, launcher, arguments (reference script each one stands for)
                                      "--num-hidden", "16", "--epochs", "20"]),                            # main_dgl_reddit_gat.py
     ("sage_products", "full_graph.py", ["--model", "sage", "--dataset", "products", "--epochs", "20"]),  # main_dgl_product_sage.py
     ("gcn_molhiv", "graph_classification.py", ["--epochs", "3"]),                                         # main_dgl_molhiv_gcn.py
+    ("gin_molhiv", "graph_classification.py", ["--model", "gin", "--epochs", "3"]),                       # BASELINE config 5 wording
     ("ns_sage_reddit", "sampling_sage.py", ["--num-epochs", "8"]),                                        # reddit/ns-sage-dgl.py
     ("gcmc_ml-1m", "link_prediction.py", ["--data_name", "ml-1m", "--train_max_iter", "30"]),             # gcmc_dgl/train.py
 ]

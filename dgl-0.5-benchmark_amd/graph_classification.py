@@ -84,6 +84,31 @@ class GCN(nn.Module):
         return self.graph_pred_fc(self.readout(g, x))
 
 
+class GIN(nn.Module):
+    """5-layer GIN (BASELINE.json config 5 as worded): h <- MLP((1 + eps) h + sum_{u->v} h_u) with dgl.nn.GINConv, i.e. one
+    copy_u/sum g-SpMM per layer on the batched graph; atom encoder, BatchNorm / relu / dropout and the mean readout as in
+    the GCN above.  Bond features are not used (plain GIN)."""
+
+    def __init__(self, emb_dim, num_classes, num_layers, dropout, atom_columns=9):
+        super(GIN, self).__init__()
+        from dgl.nn.pytorch import GINConv
+        self.atom_encoder = CategoricalEncoder(emb_dim, atom_columns)
+        mlp = lambda: nn.Sequential(nn.Linear(emb_dim, 2 * emb_dim), nn.BatchNorm1d(2 * emb_dim), nn.ReLU(),
+                                    nn.Linear(2 * emb_dim, emb_dim))
+        self.layers = nn.ModuleList([GINConv(mlp(), "sum", learn_eps=True) for _ in range(num_layers)])
+        self.bns = nn.ModuleList([nn.BatchNorm1d(emb_dim) for _ in range(num_layers - 1)])
+        self.dropout = nn.Dropout(p=dropout)
+        self.readout = dgl.nn.AvgPooling()
+        self.graph_pred_fc = nn.Linear(emb_dim, num_classes, bias=False)
+
+    def forward(self, g, atom, bond=None):
+        x = self.atom_encoder(atom)
+        for i, layer in enumerate(self.layers[:-1]):
+            x = self.dropout(F.relu(self.bns[i](layer(g, x))))
+        x = self.layers[-1](g, x)
+        return self.graph_pred_fc(self.readout(g, x))
+
+
 def train_epoch(model, device, loader, optimizer, loss_fn):
     model.train()
     loss = None
@@ -107,12 +132,14 @@ def main():
     p.add_argument("--num_graphs", type=int, default=32901)
     p.add_argument("--epochs", type=int, default=4)
     p.add_argument("--num_workers", type=int, default=0)
+    p.add_argument("--model", default="gcn", choices=["gcn", "gin"],
+                   help="gcn: the reference's main_dgl_molhiv_gcn.py model; gin: BASELINE.json's wording of config 5")
     args = p.parse_args()
     from mi355x_graph.datasets import molhiv_like
     device = torch.device("cuda:%d" % args.device)
     data = molhiv_like(args.num_graphs)
     loader = GraphDataLoader(data, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
-    model = GCN(args.emb_dim, 1, args.num_layers, 0.5).to(device)
+    model = (GCN if args.model == "gcn" else GIN)(args.emb_dim, 1, args.num_layers, 0.5).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=0.001)
     loss_fn = nn.BCEWithLogitsLoss()
     dur = []

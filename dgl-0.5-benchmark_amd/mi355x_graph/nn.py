@@ -275,6 +275,37 @@ class GraphConv(nn.Module):
             return rst
 
 
+class GINConv(nn.Module):
+    """dgl.nn.pytorch.GINConv (UPSTREAM): h_v = f((1 + eps) h_v + AGG_{u->v} h_u), AGG = sum | mean | max -- a builtin
+    copy_u aggregation (one g-SpMM) followed by `apply_func`.  BASELINE.json names "5-layer GIN on ogbg-molhiv" for the
+    batched many-small-graphs path; the reference's own molhiv script is the GCN of graph_classification.py."""
+
+    def __init__(self, apply_func=None, aggregator_type="sum", init_eps=0, learn_eps=False):
+        super(GINConv, self).__init__()
+        if aggregator_type not in ("sum", "max", "mean"):
+            raise KeyError("Aggregator type {} not recognized.".format(aggregator_type))
+        self.apply_func = apply_func
+        self._reducer = getattr(fn, aggregator_type)
+        if learn_eps:
+            self.eps = nn.Parameter(torch.FloatTensor([init_eps]))
+        else:
+            self.register_buffer("eps", torch.FloatTensor([init_eps]))
+
+    def forward(self, graph, feat, edge_weight=None):
+        with graph.local_scope():
+            feat_src, feat_dst = expand_as_pair(feat, graph)
+            graph.srcdata["h"] = feat_src
+            if edge_weight is not None:
+                graph.edata["_edge_weight"] = edge_weight
+                graph.update_all(fn.u_mul_e("h", "_edge_weight", "m"), self._reducer("m", "neigh"))
+            else:
+                graph.update_all(fn.copy_u("h", "m"), self._reducer("m", "neigh"))
+            rst = (1 + self.eps) * feat_dst + graph.dstdata["neigh"]
+            if self.apply_func is not None:
+                rst = self.apply_func(rst)
+            return rst
+
+
 def _hetero_aggregate(name):
     if callable(name):
         return name

@@ -217,3 +217,30 @@ def test_hip_graph_captured_training_step_matches_eager():
         losses_g = [float(step()) for _ in range(6)]
         assert np.allclose(losses_g, losses_e[warm:], rtol=2e-4), (name, losses_g, losses_e[warm:])
         assert losses_g[-1] < losses_g[0]
+
+
+def test_ginconv_matches_dense_formulation():
+    """dgl.nn.GINConv: (1 + eps) h_v + sum / mean / max over in-neighbours, then the apply function; gradients reach eps."""
+    from mi355x_graph.nn import GINConv
+    n, nnz, D = 400, 3000, 12
+    src, dst = random_graph(n, n, nnz, seed=8)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().to("cuda:0")
+    x = torch.randn(n, D, device="cuda:0")
+    A = torch.zeros(n, n, dtype=torch.float64, device="cuda:0")
+    A.index_put_((torch.from_numpy(dst).cuda(), torch.from_numpy(src).cuda()), torch.ones(nnz, dtype=torch.float64, device="cuda:0"), accumulate=True)
+    lin = torch.nn.Linear(D, 5).to("cuda:0")
+    for agg in ("sum", "mean"):
+        conv = GINConv(lin, agg, init_eps=0.3, learn_eps=True).to("cuda:0")
+        out = conv(g, x)
+        neigh = A @ x.double()
+        if agg == "mean":
+            neigh = neigh / A.sum(1, keepdim=True).clamp(min=1)
+        ref = lin((1.3 * x.double() + neigh).float())
+        assert nerr(out, ref) < 1e-4
+        out.sum().backward()
+        assert conv.eps.grad is not None and float(conv.eps.grad.abs()) > 0
+    out = GINConv(None, "max").to("cuda:0")(g, x)
+    dense = torch.where(A.bool().unsqueeze(-1), x.unsqueeze(0).expand(n, n, D), torch.full((1, 1, 1), -float("inf"), device="cuda:0"))
+    mx = dense.max(1)[0]
+    mx = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)
+    assert nerr(out, x + mx) < 1e-5
