@@ -107,3 +107,11 @@ def test_gcmc_script_runs_unmodified(tmp_path):
               "--train_max_iter", "8", "--gcn_agg_units", "50", "--gcn_out_units", "10", "--save_dir", str(tmp_path / "log"),
               "--device", "-1", DGL_DOWNLOAD_DIR=str(tmp_path))
     assert "Best Iter Idx" in out and "Val RMSE" in out, out[-1500:]
+
+
+@pytest.mark.timeout(900)
+def test_kernel_benchmark_script_runs_unmodified():
+    """BASELINE config 0 / SURVEY 8a1: the reference's own kernel/dgl-new.py (dgl.ops.gspmm sweep over hidden sizes on the
+    reddit / arxiv / proteins graphs) on CPU tensors; its utils.py needs torch_sparse only for the PyG path (stubbed)."""
+    out = run("dgl-new.py", "--gpu", "-1", root="/root/reference/kernel", MGX_DATASET_SCALE="0.002")
+    assert out.count("SPMM") == 3 and out.count("hidden size: 128, avg time:") == 3 and "OOM" not in out, out[-1500:]
