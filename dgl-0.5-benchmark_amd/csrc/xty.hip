@@ -16,8 +16,8 @@ constexpr int kXtyBlocks = 512;                              // x 4 waves = 2048
 constexpr int kXtyWaves = kXtyBlocks * kWavesPerBlock;
 
 template <int MT, int KT>
-__global__ __launch_bounds__(kBlock) void xty_partial_kernel(int64_t n, int M, int K, const float* __restrict__ A,
-                                                             const float* __restrict__ B, float* __restrict__ part) {
+__global__ __launch_bounds__(kBlock) void xty_partial_kernel(int64_t n, int M, int K, const float* __restrict__ A, int64_t lda,
+                                                             const float* __restrict__ B, int64_t ldb, float* __restrict__ part) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t gw = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
   const int c = lane % 16, q = lane / 16;
@@ -38,9 +38,9 @@ __global__ __launch_bounds__(kBlock) void xty_partial_kernel(int64_t n, int M, i
       const int64_t row = r0 + s * 4 + q;
       const bool ok = row < n;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[s][i] = (ok && am[i]) ? A[row * M + i * 16 + c] : 0.f;
+      for (int i = 0; i < MT; ++i) a[s][i] = (ok && am[i]) ? A[row * lda + i * 16 + c] : 0.f;
 #pragma unroll
-      for (int j = 0; j < KT; ++j) b[s][j] = (ok && bm[j]) ? B[row * K + j * 16 + c] : 0.f;
+      for (int j = 0; j < KT; ++j) b[s][j] = (ok && bm[j]) ? B[row * ldb + j * 16 + c] : 0.f;
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kBlock) void xty_partial_kernel(int64_t n, int M, i
 
 // 16 output elements x 16 slices of the partial list per workgroup; slices combined in slice order
 __global__ __launch_bounds__(kBlock) void xty_finish_kernel(int M, int K, int ldm /* KT*16 */, int tile /* MT*16*KT*16 */,
-                                                            const float* __restrict__ part, float* __restrict__ out) {
+                                                            const float* __restrict__ part, float* __restrict__ out, int64_t ldc) {
   __shared__ float red[16][17];
   const int e = threadIdx.x % 16, sl = threadIdx.x / 16;
   const int idx = blockIdx.x * 16 + e;  // over M*K
@@ -82,14 +82,15 @@ __global__ __launch_bounds__(kBlock) void xty_finish_kernel(int M, int K, int ld
   if (sl == 0 && idx < M * K) {
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += red[i][e];
-    out[idx] = s;
+    out[(int64_t)(idx / K) * ldc + idx % K] = s;
   }
 }
 
 template <int MT>
-static bool launch_xty_kt(int kt, int64_t n, int M, int K, const float* A, const float* B, float* part, hipStream_t s) {
+static bool launch_xty_kt(int kt, int64_t n, int M, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* part,
+                          hipStream_t s) {
   switch (kt) {
-#define MGX_XTY(J) case J: hipLaunchKernelGGL((xty_partial_kernel<MT, J>), dim3(kXtyBlocks), dim3(kBlock), 0, s, n, M, K, A, B, part); return true;
+#define MGX_XTY(J) case J: hipLaunchKernelGGL((xty_partial_kernel<MT, J>), dim3(kXtyBlocks), dim3(kBlock), 0, s, n, M, K, A, lda, B, ldb, part); return true;
     MGX_XTY(1) MGX_XTY(2) MGX_XTY(3) MGX_XTY(4) MGX_XTY(5) MGX_XTY(6) MGX_XTY(7) MGX_XTY(8)
 #undef MGX_XTY
     default: return false;
@@ -104,32 +105,34 @@ extern "C" int64_t mgx_xty_workspace(int64_t M, int64_t K) {
   return (int64_t)mgx::kXtyWaves * mt * 16 * kt * 16 * (int64_t)sizeof(float);
 }
 
-extern "C" int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, const float* b, float* out, void* workspace,
-                           void* stream) {
+extern "C" int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* out,
+                           int64_t ldc, void* workspace, void* stream) {
   using namespace mgx;
   MGX_ENTER();
   MGX_CHECK_ARG(n >= 0 && M >= 1 && K >= 1, "mgx_xty: bad sizes");
   const int mt = (int)((M + 15) / 16), kt = (int)((K + 15) / 16);
   if (mt > 4 || kt > 8) MGX_UNSUPPORTED("mgx_xty: needs M <= 64 and K <= 128 (got %lld x %lld)", (long long)M, (long long)K);
   MGX_CHECK_ARG(out != nullptr, "mgx_xty: out is NULL");
+  MGX_CHECK_ARG(lda >= M && ldb >= K && ldc >= K, "mgx_xty: leading dimensions smaller than the tile (lda %lld, ldb %lld, ldc %lld)",
+                (long long)lda, (long long)ldb, (long long)ldc);
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
-    MGX_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)(M * K) * sizeof(float), s));
+    MGX_CHECK_HIP(hipMemset2DAsync(out, (size_t)ldc * sizeof(float), 0, (size_t)K * sizeof(float), (size_t)M, s));
     return MGX_OK;
   }
   MGX_CHECK_ARG(a && b && workspace, "mgx_xty: NULL pointer");
   float* part = (float*)workspace;
   bool ok = false;
   switch (mt) {
-    case 1: ok = launch_xty_kt<1>(kt, n, (int)M, (int)K, a, b, part, s); break;
-    case 2: ok = launch_xty_kt<2>(kt, n, (int)M, (int)K, a, b, part, s); break;
-    case 3: ok = launch_xty_kt<3>(kt, n, (int)M, (int)K, a, b, part, s); break;
-    default: ok = launch_xty_kt<4>(kt, n, (int)M, (int)K, a, b, part, s); break;
+    case 1: ok = launch_xty_kt<1>(kt, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
+    case 2: ok = launch_xty_kt<2>(kt, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
+    case 3: ok = launch_xty_kt<3>(kt, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
+    default: ok = launch_xty_kt<4>(kt, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
   }
   MGX_CHECK_ARG(ok, "mgx_xty: no kernel for this tile shape");
   MGX_CHECK_LAUNCH();
   hipLaunchKernelGGL(xty_finish_kernel, dim3((unsigned)((M * K + 15) / 16)), dim3(kBlock), 0, s, (int)M, (int)K, kt * 16,
-                     mt * 16 * kt * 16, (const float*)part, out);
+                     mt * 16 * kt * 16, (const float*)part, out, ldc);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

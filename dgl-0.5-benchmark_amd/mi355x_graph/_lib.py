@@ -60,7 +60,7 @@ SIGNATURES = {
     "mgx_relu_dropout_fwd": (_i32, [_i64, _fp, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _fp, _vp, _vp]),
     "mgx_relu_dropout_bwd": (_i32, [_i64, _fp, _vp, ctypes.c_float, _fp, _vp]),
     "mgx_xty_workspace": (_i64, [_i64, _i64]),
-    "mgx_xty": (_i32, [_i64, _i64, _i64, _fp, _fp, _fp, _vp, _vp]),
+    "mgx_xty": (_i32, [_i64, _i64, _i64, _fp, _i64, _fp, _i64, _fp, _i64, _vp, _vp]),
     "mgx_column_sum_workspace": (_i64, [_i64]),
     "mgx_column_sum": (_i32, [_i64, _i64, _fp, _fp, _vp, _vp]),
     "mgx_coo_to_csr_workspace": (_i64, [_i64, _i64, _i32]),

@@ -397,7 +397,8 @@ class HipBackend(object):
         return dx
 
     COLUMN_SUM_MAX = 256
-    XTY_MAX = (64, 128)       # mgx_xty: a^T b with a [n, M <= 64], b [n, K <= 128]
+    XTY_TILE = (64, 128)      # one mgx_xty call: a^T b with a [n, <= 64], b [n, <= 128]
+    XTY_MAX = (256, 512)      # wider products are tiled through the leading dimensions (every operand re-read per tile)
     XTY_MIN_ROWS = 1 << 16    # shorter reductions stay with the GEMM library
 
     def xty(self, a2d, b2d):
@@ -405,10 +406,18 @@ class HipBackend(object):
         dev = self._check_dev(a2d, b2d)
         n, M = a2d.shape
         K = b2d.shape[1]
+        if M > self.XTY_MAX[0] or K > self.XTY_MAX[1]:
+            raise DGLError("mgx_xty: at most %d x %d outputs, got %d x %d" % (self.XTY_MAX + (M, K)))
+        tm, tk = self.XTY_TILE
         out = torch.empty((M, K), dtype=torch.float32, device=dev)
-        ws = torch.empty(max(_lib.lib().mgx_xty_workspace(M, K), 4) // 4, dtype=torch.float32, device=dev)  # < 0: the call reports why
+        L = _lib.lib()
+        ws = torch.empty(max(L.mgx_xty_workspace(min(M, tm), min(K, tk)), 4) // 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_xty(n, M, K, _ptr(a2d), _ptr(b2d), _ptr(out), _ptr(ws), _stream(dev)))
+            for m0 in range(0, max(M, 1), tm):
+                for k0 in range(0, max(K, 1), tk):
+                    a_t, b_t, o_t = a2d[:, m0:m0 + tm], b2d[:, k0:k0 + tk], out[m0:m0 + tm, k0:k0 + tk]
+                    _lib.check(L.mgx_xty(n, a_t.shape[1], b_t.shape[1], _ptr(a_t), max(a2d.stride(0), M), _ptr(b_t), max(b2d.stride(0), K),
+                                         _ptr(o_t), out.stride(0), _ptr(ws), _stream(dev)))
         return out
 
     def column_sum(self, x2d):

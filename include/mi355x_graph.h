@@ -224,12 +224,14 @@ int32_t mgx_segment_reduce(int64_t num_segments, const int64_t* offsets, int64_t
 int64_t mgx_column_sum_workspace(int64_t C);
 int32_t mgx_column_sum(int64_t n, int64_t C, const float* x, float* out, void* workspace, void* stream);
 
-/* out[M, K] = a^T b for a [n, M], b [n, K] row-major, M <= 64, K <= 128 (else MGX_ERR_UNSUPPORTED), n in the millions: the
- * weight gradient dW = dY^T X of the dense layer after an aggregation (main_dgl_product_sage.py:31-33,64).  fp32 MFMA,
+/* out[M, K] = a^T b for a [n, M] (row stride lda floats), b [n, K] (row stride ldb), out row stride ldc; M <= 64, K <= 128 per
+ * call (else MGX_ERR_UNSUPPORTED; wider products are tiled by the caller through the leading dimensions), n in the millions:
+ * the weight gradient dW = dY^T X of the dense layer after an aggregation (main_dgl_product_sage.py:31-33,64).  fp32 MFMA,
  * operands streamed once, per-wave partial tiles added in fixed order (deterministic); workspace of
  * mgx_xty_workspace(M, K) bytes (-1 if the shape is unsupported). */
 int64_t mgx_xty_workspace(int64_t M, int64_t K);
-int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, const float* b, float* out, void* workspace, void* stream);
+int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldc,
+                void* workspace, void* stream);
 
 /* y = dropout_p(relu(x)) in one pass (inverted dropout: kept values scaled by 1/(1-p)); the activation between two
  * aggregations (main_dgl_product_sage.py:93-95).  n elements, n % 4 == 0, 16-byte aligned; mask: n/4 bytes, 4 bits per

@@ -130,7 +130,7 @@ class OracleBackend(object):
         return (d_feat.float() if need_feat_grad else None), g_a, g_b
 
     COLUMN_SUM_MAX = 256
-    XTY_MAX = (64, 128)
+    XTY_MAX = (256, 512)
     XTY_MIN_ROWS = 1 << 16
 
     def xty(self, a2d, b2d):

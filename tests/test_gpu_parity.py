@@ -598,7 +598,7 @@ def test_head_dot_sddmm_on_csr_walk(oracle, H, F, canonical):
 
 
 @pytest.mark.parametrize("n,M,K", [(0, 3, 5), (1, 1, 1), (5, 64, 128), (1000, 47, 64), (70001, 64, 100), (300000, 16, 7),
-                                    (123457, 33, 113), (65536, 64, 64)])
+                                    (123457, 33, 113), (65536, 64, 64), (70000, 256, 128), (66000, 200, 300), (3000, 65, 129)])
 def test_xty_matches_fp64(n, M, K):
     """mgx_xty (dW = dY^T X with fp32 MFMA) against the fp64 product; every tile-count template and ragged edges."""
     rng = np.random.default_rng(n + M + K)
@@ -610,7 +610,7 @@ def test_xty_matches_fp64(n, M, K):
     scale = float((a.double().abs().t() @ b.double().abs()).max()) if n else 1.0
     assert float((got.double() - ref).abs().max()) <= 1e-5 * max(scale, 1e-30)
     with pytest.raises(mg.DGLError, match="mgx_xty"):
-        sparse.backend_for(a).xty(torch.zeros(4, 65, device=DEV), torch.zeros(4, 8, device=DEV))
+        sparse.backend_for(a).xty(torch.zeros(4, 257, device=DEV), torch.zeros(4, 8, device=DEV))
 
 
 def test_linear_weight_grad_through_xty_matches_torch():
