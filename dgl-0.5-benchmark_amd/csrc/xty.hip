@@ -12,8 +12,16 @@
 
 namespace mgx {
 
-constexpr int kXtyBlocks = 512;                              // x 4 waves = 2048 partial tiles
-constexpr int kXtyWaves = kXtyBlocks * kWavesPerBlock;
+constexpr int kXtyWaves = 2048;  // most partial tiles (workspace size); fewer for shorter inputs, see xty_waves()
+
+// One partial tile (<= 32 KB written, then read back) per wave: keep >= 256 rows per wave so that the tiles stay a small
+// part of the traffic, between 256 waves (one per CU) and kXtyWaves; a multiple of 64 for the finish kernel's 16 slices.
+static int xty_waves(int64_t n) {
+  int64_t w = (n / 256 + 63) / 64 * 64;
+  if (w < 256) w = 256;
+  if (w > kXtyWaves) w = kXtyWaves;
+  return (int)w;
+}
 
 template <int MT, int KT>
 __global__ __launch_bounds__(kBlock) void xty_partial_kernel(int64_t n, int M, int K, const float* __restrict__ A, int64_t lda,
@@ -31,7 +39,8 @@ __global__ __launch_bounds__(kBlock) void xty_partial_kernel(int64_t n, int M, i
   for (int i = 0; i < MT; ++i) am[i] = i * 16 + c < M;
 #pragma unroll
   for (int j = 0; j < KT; ++j) bm[j] = j * 16 + c < K;
-  for (int64_t r0 = gw * 16; r0 < n; r0 += (int64_t)kXtyWaves * 16) {
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * 16;
+  for (int64_t r0 = gw * 16; r0 < n; r0 += stride) {
     float a[4][MT], b[4][KT];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void xty_partial_kernel(int64_t n, int M, i
 }
 
 // 16 output elements x 16 slices of the partial list per workgroup; slices combined in slice order
-__global__ __launch_bounds__(kBlock) void xty_finish_kernel(int M, int K, int ldm /* KT*16 */, int tile /* MT*16*KT*16 */,
+__global__ __launch_bounds__(kBlock) void xty_finish_kernel(int M, int K, int ldm /* KT*16 */, int tile /* MT*16*KT*16 */, int waves,
                                                             const float* __restrict__ part, float* __restrict__ out, int64_t ldc) {
   __shared__ float red[16][17];
   const int e = threadIdx.x % 16, sl = threadIdx.x / 16;
@@ -69,7 +78,7 @@ __global__ __launch_bounds__(kBlock) void xty_finish_kernel(int M, int K, int ld
   if (idx < M * K) {
     const int m = idx / K, k = idx % K;
     const float* p = part + (int64_t)m * ldm + k;
-    constexpr int per = kXtyWaves / 16;
+    const int per = waves / 16;
     for (int w = sl * per; w < (sl + 1) * per; w += 4) {
       s0 += p[(int64_t)w * tile];
       s1 += p[(int64_t)(w + 1) * tile];
@@ -87,10 +96,10 @@ __global__ __launch_bounds__(kBlock) void xty_finish_kernel(int M, int K, int ld
 }
 
 template <int MT>
-static bool launch_xty_kt(int kt, int64_t n, int M, int K, const float* A, int64_t lda, const float* B, int64_t ldb, float* part,
-                          hipStream_t s) {
+static bool launch_xty_kt(int kt, int waves, int64_t n, int M, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                          float* part, hipStream_t s) {
   switch (kt) {
-#define MGX_XTY(J) case J: hipLaunchKernelGGL((xty_partial_kernel<MT, J>), dim3(kXtyBlocks), dim3(kBlock), 0, s, n, M, K, A, lda, B, ldb, part); return true;
+#define MGX_XTY(J) case J: hipLaunchKernelGGL((xty_partial_kernel<MT, J>), dim3(waves / kWavesPerBlock), dim3(kBlock), 0, s, n, M, K, A, lda, B, ldb, part); return true;
     MGX_XTY(1) MGX_XTY(2) MGX_XTY(3) MGX_XTY(4) MGX_XTY(5) MGX_XTY(6) MGX_XTY(7) MGX_XTY(8)
 #undef MGX_XTY
     default: return false;
@@ -122,17 +131,18 @@ extern "C" int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int6
   }
   MGX_CHECK_ARG(a && b && workspace, "mgx_xty: NULL pointer");
   float* part = (float*)workspace;
+  const int waves = xty_waves(n);
   bool ok = false;
   switch (mt) {
-    case 1: ok = launch_xty_kt<1>(kt, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
-    case 2: ok = launch_xty_kt<2>(kt, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
-    case 3: ok = launch_xty_kt<3>(kt, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
-    default: ok = launch_xty_kt<4>(kt, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
+    case 1: ok = launch_xty_kt<1>(kt, waves, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
+    case 2: ok = launch_xty_kt<2>(kt, waves, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
+    case 3: ok = launch_xty_kt<3>(kt, waves, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
+    default: ok = launch_xty_kt<4>(kt, waves, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
   }
   MGX_CHECK_ARG(ok, "mgx_xty: no kernel for this tile shape");
   MGX_CHECK_LAUNCH();
   hipLaunchKernelGGL(xty_finish_kernel, dim3((unsigned)((M * K + 15) / 16)), dim3(kBlock), 0, s, (int)M, (int)K, kt * 16,
-                     mt * 16 * kt * 16, (const float*)part, out, ldc);
+                     mt * 16 * kt * 16, waves, (const float*)part, out, ldc);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
