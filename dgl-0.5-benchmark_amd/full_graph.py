@@ -33,7 +33,7 @@ import torch.nn.functional as F  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dgl  # noqa: E402
 import dgl.function as fn  # noqa: E402
-from dgl.nn.pytorch import GATConv, Linear  # noqa: E402
+from dgl.nn.pytorch import GATConv, Linear, BatchNorm1d  # noqa: E402
 from mi355x_graph import ops  # noqa: E402
 from dgl.utils import expand_as_pair  # noqa: E402
 
@@ -74,7 +74,7 @@ class GraphSAGE(nn.Module):
         for i in range(num_layers):
             self.layers.append(SAGEConv(dims[i], dims[i + 1], neigh_bias=neigh_bias))
             if batch_norm and i < num_layers - 1:
-                self.bns.append(nn.BatchNorm1d(hidden_feats))
+                self.bns.append(BatchNorm1d(hidden_feats))  # nn.BatchNorm1d whose training-mode passes run in the library
         self.dropout = nn.Dropout(p=dropout)
 
     def reset_parameters(self):

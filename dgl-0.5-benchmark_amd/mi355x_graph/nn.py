@@ -30,6 +30,27 @@ class Linear(nn.Linear):
         return ops.linear(input, self.weight, self.bias)
 
 
+class BatchNorm1d(nn.BatchNorm1d):
+    """torch.nn.BatchNorm1d (same parameters, buffers and state_dict) over node features [N, C]: in training mode the
+    statistics, the normalisation and their gradients run in the library's column kernels (PyTorch's channels-last
+    batch-norm kernels need 0.6-0.9 ms for [169 k, 256]; the data is 173 MB).  Evaluation mode, C > 256 or C % 4 != 0 and
+    non-2-D inputs take the PyTorch path."""
+
+    def forward(self, input):
+        use_batch = self.training or not self.track_running_stats
+        if not use_batch or not ops.batch_norm_supported(input):
+            return super(BatchNorm1d, self).forward(input)
+        y, mean, var = ops.BatchNormFn.apply(input, self.weight, self.bias, self.eps)
+        if self.training and self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked.add_(1)
+                m = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+                n = input.shape[0]
+                self.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                self.running_var.mul_(1 - m).add_(var, alpha=m * n / (n - 1))
+        return y
+
+
 class Identity(nn.Module):
     def forward(self, x):
         return x

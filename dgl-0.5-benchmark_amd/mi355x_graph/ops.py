@@ -374,6 +374,49 @@ def relu_dropout(x, p=0.5, training=True):
     return ReluDropout.apply(x, p)
 
 
+class BatchNormFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d over the rows of x [N, C]: two column reductions + one per-column affine map each way
+    (mgx_column_pair_sums / mgx_column_affine).  Returns (y, batch mean, biased batch variance)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        be = sparse.backend_for(x)
+        n = x.shape[0]
+        s, ss = be.column_pair_sums(x)
+        mean = s / n
+        var = (ss / n - mean * mean).clamp_(min=0.0)
+        invstd = torch.rsqrt(var + eps)
+        A = invstd if weight is None else weight * invstd
+        Cc = -mean * A if bias is None else bias - mean * A
+        y = be.column_affine(x, A.contiguous(), Cc.contiguous())
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy, _dmean, _dvar):
+        x, weight, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        be = sparse.backend_for(dy)
+        n = x.shape[0]
+        sdy, sdyx = be.column_pair_sums(dy, x)
+        sdyxhat = (sdyx - mean * sdy) * invstd
+        A = invstd if weight is None else weight * invstd
+        B = -A * invstd * sdyxhat / n
+        Cc = -A * sdy / n - B * mean
+        dx = be.column_affine(dy, A.contiguous(), Cc.contiguous(), x, B.contiguous()) if ctx.needs_input_grad[0] else None
+        dw = sdyxhat if weight is not None and ctx.needs_input_grad[1] else None
+        db = sdy if ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+def batch_norm_supported(x):
+    return (x.dim() == 2 and x.dtype == torch.float32 and x.device.type in sparse._BACKENDS and x.shape[1] % 4 == 0
+            and 4 <= x.shape[1] <= sparse.backend_for(x).COLUMN_SUM_MAX and x.shape[0] > 1)
+
+
 def _weight_grad(dy2, x2):
     be = sparse.backend_for(dy2)
     if (x2.shape[0] >= be.XTY_MIN_ROWS and dy2.shape[1] <= be.XTY_MAX[0] and x2.shape[1] <= be.XTY_MAX[1]

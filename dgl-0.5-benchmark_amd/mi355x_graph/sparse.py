@@ -396,6 +396,26 @@ class HipBackend(object):
             _lib.check(_lib.lib().mgx_relu_dropout_bwd(dy.numel(), _ptr(dy), _ptr(mask), ctypes.c_float(p), _ptr(dx), _stream(dev)))
         return dx
 
+    def column_pair_sums(self, a2d, b2d=None):
+        """(sum a, sum a*a) per column, or (sum a, sum a*b) when b2d is given."""
+        dev = self._check_dev(a2d, b2d)
+        n, C = a2d.shape
+        out = torch.empty((2, C), dtype=torch.float32, device=dev)
+        ws = torch.empty(2 * _lib.lib().mgx_column_sum_workspace(C) // 4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_column_pair_sums(n, C, 0 if b2d is None else 1, _ptr(a2d), _ptr(b2d), _ptr(out[0]), _ptr(out[1]),
+                                                       _ptr(ws), _stream(dev)))
+        return out[0], out[1]
+
+    def column_affine(self, a2d, A, Cc, b2d=None, B=None):
+        """a*A[c] + b*B[c] + Cc[c] with per-column coefficient vectors."""
+        dev = self._check_dev(a2d, b2d, A, B, Cc)
+        out = torch.empty_like(a2d)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_column_affine(a2d.shape[0], a2d.shape[1], _ptr(a2d), _ptr(b2d), _ptr(A), _ptr(B), _ptr(Cc),
+                                                    _ptr(out), _stream(dev)))
+        return out
+
     COLUMN_SUM_MAX = 256
     XTY_TILE = (64, 128)      # one mgx_xty call: a^T b with a [n, <= 64], b [n, <= 128]
     XTY_MAX = (256, 512)      # wider products are tiled through the leading dimensions (every operand re-read per tile)

@@ -224,6 +224,15 @@ int32_t mgx_segment_reduce(int64_t num_segments, const int64_t* offsets, int64_t
 int64_t mgx_column_sum_workspace(int64_t C);
 int32_t mgx_column_sum(int64_t n, int64_t C, const float* x, float* out, void* workspace, void* stream);
 
+/* Two column reductions in one pass over a row-major [n, C] matrix (C <= 256): mode 0 -> (sum a, sum a*a), mode 1 ->
+ * (sum a, sum a*b) -- the statistics of BatchNorm1d over the node dimension (main_dgl_arxiv_sage.py:70-77) forward and
+ * backward; workspace of 2 * mgx_column_sum_workspace(C) bytes.  mgx_column_affine: out[r,c] = a[r,c]*A[c] + b[r,c]*B[c] +
+ * Cc[c] (b/B may be NULL), C % 4 == 0, 16-byte aligned: the normalisation and its input gradient. */
+int32_t mgx_column_pair_sums(int64_t n, int64_t C, int32_t mode, const float* a, const float* b, float* out0, float* out1,
+                             void* workspace, void* stream);
+int32_t mgx_column_affine(int64_t n, int64_t C, const float* a, const float* b, const float* A, const float* B, const float* Cc,
+                          float* out, void* stream);
+
 /* out[M, K] = a^T b for a [n, M] (row stride lda floats), b [n, K] (row stride ldb), out row stride ldc; M <= 64, K <= 128 per
  * call (else MGX_ERR_UNSUPPORTED; wider products are tiled by the caller through the leading dimensions), n in the millions:
  * the weight gradient dW = dY^T X of the dense layer after an aggregation (main_dgl_product_sage.py:31-33,64).  fp32 MFMA,

@@ -129,6 +129,14 @@ class OracleBackend(object):
             g_b = (d_b.double().unsqueeze(-1) * x).sum(0).float()
         return (d_feat.float() if need_feat_grad else None), g_a, g_b
 
+    def column_pair_sums(self, a2d, b2d=None):
+        a = a2d.double()
+        return a.sum(0).float(), (a * (a if b2d is None else b2d.double())).sum(0).float()
+
+    def column_affine(self, a2d, A, Cc, b2d=None, B=None):
+        out = a2d * A + Cc
+        return out if b2d is None else out + b2d * B
+
     COLUMN_SUM_MAX = 256
     XTY_MAX = (256, 512)
     XTY_MIN_ROWS = 1 << 16

@@ -680,3 +680,31 @@ def test_relu_dropout_fused(p):
     assert torch.equal(ops.relu_dropout(x, p, False), torch.relu(x))
     odd = torch.randn(7, 3, device=DEV)                                       # numel % 4 != 0: the PyTorch path
     assert ops.relu_dropout(odd, p, True).shape == odd.shape
+
+
+@pytest.mark.parametrize("n,C", [(2, 4), (1000, 64), (169343, 256), (50001, 12)])
+def test_batch_norm_matches_torch(n, C):
+    """nn.BatchNorm1d built on mgx_column_pair_sums / mgx_column_affine: outputs, input / weight / bias gradients and the
+    running statistics against torch.nn.BatchNorm1d (fp32 tolerance), training and evaluation mode."""
+    from mi355x_graph.nn import BatchNorm1d
+    torch.manual_seed(n + C)
+    x = (torch.randn(n, C, device=DEV) * 2.0 + 0.5)
+    ours, ref = BatchNorm1d(C).to(DEV), torch.nn.BatchNorm1d(C).to(DEV)
+    with torch.no_grad():
+        ours.weight.uniform_(0.5, 1.5)
+        ours.bias.uniform_(-0.5, 0.5)
+    ref.load_state_dict(ours.state_dict())
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    g = torch.randn(n, C, device=DEV)
+    for step in range(2):
+        y1, y2 = ours(x1), ref(x2)
+        assert float((y1 - y2).abs().max()) < 2e-4 * float(y2.abs().max())
+    (y1 * g).sum().backward()
+    (y2 * g).sum().backward()
+    for a_, b_ in ((x1.grad, x2.grad), (ours.weight.grad, ref.weight.grad), (ours.bias.grad, ref.bias.grad),
+                   (ours.running_mean, ref.running_mean), (ours.running_var, ref.running_var)):
+        # input gradients of a normalisation cancel to ~0 (exactly 0 for n = 2): absolute floor at fp32 rounding of O(1) terms
+        assert float((a_ - b_).abs().max()) < 5e-6 + 5e-4 * float(b_.abs().max()), (float((a_ - b_).abs().max()), float(b_.abs().max()))
+    assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+    ours.eval(), ref.eval()
+    assert float((ours(x) - ref(x)).abs().max()) < 2e-4 * float(ref(x).abs().max())
