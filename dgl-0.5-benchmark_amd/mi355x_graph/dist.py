@@ -23,7 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from ._lib import DGLError
-from . import core, schedule, sparse
+from . import core, ops, schedule, sparse
 from . import function as fn
 from .graph import DGLGraph, Frame, GraphIndex
 
@@ -535,6 +535,24 @@ class _GlobalBatchNormFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, eps, group):
         C = x.shape[1]
         stats = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        ctx.lib_path = ops.batch_norm_supported(x)
+        if ctx.lib_path:  # the library's column kernels for the local reductions and the maps (ops.BatchNormFn's scheme)
+            x = x.contiguous()
+            be = sparse.backend_for(x)
+            s, ss = be.column_pair_sums(x)
+            stats[:C], stats[C:2 * C], stats[2 * C] = s.double(), ss.double(), x.shape[0]
+            all_reduce(stats, group=group)
+            n = stats[2 * C]
+            mean = stats[:C] / n
+            var = (stats[C:2 * C] / n - mean * mean).clamp(min=0.0)
+            invstd = torch.rsqrt(var + eps)
+            A = (invstd if weight is None else weight.double() * invstd).float()
+            Cc = (-mean * A.double() if bias is None else bias.double() - mean * A.double()).float()
+            y = be.column_affine(x, A.contiguous(), Cc.contiguous())
+            ctx.save_for_backward(x, weight, mean.float(), invstd.float())
+            ctx.group, ctx.count = group, n
+            ctx.mark_non_differentiable(mean, var, n)
+            return y, mean, var, n
         xd = x.double()
         stats[:C] = xd.sum(0)
         stats[C:2 * C] = (xd * xd).sum(0)
@@ -554,9 +572,24 @@ class _GlobalBatchNormFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy, _dm, _dv, _dn):
-        xhat, weight, invstd = ctx.saved_tensors
         C = dy.shape[1]
         red = torch.empty(2 * C, dtype=torch.float64, device=dy.device)
+        if ctx.lib_path:
+            x, weight, mean, invstd = ctx.saved_tensors
+            dy = dy.contiguous()
+            be = sparse.backend_for(dy)
+            sdy, sdyx = be.column_pair_sums(dy, x)
+            sdyxhat = (sdyx - mean * sdy) * invstd                    # this rank's rows
+            red[:C], red[C:] = sdy.double(), sdyxhat.double()
+            all_reduce(red, group=ctx.group)
+            n = ctx.count
+            A = invstd if weight is None else weight * invstd
+            B = (-A.double() * invstd.double() * red[C:] / n).float()
+            Cc = (-A.double() * red[:C] / n - B.double() * mean.double()).float()
+            dx = be.column_affine(dy, A.contiguous(), Cc.contiguous(), x, B.contiguous())
+            # LOCAL contributions: the caller's gradient all_reduce (allreduce_gradients) sums them over ranks
+            return dx, (sdyxhat if weight is not None else None), (sdy if weight is not None else None), None, None
+        xhat, weight, invstd = ctx.saved_tensors
         dyd = dy.double()
         red[:C] = dyd.sum(0)
         red[C:] = (dyd * xhat.double()).sum(0)
