@@ -65,10 +65,10 @@ class GATConv(nn.Module):
         self._out_feats = out_feats
         self._allow_zero_in_degree = allow_zero_in_degree
         if isinstance(in_feats, tuple):
-            self.fc_src = nn.Linear(self._in_src_feats, out_feats * num_heads, bias=False)
-            self.fc_dst = nn.Linear(self._in_dst_feats, out_feats * num_heads, bias=False)
+            self.fc_src = Linear(self._in_src_feats, out_feats * num_heads, bias=False)
+            self.fc_dst = Linear(self._in_dst_feats, out_feats * num_heads, bias=False)
         else:
-            self.fc = nn.Linear(self._in_src_feats, out_feats * num_heads, bias=False)
+            self.fc = Linear(self._in_src_feats, out_feats * num_heads, bias=False)
         self.attn_l = nn.Parameter(torch.FloatTensor(size=(1, num_heads, out_feats)))
         self.attn_r = nn.Parameter(torch.FloatTensor(size=(1, num_heads, out_feats)))
         self.feat_drop = nn.Dropout(feat_drop)
@@ -80,7 +80,7 @@ class GATConv(nn.Module):
             self.register_buffer("bias", None)
         if residual:
             if self._in_dst_feats != out_feats:
-                self.res_fc = nn.Linear(self._in_dst_feats, num_heads * out_feats, bias=False)
+                self.res_fc = Linear(self._in_dst_feats, num_heads * out_feats, bias=False)
             else:
                 self.res_fc = Identity()
         else:

@@ -418,7 +418,7 @@ class HipBackend(object):
 
     COLUMN_SUM_MAX = 256
     XTY_TILE = (64, 128)      # one mgx_xty call: a^T b with a [n, <= 64], b [n, <= 128]
-    XTY_MAX = (256, 512)      # wider products are tiled through the leading dimensions (every operand re-read per tile)
+    XTY_MAX = (256, 1024)     # wider products are tiled through the leading dimensions (every operand re-read per tile)
     XTY_MIN_ROWS = 1 << 16    # shorter reductions stay with the GEMM library
 
     def xty(self, a2d, b2d):

@@ -138,7 +138,7 @@ class OracleBackend(object):
         return out if b2d is None else out + b2d * B
 
     COLUMN_SUM_MAX = 256
-    XTY_MAX = (256, 512)
+    XTY_MAX = (256, 1024)
     XTY_MIN_ROWS = 1 << 16
 
     def xty(self, a2d, b2d):
