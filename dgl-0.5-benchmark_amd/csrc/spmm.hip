@@ -15,6 +15,8 @@
 //   * blockIdx is remapped so each XCD (own L2) owns a contiguous range of destination rows.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mgx {
@@ -48,6 +50,7 @@ struct SpmmFastArgs {
   int F;            // D / H
   int mean;
   int accum;  // out += result (MGX_SPMM_ACCUMULATE)
+  int ragged; // D % 4 != 0 handled with 16-byte gathers (RAGGED kernel)
 };
 
 // Work items per workgroup.  Workgroups are dispatched in blockIdx order, so a SMALL value makes
@@ -309,9 +312,14 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave_kernel(const SpmmFastArgs
 //     uniform branches.
 // WMODE: 0 = plain sum, 1 = one scalar per edge (u_mul_e with one head and/or src_scale), 2 = weight per
 // (edge, head) loaded after the edge id arrives.  LANEMASK: D is not a multiple of the lane-group width.
-template <int VEC, int G, int MODE, int WMODE, bool LANEMASK>
+// RAGGED (VEC = 4, D % 4 != 0, e.g. the 41-class output layer of the reddit GAT): rows are still gathered 16 bytes per lane
+// (dword-aligned accesses); the lane that owns the last 1-3 columns loads the LAST FOUR floats of the row instead -- no
+// read past the row, its own columns are the tail components of that window -- and only the epilogue distinguishes it.
+template <int VEC, int G, int MODE, int WMODE, bool LANEMASK, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
-  typedef typename VecT<VEC>::type V;
+  typedef typename VecT<VEC>::type VA;
+  typedef VA VU __attribute__((aligned(4)));  // RAGGED: gathers / stores are only dword-aligned
+  typedef typename std::conditional<RAGGED, VU, VA>::type V;
   constexpr int NB = kWave / G;
   constexpr int U = RowwaveUnroll<G>::value;
   constexpr int STEP = NB * U;
@@ -324,7 +332,10 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastAr
   const int head = (WMODE == 2 && factive) ? f / a.F : 0;
   const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * a.rpb;
   const uint32_t rowbytes = (uint32_t)a.D * 4u;
-  const uint32_t f4 = factive ? (uint32_t)f * 4u : 0u;  // idle feature lanes re-read the row start; never stored
+  const int nvalid = RAGGED ? (a.D - f < VEC ? a.D - f : VEC) : VEC;  // columns this lane owns (RAGGED: the last lane < 4)
+  const bool tail = RAGGED && factive && nvalid < VEC;
+  // idle feature lanes re-read the row start (never stored); the tail lane reads the row's last four floats
+  const uint32_t f4 = !factive ? 0u : (tail ? (uint32_t)(a.D - VEC) * 4u : (uint32_t)f * 4u);
   const char* __restrict__ srcb = reinterpret_cast<const char*>(a.src);
   const int bidx0 = sub * 4;  // byte index of this lane group's first edge for ds_bpermute
 
@@ -447,11 +458,23 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastAr
           acc = acc / (float)(deg > 1 ? deg : 1);
         }
         if (a.dst_scale) acc = acc * a.dst_scale[row];
-        float* op = a.out + row * (int64_t)a.D + f;
-        if (a.accum) acc += *reinterpret_cast<const V*>(op);
-        __builtin_nontemporal_store(acc, reinterpret_cast<V*>(op));
-      } else {
-        *reinterpret_cast<V*>(a.partial + (-(row + 1)) * (int64_t)a.D + f) = acc;
+      }
+      if (!tail) {
+        if (row >= 0) {  // separate pointers: the output store keeps its non-temporal hint
+          float* op = a.out + row * (int64_t)a.D + f;
+          if (a.accum) acc += *reinterpret_cast<const V*>(op);
+          __builtin_nontemporal_store((VA)acc, reinterpret_cast<V*>(op));
+        } else {
+          *reinterpret_cast<V*>(a.partial + (-(row + 1)) * (int64_t)a.D + f) = acc;
+        }
+      } else {  // own columns f .. f+nvalid-1 are components VEC-nvalid .. VEC-1 of the window
+        float* op = (row >= 0 ? a.out + row * (int64_t)a.D : a.partial + (-(row + 1)) * (int64_t)a.D) + f;
+        const float* av = reinterpret_cast<const float*>(&acc);
+        for (int j = 0; j < nvalid; ++j) {
+          float v = av[VEC - nvalid + j];
+          if (row >= 0 && a.accum) v += op[j];
+          op[j] = v;
+        }
       }
     }
     if (!has_next) break;
@@ -572,6 +595,13 @@ template <int VEC, int G, int MODE>
 static bool launch_rowwave32(const SpmmFastArgs<int32_t>& a, int64_t src_rows, dim3 grid, hipStream_t s) {
   if (getenv("MGX_SPMM_V1") != nullptr) return false;  // A/B switch
   if (src_rows * (int64_t)a.D * 4 >= (int64_t(1) << 32)) return false;
+  if (a.ragged) {  // VEC == 4, D % 4 != 0, one weight per edge at most (launch_fast checked eligibility)
+    if (VEC == 4 && MODE != MODE_COPY_RHS) {
+      if (MODE == MODE_MUL_EDGE || a.src_scale) hipLaunchKernelGGL((spmm_rowwave32_kernel<VEC, G, MODE, 1, true, true>), grid, dim3(kBlock), 0, s, a);
+      else hipLaunchKernelGGL((spmm_rowwave32_kernel<VEC, G, MODE, 0, true, true>), grid, dim3(kBlock), 0, s, a);
+    }
+    return true;
+  }
   const bool lanemask = a.D % (G * VEC) != 0;
   int wmode = 0;
   if (MODE == MODE_MUL_EDGE) wmode = a.H == 1 ? 1 : 2;
@@ -631,6 +661,15 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
   const bool al8 = ((uintptr_t)a.src % 8 == 0) && ((uintptr_t)a.out % 8 == 0);
   // MODE_MUL_EDGE needs every lane's VEC features inside one head: F % VEC == 0.
   const int vec_ok = (MODE == MODE_MUL_EDGE) ? a.F : a.D;
+  // odd widths (41 classes): 16-byte gathers with a ragged last lane, lean int32 kernel only, one head
+  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.D * 4 < (int64_t(1) << 32) && getenv("MGX_SPMM_V1") == nullptr;
+  if (lean && MODE != MODE_COPY_RHS && a.D % 4 != 0 && a.D > 4 && a.D <= 256 && a.H == 1 && getenv("MGX_SPMM_NO_RAGGED") == nullptr &&
+      (uintptr_t)a.src % 4 == 0) {
+    SpmmFastArgs<Idx> b = a;
+    b.ragged = 1;
+    launch_fast_v<Idx, 4, MODE>(b, nnz, s);
+    return;
+  }
   if (a.D % 4 == 0 && vec_ok % 4 == 0 && al16) launch_fast_v<Idx, 4, MODE>(a, nnz, s);
   else if (a.D % 2 == 0 && vec_ok % 2 == 0 && al8) launch_fast_v<Idx, 2, MODE>(a, nnz, s);
   else launch_fast_v<Idx, 1, MODE>(a, nnz, s);
@@ -663,6 +702,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     a.n_rows = n_rows; a.nblocks = nblocks; a.D = (int)out_len; a.H = 1; a.F = (int)out_len;
     a.mean = reduce == MGX_REDUCE_MEAN;
     a.accum = accumulate;
+    a.ragged = 0;
     a.item_row = nullptr; a.item_beg = nullptr; a.item_end = nullptr; a.partial = nullptr; a.n_items = n_rows;
     if (plan) {
       a.item_row = plan->item_row; a.item_beg = (const Idx*)plan->item_beg; a.item_end = (const Idx*)plan->item_end;
