@@ -16,6 +16,7 @@
 // the lane groups with ds_bpermute; the next 64 are requested before the current gathers issue.
 // `dot` keeps kUn edges in flight and reduces inside the lane group with xor-shuffles.
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -241,8 +242,13 @@ __global__ __launch_bounds__(kBlock) void sddmm_csr_kernel(const SddmmArgs<Idx> 
 // row-constant operand is loaded once per work item, lane j turns its neighbour id into a 32-bit byte offset once per 64
 // edges and hands it over with ds_bpermute, 64/G edges per gather instruction and kUn of them in flight; the F/4 lanes of
 // a head combine by xor-shuffle.  (The generic body re-gathers a 4*F-byte slice per head and reloads rowc for every edge.)
-template <int G, int LPH>
+// RAGGED (one head, F % 4 != 0, e.g. 41 classes): the lane that owns the last 1-3 columns loads the LAST four floats of both
+// rows (dword-aligned 16-byte accesses, nothing read past a row) and zeroes the overlapping components of the row-constant
+// operand once per work item, so the overlap contributes nothing to the dot product.
+template <int G, int LPH, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) void sddmm_csr_headdot_kernel(const SddmmArgs<int32_t> a, const float* gat, const float* rowc) {
+  typedef v4f v4u __attribute__((aligned(4)));
+  typedef typename std::conditional<RAGGED, v4u, v4f>::type V4;
   constexpr int NB = kWave / G;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -253,7 +259,10 @@ __global__ __launch_bounds__(kBlock) void sddmm_csr_headdot_kernel(const SddmmAr
   const bool writer = factive && (l % LPH) == 0;
   const int head = l / LPH;
   const uint32_t rowbytes = (uint32_t)D * 4u;
-  const uint32_t f4 = factive ? (uint32_t)f * 4u : 0u;  // idle feature lanes re-read the row start; never stored
+  const int nvalid = RAGGED ? (D - f < 4 ? D - f : 4) : 4;
+  const bool tail = RAGGED && factive && nvalid < 4;
+  const int fw = tail ? D - 4 : f;                         // first column of this lane's 16-byte window
+  const uint32_t f4 = factive ? (uint32_t)fw * 4u : 0u;    // idle feature lanes re-read the row start; never stored
   const char* __restrict__ gatb = reinterpret_cast<const char*>(gat);
   const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * kCsrItems;
   for (int r = wave; r < kCsrItems; r += kWavesPerBlock) {
@@ -271,7 +280,12 @@ __global__ __launch_bounds__(kBlock) void sddmm_csr_headdot_kernel(const SddmmAr
       end = a.indptr[item + 1];
     }
     if (beg >= end) continue;
-    const v4f rv = factive ? *reinterpret_cast<const v4f*>(rowc + row * D + f) : (v4f)(0.f);
+    v4f rv = factive ? (v4f)*reinterpret_cast<const V4*>(rowc + row * D + fw) : (v4f)(0.f);
+    if (tail) {  // components that belong to the previous lane's columns
+      if (nvalid < 4) rv.x = 0.f;
+      if (nvalid < 3) rv.y = 0.f;
+      if (nvalid < 2) rv.z = 0.f;
+    }
     auto load_ids = [&](int32_t base, uint32_t& goff, int32_t& me) {
       const int32_t q = base + lane;
       goff = 0;
@@ -296,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_csr_headdot_kernel(const SddmmAr
           const int bi = (j < cnt ? j : 0) * 4;  // lanes past the end re-read edge 0 (valid memory), never stored
           const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)goff) + f4;
           ee[i] = __builtin_amdgcn_ds_bpermute(bi, me);
-          x[i] = *reinterpret_cast<const v4f*>(gatb + off);
+          x[i] = *reinterpret_cast<const V4*>(gatb + off);
         }
 #pragma unroll
         for (int i = 0; i < kUn; ++i) {
@@ -313,8 +327,13 @@ __global__ __launch_bounds__(kBlock) void sddmm_csr_headdot_kernel(const SddmmAr
 }
 
 template <int G>
-static bool launch_headdot_lph(const SddmmArgs<int32_t>& a, const float* gat, const float* rowc, int lph, hipStream_t s) {
+static bool launch_headdot_lph(const SddmmArgs<int32_t>& a, const float* gat, const float* rowc, int lph, bool ragged, hipStream_t s) {
   const dim3 grid((unsigned)a.nblocks), block(kBlock);
+  if (ragged) {  // one head: the whole lane group reduces
+    if (G > 16) return false;
+    hipLaunchKernelGGL((sddmm_csr_headdot_kernel<G, (G <= 16 ? G : 16), true>), grid, block, 0, s, a, gat, rowc);
+    return true;
+  }
   switch (lph) {
 #define MGX_HDOT(L) case L: if (L <= G) { hipLaunchKernelGGL((sddmm_csr_headdot_kernel<G, (L <= G ? L : G)>), grid, block, 0, s, a, gat, rowc); return true; } return false;
     MGX_HDOT(1) MGX_HDOT(2) MGX_HDOT(4) MGX_HDOT(8) MGX_HDOT(16)
@@ -328,23 +347,28 @@ static bool try_headdot(const SddmmArgs<int32_t>& a, hipStream_t s) {
   const int64_t RS = a.reduce_size, D = a.out_len * RS;
   const bool uv = a.lhs_target == MGX_TARGET_U && a.rhs_target == MGX_TARGET_V;
   const bool vu = a.lhs_target == MGX_TARGET_V && a.rhs_target == MGX_TARGET_U;
-  if (!(uv || vu) || a.l_off || a.r_off || a.l_len != D || a.r_len != D || RS % 4 != 0 || D > 256) return false;
+  if (!(uv || vu) || a.l_off || a.r_off || a.l_len != D || a.r_len != D || D > 256) return false;
+  const bool ragged = RS % 4 != 0;
   const int64_t lph = RS / 4;
-  if ((lph & (lph - 1)) != 0 || lph > 16) return false;
-  if ((uintptr_t)a.L % 16 || (uintptr_t)a.R % 16) return false;
+  if (ragged) {
+    if (a.out_len != 1 || D <= 4 || D > 64 || (uintptr_t)a.L % 4 || (uintptr_t)a.R % 4 || getenv("MGX_SPMM_NO_RAGGED")) return false;
+  } else {
+    if ((lph & (lph - 1)) != 0 || lph > 16) return false;
+    if ((uintptr_t)a.L % 16 || (uintptr_t)a.R % 16) return false;
+  }
   if (a.n_cols * D * 4 >= (int64_t(1) << 32) || a.nnz >= (int64_t(1) << 31)) return false;  // 32-bit byte offsets
   const float* gat = uv ? a.L : a.R;
   const float* rowc = uv ? a.R : a.L;
   int G = 1;
   while (G * 4 < D) G <<= 1;
   switch (G) {
-    case 1: return launch_headdot_lph<1>(a, gat, rowc, (int)lph, s);
-    case 2: return launch_headdot_lph<2>(a, gat, rowc, (int)lph, s);
-    case 4: return launch_headdot_lph<4>(a, gat, rowc, (int)lph, s);
-    case 8: return launch_headdot_lph<8>(a, gat, rowc, (int)lph, s);
-    case 16: return launch_headdot_lph<16>(a, gat, rowc, (int)lph, s);
-    case 32: return launch_headdot_lph<32>(a, gat, rowc, (int)lph, s);
-    default: return launch_headdot_lph<64>(a, gat, rowc, (int)lph, s);
+    case 1: return launch_headdot_lph<1>(a, gat, rowc, (int)lph, ragged, s);
+    case 2: return launch_headdot_lph<2>(a, gat, rowc, (int)lph, ragged, s);
+    case 4: return launch_headdot_lph<4>(a, gat, rowc, (int)lph, ragged, s);
+    case 8: return launch_headdot_lph<8>(a, gat, rowc, (int)lph, ragged, s);
+    case 16: return launch_headdot_lph<16>(a, gat, rowc, (int)lph, ragged, s);
+    case 32: return launch_headdot_lph<32>(a, gat, rowc, (int)lph, ragged, s);
+    default: return launch_headdot_lph<64>(a, gat, rowc, (int)lph, ragged, s);
   }
 }
 template <typename Idx> static bool try_headdot_any(const SddmmArgs<Idx>&, hipStream_t) { return false; }

@@ -568,7 +568,8 @@ def test_csr_transpose_bit_exact(oracle, idtype, shape):
         assert float((x1.grad - x2.grad).abs().max()) <= 1e-4 * float(x2.grad.abs().max() + 1e-12)
 
 
-@pytest.mark.parametrize("H,F", [(1, 4), (1, 16), (1, 64), (8, 8), (8, 16), (4, 32), (3, 4), (12, 4), (2, 128), (1, 256)])
+@pytest.mark.parametrize("H,F", [(1, 4), (1, 16), (1, 64), (8, 8), (8, 16), (4, 32), (3, 4), (12, 4), (2, 128), (1, 256),
+                                 (1, 41), (1, 7), (1, 47), (1, 63), (1, 5), (2, 41)])  # odd widths: ragged 16-byte lanes (one head)
 @pytest.mark.parametrize("canonical", [False, True])
 def test_head_dot_sddmm_on_csr_walk(oracle, H, F, canonical):
     """u_dot_v per head on a CSR-only graph (the specialised row-constant kernel; (2,128)/(1,256) exceed its lane-group
