@@ -359,11 +359,11 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastAr
     if (q < end) {
       int32_t gid;
       if (MODE == MODE_COPY_RHS) {
-        gid = a.eids ? a.eids[q] : q;
+        gid = a.eids ? __builtin_nontemporal_load(&a.eids[q]) : q;
       } else {
         gid = __builtin_nontemporal_load(&a.indices[q]);  // streamed once: keep L2 for the gathered rows
         if (MODE == MODE_MUL_EDGE) {
-          eid = a.eids ? a.eids[q] : q;
+          eid = a.eids ? __builtin_nontemporal_load(&a.eids[q]) : q;
           if (WMODE == 1) sc = a.w[eid];
         }
         if (WMODE == 1 && a.src_scale) sc *= a.src_scale[gid];
