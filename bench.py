@@ -2,26 +2,38 @@
 """bench.py -- full-graph GraphSAGE on an ogbn-products-shaped graph (BASELINE.json's metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
-   one rank per GPU over RCCL)
 
-A "step" is one training epoch of main_dgl_product_sage.py's loop (forward, nll_loss on the train
-split, backward, Adam step, loss.item() as the host sync; lines 101-110) on the synthetic
-products-shaped graph (N = 2,449,029, E = 123,718,280 directed, D = 100 -> 64 -> 64 -> 47, fp32).
-`value` = aggregated edges/s = (3 forward + 2 backward g-SpMMs) * E / epoch time, whole job.
-N > 1 partitions the SAME graph (edge-cut + RCCL all_to_all halo exchange): strong scaling.
+N > 1: one rank per GPU over RCCL.  The driver launches it as `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N ...`; a plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) starts those N ranks
+itself as CHILD processes, before this process has touched the GPU, and exits with their status.
+
+A "step" is one training epoch of main_dgl_product_sage.py's loop (forward, nll_loss on the train split, backward, Adam
+step, loss.item() as the host sync; lines 101-110) on the synthetic products-shaped graph (N = 2,449,029,
+E = 123,718,280 directed, D = 100 -> 64 -> 64 -> 47, fp32).  `value` = aggregated edges/s = (3 forward + 2 backward
+g-SpMMs) * E / epoch time, whole job.  N > 1 partitions the SAME graph (edge-cut + RCCL all_to_all halo exchange):
+strong scaling.
 
 The JSON line also carries
-  roofline      the dominant hot-path kernel (copy_u/sum g-SpMM at D = 64, 4 launches per epoch):
-                algorithmic bytes (4(N+1) + 4E + 4ND + 4ND) / its mean launch duration,
-                measured live with HIP events on the launch stream, against the 8 TB/s HBM peak;
-  cpu_baseline  the CPU oracle (OpenMP port of DGL's CPU algorithm) timed on the host cores on the
-                g-SpMMs of one epoch (rank 0, N = 1 only, bounded to ~30 s).
+  roofline      the dominant hot-path kernel (copy_u/sum g-SpMM at D = 64, 4 launches per epoch): algorithmic bytes
+                (4(N+1) + 4E + 4ND + 4ND) / its mean launch duration, measured live with HIP events on the
+                launch stream, against the 8 TB/s HBM peak; `kernels` lists every g-SpMM shape of the epoch (D = 100 too);
+                `traffic` = FETCH_SIZE*2 + WRITE_SIZE per launch from rocprofv3 --pmc child passes of the same kernel on
+                the same graph, run after the timed region (N = 1; --no-pmc skips them -> null);
+                `controls` = the same kernel on control graphs of the same size (dgl-0.5-benchmark_amd/kernel_controls.py);
+  epoch_ms_plain_model   the same epoch with the reference's exact module graph (torch.nn.Linear, F.relu, nn.Dropout,
+                separate add) -- only update_all() is this package's -- timed right after the headline loop;
+  cpu_baseline  the CPU oracle (OpenMP port of DGL's CPU algorithm) timed on the host cores on the g-SpMMs of one epoch
+                (rank 0, N = 1 only, bounded to ~30 s).
 """
 import argparse
+import datetime
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,16 +42,11 @@ for _p in (ROOT, PKG):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-# Dense layers of the (unmodified) model are rocBLAS/hipBLASLt GEMMs; their default heuristics pick 3 ms kernels for
-# the tall-skinny weight-gradient shapes (K = 2.45 M).  PyTorch's TunableOp selections for exactly these shapes --
-# the full graph and the per-rank owned-row counts of the deterministic P = 2, 4, 8 partitions -- were recorded once on
-# MI355X by experiments/tune_dense.py (dgl-0.5-benchmark_amd/tunableop_products<device>.csv) and are only LOADED here
-# (tuning off), which is a user-level PyTorch setting, not part of the message-passing library.
-if os.environ.get("MGX_BENCH_TUNABLEOP", "1") == "1":
-    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_RECORD_UNTUNED", "0")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(PKG, "tunableop_products.csv"))
+# Dense layers of the model are rocBLAS/hipBLASLt GEMMs; selections recorded once on MI355X for exactly these shapes
+# are only LOADED here (tuning off) -- a user-level PyTorch setting, see dgl-0.5-benchmark_amd/tunable.py.
+import tunable  # noqa: E402
+
+tunable.setup()
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -123,6 +130,59 @@ def cpu_baseline(g, feat_dim, hidden, budget_s=30.0):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as child processes (torch.distributed.run) and exit
+    with their status.  Runs before anything in this process has initialised the GPU (device_count() does not)."""
+    share = os.environ.get("MGX_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not share:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (MGX_BENCH_SHARE_GPU=1 MGX_DIST_BACKEND=gloo runs "
+                         "all ranks on cuda:0 for a smoke test)\n" % (args.gpus, have))
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def pmc_traffic(widths, reps, scale, timeout_s=240):
+    """HBM-side bytes per launch of the g-SpMM kernels on the benchmark graph from rocprofv3 counter passes run as CHILD
+    processes (rocprofv3 -- python3 kernel_controls.py ...; --pmc alone, one pass per counter group as gfx950's TCC slots
+    require).  Returns (list per width | None, note)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    import kernel_controls as kc
+    sets, t0 = [], time.time()
+    work = tempfile.mkdtemp(prefix="mgx_pmc_")
+    try:
+        for i, counters in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"])):
+            left = timeout_s - (time.time() - t0)
+            if left < 20:
+                return None, "pmc passes ran out of time"
+            out = os.path.join(work, "p%d" % i)
+            cmd = [rocprof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable,
+                                                     os.path.join(PKG, "kernel_controls.py"), "--graphs", "products",
+                                                     "--widths", ",".join(str(w) for w in widths), "--reps", str(reps),
+                                                     "--scale", str(scale)]
+            env = dict(os.environ, TMPDIR=work)
+            r = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d): %s" % (" ".join(counters), r.returncode,
+                                                                     r.stderr.decode(errors="replace")[-200:])
+            sets.append(kc.parse_pmc_dir(out))
+        return kc.pmc_to_traffic(sets, reps), "rocprofv3 --pmc child passes (FETCH_SIZE x2 + WRITE_SIZE; %d launches each)" % reps
+    except (subprocess.TimeoutExpired, OSError) as err:
+        return None, "pmc passes: %s" % (str(err)[:160],)
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -131,7 +191,13 @@ def main():
     p.add_argument("--dataset", default="products")
     p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; makes the line invalid)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
+    p.add_argument("--no-controls", action="store_true", help="skip the control graphs (roofline.controls)")
+    p.add_argument("--no-plain", action="store_true", help="skip the plain-torch-module epoch (epoch_ms_plain_model)")
     args = p.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -146,12 +212,16 @@ def main():
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # generous collective timeout: rank 0 partitions while the others wait in a broadcast
+        tmo = datetime.timedelta(minutes=60)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        world = dist.get_world_size()  # what the backend really connected
     if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+        print("warning: --gpus %d but the process group has %d rank(s); reporting n_gpus=%d" % (args.gpus, world, world),
+              file=sys.stderr)
 
     import dgl
     import full_graph
@@ -169,62 +239,101 @@ def main():
     labels = torch.randint(0, spec["classes"], (n,), generator=gen)
     train_mask = torch.rand(n, generator=gen) < 0.08  # ogbn-products trains on 8 % of the nodes
 
-    torch.manual_seed(1234)
-    model = full_graph.GraphSAGE(spec["feat"], cfg["hidden"], spec["classes"], cfg["num_layers"], cfg["dropout"],
-                                 cfg["batch_norm"], cfg["neigh_bias"]).to(device)
+    def make_model(plain=False):
+        torch.manual_seed(1234)
+        return full_graph.GraphSAGE(spec["feat"], cfg["hidden"], spec["classes"], cfg["num_layers"], cfg["dropout"],
+                                    cfg["batch_norm"], cfg["neigh_bias"], plain=plain).to(device)
+
+    model = make_model()
     part_stats = {}
+    bucket = None
     if world == 1:
         g = dgl.graph((src, dst), num_nodes=n).int().formats(["csr", "csc"]).to(device)
         x, y = feats.to(device), labels.to(device)
         train_idx = torch.nonzero(train_mask).flatten().to(device)
         total_train = float(train_idx.numel())
     else:
+        # every rank generated the edge list itself (same seed): make sure they agree before rank 0's partition is applied
+        finger = mdist.edge_fingerprint(src, dst)
+        fp = torch.tensor([finger, -finger], dtype=torch.int64, device=device)
+        mdist.all_reduce(fp, op=dist.ReduceOp.MAX)
+        if int(fp[0]) != finger or int(fp[1]) != -finger:
+            raise SystemExit("bench.py: ranks generated different graphs (edge checksums differ)")
+        t0 = time.perf_counter()
         if rank == 0:
             assign, part_stats = mdist.cached_partition(src, dst, n, world)
         else:
             assign = torch.empty(n, dtype=torch.int64, device=device)
+        part_stats["partition_s_rank0"] = round(time.perf_counter() - t0, 2)
         mdist.broadcast(assign, 0)
+        t0 = time.perf_counter()
         block, hplan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
         g = mdist.DistGraph(block, hplan)
         own_cpu = own.cpu()
         x, y = feats[own_cpu].to(device), labels[own_cpu].to(device)
+        g.set_static_input(x)  # the layer-1 input is constant: its halo rows are exchanged once and stay resident
         train_idx = torch.nonzero(train_mask[own_cpu]).flatten().to(device)
         total_train = float(train_mask.sum())
         mdist.broadcast_parameters(model)
-        part_stats.update({"halo_rows": hplan.n_halo, "owned_rows": hplan.n_own, "send_rows": int(sum(hplan.send_splits)),
-                           "local_edges": block.number_of_edges(),
-                           "halo_bytes_per_exchange": {"D=%d" % d: hplan.n_halo * d * 4 for d in (spec["feat"], cfg["hidden"])},
-                           "exchanges_per_epoch": "2 forward (layer-1 input halo is resident) + 2 backward"})
+        bucket = mdist.GradBucket(model)
+        torch.cuda.synchronize()
+        part_stats["build_local_s_rank0"] = round(time.perf_counter() - t0, 2)
+        # per-rank halo statistics, gathered on every rank (tiny)
+        mine = torch.tensor([hplan.n_own, hplan.n_halo, int(sum(hplan.send_splits)), block.number_of_edges(),
+                             int(hplan.halo.num_edges())], dtype=torch.int64, device=device)
+        allr = torch.zeros(world * 5, dtype=torch.int64, device=device)
+        allr[rank * 5:(rank + 1) * 5] = mine
+        mdist.all_reduce(allr)
+        allr = allr.view(world, 5).cpu().tolist()
+        D_hid = cfg["hidden"]
+        part_stats.update({
+            "edge_cut_pct": round(100.0 * sum(r[4] for r in allr) / max(num_edges, 1), 2),
+            "per_rank": [{"owned_rows": r[0], "halo_rows": r[1], "send_rows": r[2], "local_edges": r[3], "halo_edges": r[4],
+                          "halo_bytes_per_exchange_D%d" % D_hid: r[1] * D_hid * 4} for r in allr],
+            "max_halo_bytes_per_exchange": max(r[1] for r in allr) * D_hid * 4,
+            "exchanges_per_epoch": "2 forward (the layer-1 input halo is resident) + 2 backward, D=%d each" % D_hid})
     del src, dst
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
 
-    def step():
-        # main_dgl_product_sage.py:101-110; for P > 1 the mean loss is taken over the GLOBAL train set
-        model.train()
-        opt.zero_grad()
-        out = model(g, x)[train_idx]
-        loss = F.nll_loss(out, y[train_idx], reduction="sum") / total_train
-        loss.backward()
-        if world > 1:
-            mdist.allreduce_gradients(model)
-        opt.step()
-        return loss.item()
+    def make_step(model, opt, bucket):
+        def step():
+            # main_dgl_product_sage.py:101-110; for P > 1 the mean loss is taken over the GLOBAL train set
+            model.train()
+            if bucket is not None:
+                bucket.zero()  # gradients are views into one flat buffer (zero_grad would drop them)
+            else:
+                opt.zero_grad()
+            out = model(g, x)[train_idx]
+            loss = F.nll_loss(out, y[train_idx], reduction="sum") / total_train
+            loss.backward()
+            if bucket is not None:
+                bucket.all_reduce()
+            opt.step()
+            return loss.item()
+        return step
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    sparse.PROFILE = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    records, sparse.PROFILE = sparse.PROFILE, None
+    def timed(step, steps, warmup, profile):
+        for _ in range(warmup):
+            step()
+        fence()
+        if profile:
+            sparse.PROFILE = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        records = None
+        if profile:
+            records, sparse.PROFILE = sparse.PROFILE, None
+        return elapsed, loss, records
+
+    elapsed, loss, records = timed(make_step(model, opt, bucket), args.steps, args.warmup, True)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         mdist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -233,29 +342,24 @@ def main():
         mdist.all_reduce(lt, op=dist.ReduceOp.SUM)
         loss = float(lt.item())
 
-    # ---- roofline of the dominant kernel: copy_u g-SpMM at D = hidden (4 of the 5 launches per epoch)
+    # ---- roofline: every copy_u g-SpMM shape of the epoch from the live HIP-event records; the headline entry is the
+    # dominant one, D = hidden (4 of the 5 launches per epoch)
     D = cfg["hidden"]
-    sel = [r for r in records if r["op"] == "copy_lhs" and r["out_len"] == D]
-    durs = [r["start"].elapsed_time(r["end"]) * 1e-3 for r in sel]
-    roofline = None
-    if durs:
+    kernels = []
+    for width in sorted({r["out_len"] for r in records if r["op"] == "copy_lhs"}):
+        sel = [r for r in records if r["op"] == "copy_lhs" and r["out_len"] == width]
+        durs = [r["start"].elapsed_time(r["end"]) * 1e-3 for r in sel]
         r0 = sel[0]
         avg = sum(durs) / len(durs)
-        algo = sum(spmm_algorithmic_bytes(r["n_rows"], r["n_cols"], r["nnz"], D) for r in sel) / len(sel)
+        algo = sum(spmm_algorithmic_bytes(r["n_rows"], r["n_cols"], r["nnz"], width) for r in sel) / len(sel)
         achieved = algo / avg / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and world == 1 and args.scale == 1.0:
-            tj = json.load(open(tpath))
-            if tj.get("dataset") == args.dataset and tj.get("D") == D:
-                traffic = tj.get("hbm_bytes_per_launch")
-        roofline = {"bound": "hbm", "kernel": "mgx::spmm_rowwave32_kernel<4,16,copy_lhs> (copy_u/sum, D=%d)" % D,
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(algo),
-                    "no_reuse_gather_bytes_per_launch": int(algo - 4 * r0["n_cols"] * D + 4 * r0["nnz"] * D),
-                    "avg_launch_ms": round(avg * 1e3, 4),
-                    "launches_timed": len(durs), "rows": r0["n_rows"], "nnz": r0["nnz"]}
+        kernels.append({"bound": "hbm", "kernel": "g-SpMM copy_u/sum|mean, D=%d (mgx_spmm_csr)" % width, "D": width,
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": int(algo),
+                        "no_reuse_gather_bytes_per_launch": int(algo - 4 * r0["n_cols"] * width + 4 * r0["nnz"] * width),
+                        "avg_launch_ms": round(avg * 1e3, 4), "launches_timed": len(durs),
+                        "launches_per_epoch": len(durs) // max(args.steps, 1), "rows": r0["n_rows"], "nnz": r0["nnz"]})
 
     epoch = elapsed / args.steps
     agg_edges = full_graph.spmm_edges_per_epoch(cfg["num_layers"], num_edges)
@@ -271,10 +375,56 @@ def main():
                                 "1 GPU" if world == 1 else "edge-cut partition over %d GPUs, RCCL all_to_all halo" % world),
                    "spmm_per_epoch": 2 * cfg["num_layers"] - 1, "final_loss": loss,
                    "schedule": os.environ.get("MGX_SCHEDULE", "auto"), "partition": part_stats,
-                   "dense_gemm_selection": "tunableop file" if os.environ.get("PYTORCH_TUNABLEOP_ENABLED") == "1" else "default"},
-        "roofline": roofline,
+                   "model": "full_graph.GraphSAGE (reference module graph; dense layers with this package's gradient helpers)",
+                   "dense_gemm_selection": tunable.status()},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+
+    single = rank == 0 and world == 1
+    # ---- the reference's exact module graph on the same graph, same step function
+    if single and not args.no_plain:
+        del model, opt
+        torch.cuda.empty_cache()
+        pm = make_model(plain=True)
+        popt = torch.optim.Adam(pm.parameters(), lr=cfg["lr"])
+        psteps = min(args.steps, 10)
+        pel, ploss, _ = timed(make_step(pm, popt, None), psteps, min(args.warmup, 3), False)
+        line["epoch_ms_plain_model"] = round(pel / psteps * 1e3, 3)
+        line["plain_model"] = {"modules": "torch.nn.Linear, F.relu, nn.Dropout, fc_self(h) + fc_neigh(neigh) as two GEMMs and an "
+                                          "add (main_dgl_product_sage.py:15-99); update_all() by this package",
+                               "steps": psteps, "final_loss": ploss,
+                               "value_edges_per_s": agg_edges / (pel / psteps)}
+        del pm, popt
+        torch.cuda.empty_cache()
+
+    head = next((k for k in kernels if k["D"] == D), kernels[0] if kernels else None)
+    roofline = dict(head) if head else None
+    if roofline is not None:
+        roofline["kernels"] = kernels
+        if single and args.dataset == "products" and not args.no_controls:
+            import kernel_controls as kc
+            try:
+                roofline["controls"] = kc.run_controls(device, [k for k in kc.CONTROLS if k != "products"], (D,), args.scale, reps=5)
+                roofline["controls"]["note"] = ("same kernel, same N and E, other edge structure (kernel_controls.py); counter "
+                                                "traffic per control: profiles/r02_controls.txt")
+            except Exception as err:  # a control graph must not lose the bench line
+                roofline["controls"] = {"error": str(err)[:200]}
+        if single and args.dataset == "products" and not args.no_pmc:
+            widths = [k["D"] for k in kernels]
+            traffic, note = pmc_traffic(widths, 3, args.scale)
+            roofline["traffic_source"] = note
+            if traffic:
+                for k, t in zip(kernels, traffic):
+                    if "hbm_read_bytes" in t and "hbm_write_bytes" in t:
+                        k["traffic"] = t["hbm_read_bytes"] + t["hbm_write_bytes"]
+                        k["traffic_detail"] = t
+                roofline["traffic"] = head["traffic"]
+                if "traffic_detail" in head:
+                    roofline["traffic_detail"] = head["traffic_detail"]
+        elif roofline is not None:
+            roofline["traffic_source"] = "not collected (N > 1, --no-pmc or another dataset)"
+    line["roofline"] = roofline
+
+    if single and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(g, spec["feat"], cfg["hidden"])
     elif rank == 0:
         line["cpu_baseline"] = None

@@ -102,6 +102,10 @@ extern "C" int32_t mgx_column_sum(int64_t n, int64_t C, const float* x, float* o
 // (173 MB: 0.04 ms at the HBM rate).  Same two-stage scheme as the column sum, two accumulators per column:
 //   mode 0: (sum a, sum a*a)          forward statistics
 //   mode 1: (sum a, sum a*b)          backward: (sum dy, sum dy*x)
+//   mode 2: (sum (a-p), sum (a-p)^2)  p[c] = a[0, c]: statistics relative to the first row.  E[x^2] - mean^2 from plain
+//   mode 3: (sum a, sum a*(b-p))      p[c] = b[0, c]  fp32 sums cancels catastrophically when |mean| >> std (mean 1e3,
+//                                     std 1e-1 loses every significant bit of the variance); relative to ANY sample the
+//                                     terms are O(std), which is what Welford's update achieves in torch.nn.BatchNorm1d.
 namespace mgx {
 
 __global__ __launch_bounds__(kBlock) void column_pair_partial_kernel(int64_t n, int C, int mode, const float* a, const float* b,
@@ -114,17 +118,19 @@ __global__ __launch_bounds__(kBlock) void column_pair_partial_kernel(int64_t n, 
   const int64_t r0 = (int64_t)blockIdx.x * slab, r1 = (r0 + slab < n) ? r0 + slab : n;
   float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f;
   if (active) {
+    const bool two = mode & 1;  // second operand is b
+    const float pa = mode == 2 ? a[c] : 0.f, pb = mode == 3 ? b[c] : 0.f;  // pivot: first row of the shifted operand
     int64_t r = r0 + rl;
     for (; r + rpp < r1; r += 2 * rpp) {  // two independent rows in flight
-      const float x0 = a[r * C + c], x1 = a[(r + rpp) * C + c];
-      const float y0 = mode ? b[r * C + c] : x0, y1 = mode ? b[(r + rpp) * C + c] : x1;
+      const float x0 = a[r * C + c] - pa, x1 = a[(r + rpp) * C + c] - pa;
+      const float y0 = two ? b[r * C + c] - pb : x0, y1 = two ? b[(r + rpp) * C + c] - pb : x1;
       s0 += x0; s1 += x1;
       t0 += x0 * y0; t1 += x1 * y1;
     }
     for (; r < r1; r += rpp) {
-      const float x0 = a[r * C + c];
+      const float x0 = a[r * C + c] - pa;
       s0 += x0;
-      t0 += x0 * (mode ? b[r * C + c] : x0);
+      t0 += x0 * (two ? b[r * C + c] - pb : x0);
     }
   }
   lds0[threadIdx.x] = active ? s0 + s1 : 0.f;
@@ -159,7 +165,7 @@ extern "C" int32_t mgx_column_pair_sums(int64_t n, int64_t C, int32_t mode, cons
                                         void* workspace, void* stream) {
   using namespace mgx;
   MGX_ENTER();
-  MGX_CHECK_ARG(n >= 0 && C >= 1 && (mode == 0 || mode == 1), "mgx_column_pair_sums: bad arguments");
+  MGX_CHECK_ARG(n >= 0 && C >= 1 && mode >= 0 && mode <= 3, "mgx_column_pair_sums: bad arguments");
   MGX_CHECK_ARG(out0 && out1, "mgx_column_pair_sums: out is NULL");
   if (C > kBlock) MGX_UNSUPPORTED("mgx_column_pair_sums: C = %lld > %d columns", (long long)C, kBlock);
   hipStream_t s = (hipStream_t)stream;
@@ -168,7 +174,7 @@ extern "C" int32_t mgx_column_pair_sums(int64_t n, int64_t C, int32_t mode, cons
     MGX_CHECK_HIP(hipMemsetAsync(out1, 0, (size_t)C * sizeof(float), s));
     return MGX_OK;
   }
-  MGX_CHECK_ARG(a && workspace && (mode == 0 || b), "mgx_column_pair_sums: NULL pointer");
+  MGX_CHECK_ARG(a && workspace && (!(mode & 1) || b), "mgx_column_pair_sums: NULL pointer");
   float* p0 = (float*)workspace;
   float* p1 = p0 + (int64_t)kColSumSlabs * C;
   hipLaunchKernelGGL(column_pair_partial_kernel, dim3(kColSumSlabs), dim3(kBlock), 0, s, n, (int)C, mode, a, b, p0, p1);

@@ -620,6 +620,7 @@ static bool launch_rowwave32(const SpmmFastArgs<int64_t>&, int64_t, dim3, hipStr
 template <typename Idx, int VEC, int G, int MODE>
 static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, hipStream_t s) {
   constexpr int NB = kWave / G;
+  if (a.ragged) split = true;  // only the lean row-per-wave kernel implements the ragged 16-byte tail window
   a.rpb = rows_per_block_setting();
   if (!split && a.rpb < kWavesPerBlock * NB) a.rpb = kWavesPerBlock * NB;  // one item per lane group
   a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);

@@ -19,12 +19,10 @@ import time
 # GEMM selections recorded once on MI355X for the dense layers of the products model (experiments/tune_dense.py) are
 # loaded, never tuned, here -- hipBLASLt's default heuristics pick 3 ms kernels for the K = 2.45 M weight-gradient
 # shapes.  Other shapes fall through to the default.  MGX_BENCH_TUNABLEOP=0 turns it off (same switch as bench.py).
-if os.environ.get("MGX_BENCH_TUNABLEOP", "1") == "1":
-    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_RECORD_UNTUNED", "0")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME",
-                          os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_products.csv"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import tunable  # noqa: E402
+
+tunable.setup()
 
 import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
@@ -42,11 +40,15 @@ class SAGEConv(nn.Module):
     """mean-aggregator GraphSAGE layer: fc_self(h_v) + fc_neigh(mean_{u->v} h_u); aggregation happens
     BEFORE the projection, on the un-projected feature (main_dgl_product_sage.py:61-64)."""
 
-    def __init__(self, in_feats, out_feats, self_bias=False, neigh_bias=True):
+    def __init__(self, in_feats, out_feats, self_bias=False, neigh_bias=True, plain=False):
         super(SAGEConv, self).__init__()
         self._in_src_feats, self._in_dst_feats = expand_as_pair(in_feats)
-        self.fc_self = Linear(self._in_dst_feats, out_feats, bias=self_bias)
-        self.fc_neigh = Linear(self._in_src_feats, out_feats, bias=neigh_bias)
+        # plain: the reference's exact module graph (torch.nn.Linear, separate add); otherwise the same parameters with
+        # the dense-side helpers of this package (mgx_xty / mgx_column_sum gradients, accumulate-GEMM)
+        self.plain = plain
+        lin = nn.Linear if plain else Linear
+        self.fc_self = lin(self._in_dst_feats, out_feats, bias=self_bias)
+        self.fc_neigh = lin(self._in_src_feats, out_feats, bias=neigh_bias)
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -59,22 +61,28 @@ class SAGEConv(nn.Module):
         feat_src, feat_dst = feat if isinstance(feat, tuple) else (feat, feat)
         graph.srcdata["h"] = feat_src
         graph.update_all(fn.copy_src("h", "m"), fn.mean("m", "neigh"))
-        if self.fc_self.bias is None and os.environ.get("MGX_SAGE_FUSED_ADD", "1") == "1":
+        if not self.plain and self.fc_self.bias is None and os.environ.get("MGX_SAGE_FUSED_ADD", "1") == "1":
             # fc_self(h) + fc_neigh(neigh): the second GEMM accumulates into the first's output (no separate add pass)
             return ops.linear_sum(feat_dst, self.fc_self.weight, graph.dstdata["neigh"], self.fc_neigh.weight, self.fc_neigh.bias)
         return self.fc_self(feat_dst) + self.fc_neigh(graph.dstdata["neigh"])
 
 
 class GraphSAGE(nn.Module):
-    def __init__(self, in_feats, hidden_feats, out_feats, num_layers, dropout, batch_norm=False, neigh_bias=True):
+    """`plain=True` is the reference's module graph verbatim in structure -- torch.nn.Linear, F.relu, nn.Dropout,
+    nn.BatchNorm1d, `fc_self(h) + fc_neigh(neigh)` as two GEMMs and an add (main_dgl_product_sage.py:15-99): only the
+    aggregation inside update_all() is this package's.  bench.py reports its epoch beside the default's."""
+
+    def __init__(self, in_feats, hidden_feats, out_feats, num_layers, dropout, batch_norm=False, neigh_bias=True, plain=False):
         super(GraphSAGE, self).__init__()
+        self.plain = plain
         self.layers = nn.ModuleList()
         self.bns = nn.ModuleList()
         dims = [in_feats] + [hidden_feats] * (num_layers - 1) + [out_feats]
         for i in range(num_layers):
-            self.layers.append(SAGEConv(dims[i], dims[i + 1], neigh_bias=neigh_bias))
+            self.layers.append(SAGEConv(dims[i], dims[i + 1], neigh_bias=neigh_bias, plain=plain))
             if batch_norm and i < num_layers - 1:
-                self.bns.append(BatchNorm1d(hidden_feats))  # nn.BatchNorm1d whose training-mode passes run in the library
+                # default: nn.BatchNorm1d whose training-mode passes run in the library
+                self.bns.append(nn.BatchNorm1d(hidden_feats) if plain else BatchNorm1d(hidden_feats))
         self.dropout = nn.Dropout(p=dropout)
 
     def reset_parameters(self):
@@ -88,7 +96,10 @@ class GraphSAGE(nn.Module):
             x = layer(g, x)
             if len(self.bns):
                 x = self.bns[i](x)
-            x = ops.relu_dropout(x, self.dropout.p, self.training)  # F.relu + dropout, one pass each way on the device
+            if self.plain:
+                x = self.dropout(F.relu(x))
+            else:
+                x = ops.relu_dropout(x, self.dropout.p, self.training)  # F.relu + dropout, one pass each way on the device
         x = self.layers[-1](g, x)
         return x.log_softmax(dim=-1)
 

@@ -93,17 +93,23 @@ def partition_nodes(src, dst, num_nodes, num_parts, rounds=5, clusters=None):
     return assign, {"edge_cut": cut, "num_clusters": int(uniq.shape[0])}
 
 
+def edge_fingerprint(src, dst):
+    """Order-dependent-free checksum of an edge list (python int < 2^61): keys the partition cache and lets ranks check
+    that they hold the same graph."""
+    mix = (src.long() * 1000003 + dst.long() * 7919) % 2147483629
+    return int(mix.sum().item()) % (1 << 61)
+
+
 def cached_partition(src, dst, num_nodes, num_parts, cache_dir=None, **kwargs):
     """partition_nodes with the result kept on disk, as the reference caches its METIS partitions
     (cluster-sage/dgl/sampler.py:34-41): `<cache_dir>/partition_n<N>_e<E>_p<P>_<fingerprint>.pt`.  The fingerprint is a
     checksum of the edge list, so a different graph of the same size never reuses a stale file."""
     cache_dir = cache_dir or os.environ.get("MGX_CACHE_DIR") or os.path.join(os.path.expanduser("~"), ".cache", "mi355x_graph")
-    mix = (src.long() * 1000003 + dst.long() * 7919) % 2147483629
-    finger = int(mix.sum().item()) % (1 << 61)
+    finger = edge_fingerprint(src, dst)
     path = os.path.join(cache_dir, "partition_n%d_e%d_p%d_%x.pt" % (num_nodes, src.shape[0], num_parts, finger))
     if os.path.exists(path):
         try:
-            blob = torch.load(path, map_location=src.device)
+            blob = torch.load(path, map_location=src.device, weights_only=True)
             if blob["assign"].shape[0] == num_nodes:
                 stats = dict(blob["stats"], cached=True)
                 return blob["assign"].to(src.device), stats
@@ -210,6 +216,22 @@ class HaloPlan(object):
         for c in send_splits:
             self.send_ranges.append((off, off + c))
             off += c
+        self._ret = None
+
+    def return_csr(self):
+        """CSR over the OWNED rows whose entries are positions of the returned halo-gradient buffer (`back`, grouped by
+        peer like send_idx): adding the rows that come back into their owners is then ONE copy_e/sum g-SpMM accumulating
+        into the gradient -- rows that went to several peers are summed in peer order (stable sort), so the result is
+        deterministic, and there is one launch instead of one scatter per peer."""
+        if self._ret is None:
+            pos = torch.arange(self.send_idx.shape[0], dtype=self.send_idx.dtype, device=self.send_idx.device)
+            self._ret = sparse.coo_to_csr(self.n_own, max(int(pos.shape[0]), 1), self.send_idx.contiguous(), pos)
+        return self._ret
+
+    def add_returned_rows(self, gx, back):
+        if back.shape[0]:
+            sparse.gspmm_raw(self.return_csr(), "copy_rhs", "sum", None, back, accumulate_into=gx)
+        return gx
 
 
 def build_local_partition(src, dst, num_nodes, assign, rank, world, idtype=torch.int32):
@@ -309,23 +331,24 @@ class DistCopyU(torch.autograd.Function):
       backward  g-SpMM^T producing halo-row gradients -> all_to_all (async) || g-SpMM^T over owned rows
                 -> wait -> add received rows into their owners (per peer, fixed order)
     Both halves write through dst_scale = 1/max(deg,1) for `mean` (deg = full in-degree).
-    `static_cache` (a dict, or None): halo rows of a CONSTANT input (the node features of layer 1: a leaf that needs no
-    gradient) stay resident on the receiving rank after the first exchange -- keyed by the tensor's storage, shape and
-    version counter, so an in-place update or a different tensor exchanges again.  The aggregation itself always runs."""
+    `static_cache` (a dict, or None): the caller declared THIS tensor constant (DistGraph.set_static_input: the node
+    features of layer 1), so its halo rows stay resident on the receiving rank after the first exchange.  The dict holds
+    the tensor itself (identity, not an address that the allocator may hand to another tensor) and its version counter:
+    an in-place update exchanges again.  Every rank runs the same program on the same declaration, so all ranks hit or
+    miss together.  The aggregation itself always runs."""
 
     @staticmethod
     def forward(ctx, x, plan, comm, reduce, static_cache=None):
         x = x.contiguous()
         feat = tuple(x.shape[1:])
-        key = (x.data_ptr(), x._version, tuple(x.shape))
-        if static_cache is not None and static_cache.get("key") == key:
+        if static_cache is not None and static_cache.get("recv") is not None and static_cache.get("version") == x._version:
             recv, work = static_cache["recv"], _Done()
         else:
             send = sparse.gather_rows_raw(x, plan.send_idx)
             recv = torch.empty((plan.n_halo,) + feat, dtype=x.dtype, device=x.device)
             work = comm.all_to_all_async(recv, send, plan.recv_splits, plan.send_splits)
             if static_cache is not None:
-                static_cache["key"], static_cache["recv"] = key, recv
+                static_cache["version"], static_cache["recv"] = x._version, recv
         scale = plan.inv_deg if reduce == "mean" else None
         out, _, _ = sparse.gspmm_raw(plan.loc.csc(), "copy_lhs", "sum", x, None, dst_scale=scale)
         work.wait()
@@ -350,9 +373,7 @@ class DistCopyU(torch.autograd.Function):
         work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
         gx, _, _ = sparse.gspmm_raw(plan.loc.csr(), "copy_lhs", "sum", dZ, None)
         work.wait()
-        for (a, b) in plan.send_ranges:
-            if b > a:
-                sparse.scatter_add_rows_raw(gx, plan.send_idx[a:b], back[a:b])
+        plan.add_returned_rows(gx, back)
         return gx, None, None, None, None
 
 
@@ -378,9 +399,7 @@ class HaloExchange(torch.autograd.Function):
         gx = g[:plan.n_own].clone()
         back = torch.empty((plan.send_idx.shape[0],) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
         comm.all_to_all(back, g[plan.n_own:], plan.send_splits, plan.recv_splits)
-        for (a, b) in plan.send_ranges:  # one peer at a time: ids are unique inside a peer's list
-            if b > a:
-                sparse.scatter_add_rows_raw(gx, plan.send_idx[a:b], back[a:b])
+        plan.add_returned_rows(gx, back)
         return gx, None, None
 
 
@@ -398,7 +417,7 @@ class DistGraph(DGLGraph):
         self._edge_frame = Frame(block.number_of_edges(), kind="edge")
         self._batch_num_nodes = None
         self._batch_num_edges = None
-        self._static_halo = {}  # halo rows of the constant input features (see DistCopyU); shared by local_var() clones
+        self._static_halo = {}  # set_static_input(): tensor / version / resident halo rows; shared by local_var() clones
 
     def _clone(self, index=None, frames=None):
         g = DistGraph.__new__(DistGraph)
@@ -413,6 +432,14 @@ class DistGraph(DGLGraph):
             g._src_frame, g._dst_frame, g._edge_frame = frames
         g._batch_num_nodes = g._batch_num_edges = None
         return g
+
+    def set_static_input(self, x):
+        """Declare `x` (this rank's rows of the constant input features) static: update_all(copy_u, sum|mean) on exactly
+        this tensor object exchanges its halo rows once and keeps them resident; every rank must make the same call.
+        `None` withdraws the declaration."""
+        self._static_halo.clear()
+        if x is not None and os.environ.get("MGX_STATIC_HALO", "1") == "1":
+            self._static_halo.update(tensor=x, version=None, recv=None)
 
     def number_of_nodes(self, ntype=None):
         return self._plan.n_own
@@ -466,9 +493,7 @@ class DistGraph(DGLGraph):
                 and reduce_func.msg_field == message_func.out_field and self._plan.loc is not None
                 and apply_node_func is None):
             x = self._src_frame[message_func.in_field]
-            # a leaf without gradient inside a training forward = constant input features: their halo rows stay resident
-            static = self._static_halo if (torch.is_grad_enabled() and not x.requires_grad and x.is_leaf
-                                           and os.environ.get("MGX_STATIC_HALO", "1") == "1") else None
+            static = self._static_halo if self._static_halo.get("tensor") is x else None  # declared by set_static_input
             self._dst_frame[reduce_func.out_field] = DistCopyU.apply(x, self._plan, self._comm, reduce_func.name, static)
             return
         blk = self._local(self._u_fields(message_func))
@@ -520,6 +545,30 @@ def allreduce_gradients(model, group=None):
         off += n
 
 
+class GradBucket(object):
+    """Every parameter gradient of `model` as a view into ONE flat buffer, set up once: autograd accumulates into the
+    views in place, so the per-step gradient all_reduce is a single call on the buffer with no concatenate / copy-back.
+    Use `bucket.zero()` where the training loop calls `optimizer.zero_grad()` (set_to_none would drop the views)."""
+
+    def __init__(self, model, group=None):
+        self.group = group
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        ref = self.params[0]
+        self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce(self):
+        all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+
 def broadcast_parameters(model, src=0, group=None):
     for p in list(model.parameters()) + list(model.buffers()):
         broadcast(p.data, src, group=group)
@@ -539,8 +588,11 @@ class _GlobalBatchNormFn(torch.autograd.Function):
         if ctx.lib_path:  # the library's column kernels for the local reductions and the maps (ops.BatchNormFn's scheme)
             x = x.contiguous()
             be = sparse.backend_for(x)
-            s, ss = be.column_pair_sums(x)
-            stats[:C], stats[C:2 * C], stats[2 * C] = s.double(), ss.double(), x.shape[0]
+            # local sums relative to this rank's first row p (no fp32 cancellation), re-based to raw moments in fp64
+            s, ss = be.column_pair_sums(x, shifted=True)
+            pv, nl = x[0].double(), float(x.shape[0])
+            s, ss = s.double(), ss.double()
+            stats[:C], stats[C:2 * C], stats[2 * C] = s + nl * pv, ss + 2.0 * pv * s + nl * pv * pv, x.shape[0]
             all_reduce(stats, group=group)
             n = stats[2 * C]
             mean = stats[:C] / n
@@ -578,8 +630,8 @@ class _GlobalBatchNormFn(torch.autograd.Function):
             x, weight, mean, invstd = ctx.saved_tensors
             dy = dy.contiguous()
             be = sparse.backend_for(dy)
-            sdy, sdyx = be.column_pair_sums(dy, x)
-            sdyxhat = (sdyx - mean * sdy) * invstd                    # this rank's rows
+            sdy, sdyx = be.column_pair_sums(dy, x, shifted=True)      # sum dy * (x - x[0])
+            sdyxhat = (sdyx - (mean - x[0]) * sdy) * invstd           # this rank's rows
             red[:C], red[C:] = sdy.double(), sdyxhat.double()
             all_reduce(red, group=ctx.group)
             n = ctx.count

@@ -382,7 +382,7 @@ class _Pooling(nn.Module):
     _op = "sum"
 
     def forward(self, graph, feat):
-        return ops.segment_reduce(graph.batch_num_nodes(), feat, self._op)
+        return ops.segment_reduce(graph.batch_num_nodes(), feat, self._op, total=graph.number_of_nodes())
 
 
 class SumPooling(_Pooling):

@@ -216,6 +216,9 @@ class GATAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gidx, el, er, slope):
         csc = gidx.csc()
+        if el.shape[0] != csc.num_cols or er.shape[0] != csc.num_rows:  # the kernel indexes el by source id, er by row
+            raise DGLError("gat_attention: expected el with %d source rows and er with %d destination rows, got %d and %d"
+                           % (csc.num_cols, csc.num_rows, el.shape[0], er.shape[0]))
         shape = el.shape[1:]
         el2, er2 = el.contiguous().view(el.shape[0], -1), er.contiguous().view(er.shape[0], -1)
         a = sparse.backend_for(el2).gat_attention_fwd(csc, el2, er2, float(slope))
@@ -383,9 +386,11 @@ class BatchNormFn(torch.autograd.Function):
         x = x.contiguous()
         be = sparse.backend_for(x)
         n = x.shape[0]
-        s, ss = be.column_pair_sums(x)
-        mean = s / n
-        var = (ss / n - mean * mean).clamp_(min=0.0)
+        # sums relative to the first row p: E[(x-p)^2] - E[x-p]^2 has O(std) terms, so |mean| >> std does not cancel
+        s, ss = be.column_pair_sums(x, shifted=True)
+        m1 = s / n
+        mean = x[0] + m1
+        var = (ss / n - m1 * m1).clamp_(min=0.0)
         invstd = torch.rsqrt(var + eps)
         A = invstd if weight is None else weight * invstd
         Cc = -mean * A if bias is None else bias - mean * A
@@ -401,8 +406,8 @@ class BatchNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         be = sparse.backend_for(dy)
         n = x.shape[0]
-        sdy, sdyx = be.column_pair_sums(dy, x)
-        sdyxhat = (sdyx - mean * sdy) * invstd
+        sdy, sdyx = be.column_pair_sums(dy, x, shifted=True)  # sum dy * (x - x[0])
+        sdyxhat = (sdyx - (mean - x[0]) * sdy) * invstd
         A = invstd if weight is None else weight * invstd
         B = -A * invstd * sdyxhat / n
         Cc = -A * sdy / n - B * mean
@@ -468,8 +473,8 @@ def linear(x, weight, bias=None):
 
 class SegmentReduce(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, op, x, offsets):
-        out, arg = sparse.segment_reduce_raw(offsets, x, op, want_arg=op in ("max", "min"))
+    def forward(ctx, op, x, offsets, total):
+        out, arg = sparse.segment_reduce_raw(offsets, x, op, want_arg=op in ("max", "min"), total=total)
         ctx.backward_cache = op, x.shape[0]
         ctx.save_for_backward(arg, offsets)
         return out
@@ -490,7 +495,7 @@ class SegmentReduce(torch.autograd.Function):
             dx = torch.zeros((n,) + tuple(dy.shape[1:]), dtype=dy.dtype, device=dy.device)
             valid = arg >= 0
             dx.scatter_add_(0, arg.clamp(min=0), dy * valid)
-        return None, dx, None
+        return None, dx, None, None
 
 
 # ----------------------------------------------------------------------------- public API
@@ -552,13 +557,17 @@ def edge_softmax(graph, logits, eids="__ALL__", norm_by="dst"):
     return EdgeSoftmax.apply(_gidx(graph), logits, norm_by)
 
 
-def segment_reduce(seglen, value, reducer="sum"):
+def segment_reduce(seglen, value, reducer="sum", total=None):
     """dgl.ops.segment_reduce: reduce consecutive row segments of `value` (AvgPooling readout)."""
     if reducer not in ("sum", "mean", "max", "min"):
         raise DGLError("Unsupported segment reducer %r" % (reducer,))
+    # value must have sum(seglen) rows: known on the host for host lengths, or passed by a caller that knows it
+    # (a batched graph's node count); otherwise read back once
+    if total is None and not seglen.is_cuda:
+        total = int(seglen.sum())
     offsets = torch.zeros(seglen.shape[0] + 1, dtype=torch.int64, device=value.device)
     torch.cumsum(seglen.to(value.device).long(), 0, out=offsets[1:])
-    return SegmentReduce.apply(reducer, value, offsets)
+    return SegmentReduce.apply(reducer, value, offsets, total)
 
 
 # named shortcuts (dgl.ops.copy_u_sum, ...)

@@ -396,14 +396,15 @@ class HipBackend(object):
             _lib.check(_lib.lib().mgx_relu_dropout_bwd(dy.numel(), _ptr(dy), _ptr(mask), ctypes.c_float(p), _ptr(dx), _stream(dev)))
         return dx
 
-    def column_pair_sums(self, a2d, b2d=None):
-        """(sum a, sum a*a) per column, or (sum a, sum a*b) when b2d is given."""
+    def column_pair_sums(self, a2d, b2d=None, shifted=False):
+        """(sum a, sum a*a) per column, or (sum a, sum a*b) when b2d is given.  `shifted`: relative to the first row p of
+        the squared / second operand -- (sum (a-p), sum (a-p)^2) with p = a[0], or (sum a, sum a*(b-p)) with p = b[0]."""
         dev = self._check_dev(a2d, b2d)
         n, C = a2d.shape
         out = torch.empty((2, C), dtype=torch.float32, device=dev)
         ws = torch.empty(2 * _lib.lib().mgx_column_sum_workspace(C) // 4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_column_pair_sums(n, C, 0 if b2d is None else 1, _ptr(a2d), _ptr(b2d), _ptr(out[0]), _ptr(out[1]),
+            _lib.check(_lib.lib().mgx_column_pair_sums(n, C, (0 if b2d is None else 1) + (2 if shifted else 0), _ptr(a2d), _ptr(b2d), _ptr(out[0]), _ptr(out[1]),
                                                        _ptr(ws), _stream(dev)))
         return out[0], out[1]
 
@@ -608,18 +609,28 @@ def gsddmm_raw(gidx, op, L, R, lhs_target="u", rhs_target="v"):
 
 def edge_softmax_fwd_raw(csr, z):
     z = _as_f32(z, "edge_softmax logits")
+    if z.shape[0] != csr.nnz:
+        raise DGLError("edge_softmax: expected %d edge rows, got %d" % (csr.nnz, z.shape[0]))
     a = backend_for(z).edge_softmax_fwd(csr, z.view(z.shape[0], -1))
     return a.view(z.shape)
 
 
 def edge_softmax_bwd_raw(csr, a, da):
     a, da = _as_f32(a, "edge_softmax out"), _as_f32(da, "edge_softmax grad")
+    if a.shape[0] != csr.nnz or tuple(da.shape) != tuple(a.shape):
+        raise DGLError("edge_softmax backward: expected two (%d, ...) tensors of one shape, got %s and %s"
+                       % (csr.nnz, tuple(a.shape), tuple(da.shape)))
     dz = backend_for(a).edge_softmax_bwd(csr, a.view(a.shape[0], -1), da.view(da.shape[0], -1))
     return dz.view(a.shape)
 
 
-def segment_reduce_raw(offsets, x, reduce="sum", want_arg=False):
+def segment_reduce_raw(offsets, x, reduce="sum", want_arg=False, total=None):
+    """`total`: the caller's host-side sum of the segment lengths, checked against x.shape[0] without a device sync."""
     x = _as_f32(x, "segment_reduce input")
+    if total is None:
+        total = int(offsets[-1].item()) if offsets.numel() else 0
+    if total != x.shape[0]:
+        raise DGLError("segment_reduce: segment lengths sum to %d, value has %d rows" % (total, x.shape[0]))
     out, arg = backend_for(x).segment_reduce(offsets, x.view(x.shape[0], -1), reduce, want_arg)
     shape = (offsets.shape[0] - 1,) + tuple(x.shape[1:])
     return out.view(shape), (None if arg is None else arg.view(shape))

@@ -226,7 +226,9 @@ int32_t mgx_column_sum(int64_t n, int64_t C, const float* x, float* out, void* w
 
 /* Two column reductions in one pass over a row-major [n, C] matrix (C <= 256): mode 0 -> (sum a, sum a*a), mode 1 ->
  * (sum a, sum a*b) -- the statistics of BatchNorm1d over the node dimension (main_dgl_arxiv_sage.py:70-77) forward and
- * backward; workspace of 2 * mgx_column_sum_workspace(C) bytes.  mgx_column_affine: out[r,c] = a[r,c]*A[c] + b[r,c]*B[c] +
+ * backward; modes 2 / 3 are the same sums taken relative to the first row p of the squared / second operand, mode 2 ->
+ * (sum (a-p), sum (a-p)^2) with p = a[0,:], mode 3 -> (sum a, sum a*(b-p)) with p = b[0,:], which keeps the variance
+ * accurate when |mean| >> std; workspace of 2 * mgx_column_sum_workspace(C) bytes.  mgx_column_affine: out[r,c] = a[r,c]*A[c] + b[r,c]*B[c] +
  * Cc[c] (b/B may be NULL), C % 4 == 0, 16-byte aligned: the normalisation and its input gradient. */
 int32_t mgx_column_pair_sums(int64_t n, int64_t C, int32_t mode, const float* a, const float* b, float* out0, float* out1,
                              void* workspace, void* stream);

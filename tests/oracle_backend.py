@@ -129,9 +129,16 @@ class OracleBackend(object):
             g_b = (d_b.double().unsqueeze(-1) * x).sum(0).float()
         return (d_feat.float() if need_feat_grad else None), g_a, g_b
 
-    def column_pair_sums(self, a2d, b2d=None):
+    def column_pair_sums(self, a2d, b2d=None, shifted=False):
         a = a2d.double()
-        return a.sum(0).float(), (a * (a if b2d is None else b2d.double())).sum(0).float()
+        if b2d is None:
+            if shifted:
+                a = a - a[0]
+            return a.sum(0).float(), (a * a).sum(0).float()
+        b = b2d.double()
+        if shifted:
+            b = b - b[0]
+        return a.sum(0).float(), (a * b).sum(0).float()
 
     def column_affine(self, a2d, A, Cc, b2d=None, B=None):
         out = a2d * A + Cc

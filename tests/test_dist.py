@@ -76,14 +76,15 @@ def _worker(rank, world, port, q, device="cpu", batch_norm=False):
     if device == "cpu":
         mdist.broadcast_parameters(model)  # same seed => same init; exercised on the CPU run only
     x, y, m = feats[own], labels[own], train[own]
+    g.set_static_input(x)  # explicit declaration (every rank alike): the layer-1 halo rows stay resident
     total = torch.tensor([float(train.sum())], device=device)
+    bucket = mdist.GradBucket(model)  # gradients are views into one flat buffer: one all_reduce, no copies (bench.py's path)
+    bucket.zero()
     out = model(g, x)
     loss = F.nll_loss(out[m], y[m], reduction="sum") / total  # global mean
     loss.backward()
-    for prm in model.parameters():  # gloo all_reduce on host copies (RCCL path: mdist.allreduce_gradients)
-        gcpu = prm.grad.detach().cpu()
-        dist.all_reduce(gcpu)
-        prm.grad.copy_(gcpu)
+    assert all(prm.grad.data_ptr() >= bucket.flat.data_ptr() for prm in model.parameters())  # still the views
+    bucket.all_reduce()
     lsum = loss.detach().cpu().clone()
     dist.all_reduce(lsum)
     q.put((rank, own.cpu().numpy(), out.detach().cpu().numpy(), float(lsum),
@@ -99,6 +100,13 @@ def _worker(rank, world, port, q, device="cpu", batch_norm=False):
     n_before = g._comm.n_exchanges
     model(g, x)
     assert g._comm.n_exchanges - n_before == n_layers
+    # identity, not address: a per-step temporary with the same values (e.g. feat_drop(feat)) never hits the cache
+    n_before = g._comm.n_exchanges
+    model(g, x.clone())
+    assert g._comm.n_exchanges - n_before == n_layers
+    n_before = g._comm.n_exchanges
+    model(g, x)  # the declared tensor is still resident
+    assert g._comm.n_exchanges - n_before == n_layers - 1
     dist.barrier()
     dist.destroy_process_group()
 

@@ -709,3 +709,25 @@ def test_batch_norm_matches_torch(n, C):
     assert int(ours.num_batches_tracked) == int(ref.num_batches_tracked) == 2
     ours.eval(), ref.eval()
     assert float((ours(x) - ref(x)).abs().max()) < 2e-4 * float(ref(x).abs().max())
+
+
+@pytest.mark.parametrize("n,C", [(4096, 8), (300001, 64)])
+def test_batch_norm_large_mean_small_std(n, C):
+    """|mean| >> std (mean 1e3, std 1e-1): E[x^2] - mean^2 from plain fp32 sums would lose the variance entirely; the
+    library's sums are taken relative to the first row (mgx_column_pair_sums modes 2 / 3), like Welford in torch."""
+    from mi355x_graph.nn import BatchNorm1d
+    torch.manual_seed(n)
+    x = torch.randn(n, C, device=DEV) * 0.1 + 1000.0
+    ours, ref = BatchNorm1d(C).to(DEV), torch.nn.BatchNorm1d(C).to(DEV)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    g = torch.randn(n, C, device=DEV)
+    y1, y2 = ours(x1), ref(x2)
+    exact = (x.double() - x.double().mean(0)) / (x.double().var(0, unbiased=False) + 1e-5).sqrt()
+    e_ours, e_ref = float((y1.double() - exact).abs().max()), float((y2.double() - exact).abs().max())
+    assert e_ours < max(4.0 * e_ref, 5e-3), (e_ours, e_ref)     # outputs are O(1); fp32 x carries ~6e-5 of its own
+    assert float((ours.running_var - ref.running_var).abs().max()) < 1e-3 * float(ref.running_var.abs().max())
+    (y1 * g).sum().backward()
+    (y2 * g).sum().backward()
+    gscale = float(x2.grad.abs().max())
+    assert float((x1.grad - x2.grad).abs().max()) < 2e-2 * gscale, (float((x1.grad - x2.grad).abs().max()), gscale)
+    assert float((ours.weight.grad - ref.weight.grad).abs().max()) < 2e-3 * float(ref.weight.grad.abs().max()) + 1e-2
