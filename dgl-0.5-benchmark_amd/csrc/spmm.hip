@@ -316,7 +316,10 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave_kernel(const SpmmFastArgs
 // (dword-aligned accesses); the lane that owns the last 1-3 columns loads the LAST FOUR floats of the row instead -- no
 // read past the row, its own columns are the tail components of that window -- and only the epilogue distinguishes it.
 template <int VEC, int G, int MODE, int WMODE, bool LANEMASK, bool RAGGED = false>
-__global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
+#ifndef MGX_RW32_WAVES
+#define MGX_RW32_WAVES 1
+#endif
+__global__ __launch_bounds__(kBlock, MGX_RW32_WAVES) void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
   typedef typename VecT<VEC>::type VA;
   typedef VA VU __attribute__((aligned(4)));  // RAGGED: gathers / stores are only dword-aligned
   typedef typename std::conditional<RAGGED, VU, VA>::type V;
@@ -635,6 +638,9 @@ static void launch_fast_v(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s
   const int lanes = (a.D + VEC - 1) / VEC;
   int G = 1;
   while (G < lanes && G < kWave) G <<= 1;
+  // experiment: column tiling -- fewer lanes per row, the remaining columns in further passes (grid.y)
+  static const int env_g = getenv("MGX_SPMM_G") ? atoi(getenv("MGX_SPMM_G")) : 0;
+  if (env_g > 0 && env_g < G && !a.ragged && MODE == MODE_COPY_LHS) G = env_g;
   const int NB = kWave / G;
   const double avg_deg = a.n_rows > 0 ? (double)nnz / (double)a.n_rows : 0.0;
   // One row per wave (lane groups share the row's edges) or one row per lane group.  The lean int32 kernel is faster

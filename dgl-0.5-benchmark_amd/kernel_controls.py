@@ -112,7 +112,7 @@ def time_spmm(csc, X, reps=6, discard=2):
     return sum(d) / len(d)
 
 
-MARKER = "gather_rows_kernel"  # one 1-row mgx_gather_rows launch closes every (graph, width) block in a counter trace
+MARKER = "mgx::rows_kernel"  # one 1-row mgx_gather_rows launch closes every (graph, width) block in a counter trace
 
 
 def _marker(device):
