@@ -1,0 +1,507 @@
+// gatfused.hip -- one GAT layer's message passing without any E-sized tensor (gfx950 / MI355X).
+//
+// Replaces what dgl.nn.pytorch.GATConv.forward runs between the projection and the bias
+// (main_dgl_reddit_gat.py:10,31-55; UPSTREAM module): apply_edges(fn.u_add_v) -> leaky_relu -> edge_softmax ->
+// attn_drop -> update_all(fn.u_mul_e, fn.sum), and its backward.  DGL 0.6 launches ~7 kernels forward and ~12 backward
+// and writes / re-reads six E x H tensors; round 1 of this library fused the logit chain but still wrote the attention
+// `a` (E x H), its gradient and the logit gradient.  Here the attention weight of an edge is REBUILT in registers
+// wherever it is needed from four per-node numbers (er, row max m, 1 / row sum, t = <out, d out>):
+//
+//   forward   gat_stats_kernel          per destination row and head: m = max_e z, s = sum_e exp(z - m),
+//                                       z = leaky_relu(el[u] + er[v])            -> nstat[v,h] = (er, m, 1/s, .)
+//             gat_fused_kernel<FWD>     out[v,h,:] = sum_e keep(e,h)/(1-p) * exp(z - m) / s * feat[u,h,:]
+//   backward  gat_fused_kernel<BWD_DST> walks the in-CSR again (gathers feat[u]): d a = <feat[u,h,:], d out[v,h,:]>,
+//                                       d z = a (d a - t) leaky_relu'(.), d er[v,h] = sum_e d z; also writes t[v,h]
+//             gat_fused_kernel<BWD_SRC> walks the out-CSR (gathers d out[v] and nstat[v]): d feat[u,h,:] = sum_e a' d out[v,h,:]
+//                                       and d el[u,h] = sum_e d z
+// using  sum_e a' d a = <out[v,h,:], d out[v,h,:]>  (out IS that weighted sum), so the softmax backward needs no pass
+// of its own.  attn_drop is a counter-based mask keyed by (seed, edge id, head): every kernel regenerates the same bit.
+//
+// All three gather kernels are laid out like the summing g-SpMM (spmm.hip): one wave per work item of the
+// mgx_spmm_plan, lanes ALONG the H*F feature row with 16-byte loads, 64/G neighbour rows per wave-instruction, ids
+// handed out by ds_bpermute as 32-bit byte offsets; hub rows are split by the plan, their partial sums are combined in
+// slot order by gat_rows_fixup_kernel (no atomics: deterministic).  HBM/gather-bound fp32 work, no MFMA.
+#include <math.h>
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace mgx {
+
+__device__ __forceinline__ uint64_t gat_mix64(uint64_t z) {  // splitmix64 finaliser (same generator as elementwise.hip)
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct GatArgs {
+  const int32_t* indptr;
+  const int32_t* indices;
+  const int32_t* eids;      // CSR position -> edge id (NULL: identity); keys the dropout mask
+  const int32_t* item_row;  // plan (all NULL: one item per row)
+  const int32_t* item_beg;
+  const int32_t* item_end;
+  const int32_t* item_node;
+  int64_t n_items;
+  int64_t nblocks;
+  int rpb;
+  int H, F, D;
+  float slope;
+  uint32_t drop_below;  // keep when (uint32)hash >= drop_below
+  float keep_scale;     // 1 / (1 - p)
+  uint64_t seed;
+  const float* gat;     // gathered matrix [*, D]: feat (FWD, BWD_DST) or d out (BWD_SRC)
+  const float* el;      // [num_src, H]
+  const float* er;      // [num_dst, H]  (stats kernel)
+  const float* nstat;   // [num_dst, H, 4] = (er, m, 1/s, t)
+  float* nstat_w;
+  const float* rowa;    // row-constant operand: d out[v] (BWD_DST), feat[u] (BWD_SRC)
+  const float* rowb;    // BWD_DST: out[v]
+  float* out;           // FWD: out; BWD_SRC: d feat
+  float* out_h;         // BWD_DST: d er; BWD_SRC: d el   [rows, H]
+  float* partial;       // [slots, D]
+  float* partial_h;     // [slots, H] (stats: [slots, 2H])
+};
+
+// ---------------------------------------------------------------------------------------------- row statistics
+// lanes = (edge slot j, head h); every lane keeps an online (max, sum) pair, merged across slots at the end.
+template <int LH>
+__global__ __launch_bounds__(kBlock) void gat_stats_kernel(const GatArgs a) {
+  constexpr int EPI = kWave / LH;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int j = lane / LH, h = lane % LH;
+  const bool hact = h < a.H;
+  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * a.rpb;
+  for (int r = wave; r < a.rpb; r += kWavesPerBlock) {
+    const int64_t item = item_base + r;
+    if (item >= a.n_items) break;
+    int64_t row, irow;
+    int32_t beg, end;
+    if (a.item_row) {
+      irow = a.item_row[item];
+      row = a.item_node[item];
+      beg = a.item_beg[item];
+      end = a.item_end[item];
+    } else {
+      irow = row = item;
+      beg = a.indptr[item];
+      end = a.indptr[item + 1];
+    }
+    const float er_v = hact ? a.er[row * a.H + h] : 0.f;
+    float m = -INFINITY, s = 0.f;
+    for (int32_t p = beg + j; p < end; p += EPI) {
+      if (hact) {
+        const float t = a.el[(int64_t)a.indices[p] * a.H + h] + er_v;
+        const float z = t > 0.f ? t : t * a.slope;
+        const float mn = fmaxf(m, z);
+        s = s * __expf(m - mn) + __expf(z - mn);  // m = -inf: exp(-inf) = 0
+        m = mn;
+      }
+    }
+#pragma unroll
+    for (int off = LH; off < kWave; off <<= 1) {
+      const float mo = __shfl_xor(m, off, kWave), so = __shfl_xor(s, off, kWave);
+      const float mn = fmaxf(m, mo);
+      s = (m > -INFINITY ? s * __expf(m - mn) : 0.f) + (mo > -INFINITY ? so * __expf(mo - mn) : 0.f);
+      m = mn;
+    }
+    if (j == 0 && hact) {
+      if (irow >= 0) {
+        v4f st;
+        st.x = er_v;
+        st.y = m > -INFINITY ? m : 0.f;
+        st.z = s > 0.f ? 1.f / s : 0.f;  // rows without in-edges aggregate to 0
+        st.w = 0.f;
+        *reinterpret_cast<v4f*>(a.nstat_w + (row * a.H + h) * 4) = st;
+      } else {
+        const int64_t slot = -(irow + 1);
+        a.partial_h[slot * 2 * a.H + h] = m;
+        a.partial_h[slot * 2 * a.H + a.H + h] = s;
+      }
+    }
+  }
+}
+
+// per hub row and head: merge the chunk statistics in slot order
+__global__ __launch_bounds__(kBlock) void gat_stats_combine_kernel(const int32_t* hub_row, const int32_t* hub_slot_ptr, int64_t n_hubs,
+                                                                   int H, const float* er, const float* partial, float* nstat) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_hubs * H) return;
+  const int64_t hub = t / H;
+  const int h = (int)(t % H);
+  const int s0 = hub_slot_ptr[hub], s1 = hub_slot_ptr[hub + 1];
+  float m = -INFINITY;
+  for (int s = s0; s < s1; ++s) m = fmaxf(m, partial[(int64_t)s * 2 * H + h]);
+  float sum = 0.f;
+  for (int s = s0; s < s1; ++s) {
+    const float mc = partial[(int64_t)s * 2 * H + h];
+    if (mc > -INFINITY) sum += partial[(int64_t)s * 2 * H + H + h] * __expf(mc - m);
+  }
+  const int64_t row = hub_row[hub];
+  v4f st;
+  st.x = er[row * H + h];
+  st.y = m > -INFINITY ? m : 0.f;
+  st.z = sum > 0.f ? 1.f / sum : 0.f;
+  st.w = 0.f;
+  *reinterpret_cast<v4f*>(nstat + (row * H + h) * 4) = st;
+}
+
+// out[hub_row[h], k] = sum over the hub's slots, in slot order, of partial[slot, k]
+__global__ __launch_bounds__(kBlock) void gat_rows_fixup_kernel(const int32_t* hub_row, const int32_t* hub_slot_ptr, int64_t n_hubs,
+                                                                int L, const float* partial, float* out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t h = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (h >= n_hubs) return;
+  const int64_t row = hub_row[h];
+  const int s0 = hub_slot_ptr[h], s1 = hub_slot_ptr[h + 1];
+  for (int k = lane; k < L; k += kWave) {
+    float acc = 0.f;
+    for (int s = s0; s < s1; ++s) acc += partial[(int64_t)s * L + k];
+    out[row * L + k] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- the gather kernels
+enum { GAT_FWD = 0, GAT_BWD_DST = 1, GAT_BWD_SRC = 2 };
+
+template <int G>
+struct GatUnroll {
+  static constexpr int NB = kWave / G;
+  static constexpr int value = NB >= 16 ? 1 : (NB >= 8 ? 2 : 4);
+};
+
+// G lanes cover one H*F row (16 bytes each); LPH = F / 4 lanes share a head.
+template <int G, int LPH, int MODE, bool DROP>
+__global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
+  constexpr int NB = kWave / G;
+  constexpr int U = GatUnroll<G>::value;
+  constexpr int STEP = NB * U;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int sub = lane / G, l = lane % G;
+  const int D = a.D, H = a.H;
+  const int f = l * 4;
+  const bool fact = f < D;
+  const int head = fact ? l / LPH : 0;
+  const uint32_t rowbytes = (uint32_t)D * 4u;
+  const uint32_t f4 = fact ? (uint32_t)f * 4u : 0u;  // idle feature lanes re-read the row start, never stored
+  const uint32_t hbytes = (uint32_t)H * (MODE == GAT_BWD_SRC ? 16u : 4u);  // per-node stride of the small per-head array
+  const uint32_t h4 = (uint32_t)head * (MODE == GAT_BWD_SRC ? 16u : 4u);
+  const char* __restrict__ gatb = reinterpret_cast<const char*>(a.gat);
+  const char* __restrict__ smallb = reinterpret_cast<const char*>(MODE == GAT_BWD_SRC ? a.nstat : a.el);
+  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * a.rpb;
+
+  for (int r = wave; r < a.rpb; r += kWavesPerBlock) {
+    const int64_t item = item_base + r;
+    if (item >= a.n_items) break;
+    int64_t row, irow;
+    int32_t beg, end;
+    if (a.item_row) {
+      irow = a.item_row[item];
+      row = a.item_node[item];
+      beg = a.item_beg[item];
+      end = a.item_end[item];
+    } else {
+      irow = row = item;
+      beg = a.indptr[item];
+      end = a.indptr[item + 1];
+    }
+    // ---- row constants
+    v4f ra = (v4f)(0.f);
+    float c_er = 0.f, c_m = 0.f, c_is = 0.f, c_t = 0.f, c_el = 0.f;
+    if (MODE == GAT_FWD || MODE == GAT_BWD_DST) {
+      if (fact) {
+        const v4f st = *reinterpret_cast<const v4f*>(a.nstat + (row * H + head) * 4);
+        c_er = st.x; c_m = st.y; c_is = st.z;
+      }
+    }
+    if (MODE == GAT_BWD_DST) {
+      v4f ov = (v4f)(0.f);
+      if (fact) {
+        ra = *reinterpret_cast<const v4f*>(a.rowa + row * D + f);  // d out[v]
+        ov = *reinterpret_cast<const v4f*>(a.rowb + row * D + f);  // out[v]
+      }
+      float t = ra.x * ov.x + ra.y * ov.y + ra.z * ov.z + ra.w * ov.w;  // idle lanes take part with zeros
+#pragma unroll
+      for (int off = 1; off < LPH; off <<= 1) t += __shfl_xor(t, off, kWave);
+      c_t = t;
+      // every chunk of a hub row writes the same value
+      if (fact && (l % LPH) == 0 && sub == 0) a.nstat_w[(row * H + head) * 4 + 3] = t;
+    }
+    if (MODE == GAT_BWD_SRC && fact) {
+      ra = *reinterpret_cast<const v4f*>(a.rowa + row * D + f);  // feat[u]
+      c_el = a.el[row * H + head];
+    }
+    v4f acc = (v4f)(0.f);
+    float hacc = 0.f;  // d er (BWD_DST) / d el (BWD_SRC) of this lane's head
+
+    for (int32_t cbase = beg; cbase < end; cbase += kWave) {
+      const int32_t q = cbase + lane;
+      uint32_t goff = 0, soff = 0;
+      int32_t eid = 0;
+      if (q < end) {
+        const int32_t gid = __builtin_nontemporal_load(&a.indices[q]);
+        goff = (uint32_t)gid * rowbytes;
+        soff = (uint32_t)gid * hbytes;
+        if (DROP) eid = a.eids ? __builtin_nontemporal_load(&a.eids[q]) : q;
+      }
+      const int cnt = (end - cbase) < kWave ? (end - cbase) : kWave;
+      for (int k = 0; k < cnt; k += STEP) {
+        v4f val[U];
+        v4f sm[U];
+        int32_t ee[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int jdx = k + u * NB + sub;
+          const int bi = (jdx < cnt ? jdx : 0) * 4;  // lanes past the end re-read edge 0 (valid memory), weight zeroed below
+          const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)goff) + f4;
+          const uint32_t so = (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)soff) + h4;
+          ee[u] = DROP ? __builtin_amdgcn_ds_bpermute(bi, eid) : 0;
+          val[u] = *reinterpret_cast<const v4f*>(gatb + off);
+          if (MODE == GAT_BWD_SRC) sm[u] = *reinterpret_cast<const v4f*>(smallb + so);
+          else sm[u].x = *reinterpret_cast<const float*>(smallb + so);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool live = k + u * NB + sub < cnt;
+          float keep = 1.f;
+          if (DROP) {
+            const uint64_t rnd = gat_mix64(a.seed ^ ((uint64_t)(uint32_t)ee[u] * (uint64_t)H + (uint64_t)head));
+            keep = (uint32_t)rnd >= a.drop_below ? a.keep_scale : 0.f;
+          }
+          if (MODE == GAT_FWD) {
+            const float t = sm[u].x + c_er;
+            const float z = t > 0.f ? t : t * a.slope;
+            float w = __expf(z - c_m) * c_is * keep;
+            w = live ? w : 0.f;
+            acc += val[u] * w;
+          } else {
+            const float t = MODE == GAT_BWD_DST ? sm[u].x + c_er : c_el + sm[u].x;
+            const float mm = MODE == GAT_BWD_DST ? c_m : sm[u].y;
+            const float is = MODE == GAT_BWD_DST ? c_is : sm[u].z;
+            const float tt = MODE == GAT_BWD_DST ? c_t : sm[u].w;
+            const float z = t > 0.f ? t : t * a.slope;
+            const float av = __expf(z - mm) * is;
+            float dot = val[u].x * ra.x + val[u].y * ra.y + val[u].z * ra.z + val[u].w * ra.w;
+#pragma unroll
+            for (int off = 1; off < LPH; off <<= 1) dot += __shfl_xor(dot, off, kWave);
+            float de = av * (dot * keep - tt) * (t > 0.f ? 1.f : a.slope);
+            de = live ? de : 0.f;
+            hacc += de;
+            if (MODE == GAT_BWD_SRC) {
+              const float w = live ? av * keep : 0.f;
+              acc += val[u] * w;
+            }
+          }
+        }
+      }
+    }
+    // ---- combine the lane groups, write the row (or the partial slot of a hub chunk)
+    if (MODE != GAT_BWD_DST) {
+#pragma unroll
+      for (int off = G; off < kWave; off <<= 1) acc += vec_shfl_xor<4>(acc, off);
+    }
+    if (MODE != GAT_FWD) {
+#pragma unroll
+      for (int off = G; off < kWave; off <<= 1) hacc += __shfl_xor(hacc, off, kWave);
+    }
+    if (fact && sub == 0) {
+      if (MODE != GAT_BWD_DST) {
+        float* op = irow >= 0 ? a.out + row * (int64_t)D + f : a.partial + (-(irow + 1)) * (int64_t)D + f;
+        *reinterpret_cast<v4f*>(op) = acc;
+      }
+      if (MODE != GAT_FWD && (l % LPH) == 0) {
+        float* op = irow >= 0 ? a.out_h + row * (int64_t)H + head : a.partial_h + (-(irow + 1)) * (int64_t)H + head;
+        *op = hacc;
+      }
+    }
+  }
+}
+
+template <int G, int LPH, int MODE>
+static void gat_launch_drop(const GatArgs& a, bool drop, hipStream_t s) {
+  const dim3 grid((unsigned)a.nblocks), block(kBlock);
+  if (drop) hipLaunchKernelGGL((gat_fused_kernel<G, LPH, MODE, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gat_fused_kernel<G, LPH, MODE, false>), grid, block, 0, s, a);
+}
+
+template <int G, int MODE>
+static bool gat_launch_lph(const GatArgs& a, int lph, bool drop, hipStream_t s) {
+  switch (lph) {
+#define MGX_GAT_LPH(L) case L: if (L <= G) { gat_launch_drop<G, (L <= G ? L : G), MODE>(a, drop, s); return true; } return false;
+    MGX_GAT_LPH(1) MGX_GAT_LPH(2) MGX_GAT_LPH(4) MGX_GAT_LPH(8) MGX_GAT_LPH(16) MGX_GAT_LPH(32) MGX_GAT_LPH(64)
+#undef MGX_GAT_LPH
+    default: return false;
+  }
+}
+
+template <int MODE>
+static bool gat_launch(const GatArgs& a, bool drop, hipStream_t s) {
+  int G = 1;
+  while (G * 4 < a.D) G <<= 1;
+  const int lph = a.F / 4;
+  switch (G) {
+    case 1: return gat_launch_lph<1, MODE>(a, lph, drop, s);
+    case 2: return gat_launch_lph<2, MODE>(a, lph, drop, s);
+    case 4: return gat_launch_lph<4, MODE>(a, lph, drop, s);
+    case 8: return gat_launch_lph<8, MODE>(a, lph, drop, s);
+    case 16: return gat_launch_lph<16, MODE>(a, lph, drop, s);
+    case 32: return gat_launch_lph<32, MODE>(a, lph, drop, s);
+    case 64: return gat_launch_lph<64, MODE>(a, lph, drop, s);
+    default: return false;
+  }
+}
+
+static int gat_rows_per_block() {
+  const char* e = getenv("MGX_ROWS_PER_BLOCK");
+  int x = e ? atoi(e) : 16;
+  if (x < 4) x = 4;
+  if (x > 1024) x = 1024;
+  return x / 4 * 4;
+}
+
+static int32_t gat_check(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, int64_t F, int64_t gathered_rows, float p,
+                         const char* who) {
+  MGX_CHECK_ARG(csr != nullptr, "%s: csr is NULL", who);
+  if (csr->idx_bits != 32) MGX_UNSUPPORTED("%s: 32-bit graph indices only (got %d)", who, csr->idx_bits);
+  MGX_CHECK_ARG(H >= 1 && F >= 1, "%s: H and F must be positive", who);
+  if (F % 4 != 0 || ((F / 4) & (F / 4 - 1)) != 0 || H * F > 256)
+    MGX_UNSUPPORTED("%s: needs F in {4, 8, 16, ..., 256} and H*F <= 256 (got H = %lld, F = %lld)", who, (long long)H, (long long)F);
+  if (gathered_rows * H * F * 4 >= (int64_t(1) << 32) || gathered_rows * H * 16 >= (int64_t(1) << 32) || csr->nnz >= (int64_t(1) << 31))
+    MGX_UNSUPPORTED("%s: operands beyond 32-bit byte offsets", who);
+  MGX_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout probability %g outside [0, 1)", who, (double)p);
+  MGX_CHECK_ARG(csr->num_rows == 0 || csr->indptr, "%s: indptr is NULL", who);
+  MGX_CHECK_ARG(csr->nnz == 0 || csr->indices, "%s: indices is NULL", who);
+  if (plan) {
+    MGX_CHECK_ARG(plan->item_row && plan->item_beg && plan->item_end && plan->item_node && plan->num_items >= csr->num_rows,
+                  "%s: malformed plan", who);
+    MGX_CHECK_ARG(plan->num_slots == 0 || (plan->hub_row && plan->hub_slot_ptr), "%s: plan has split rows but no hub tables", who);
+  }
+  return MGX_OK;
+}
+
+static void gat_fill(GatArgs& a, const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, int64_t F, float slope, float p,
+                     uint64_t seed) {
+  memset(&a, 0, sizeof(a));
+  a.indptr = (const int32_t*)csr->indptr; a.indices = (const int32_t*)csr->indices; a.eids = (const int32_t*)csr->eids;
+  a.n_items = csr->num_rows;
+  if (plan) {
+    a.item_row = plan->item_row; a.item_beg = (const int32_t*)plan->item_beg; a.item_end = (const int32_t*)plan->item_end;
+    a.item_node = plan->item_node; a.n_items = plan->num_items;
+  }
+  a.rpb = gat_rows_per_block();
+  a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);
+  a.H = (int)H; a.F = (int)F; a.D = (int)(H * F);
+  a.slope = slope; a.seed = seed;
+  a.keep_scale = 1.f / (1.f - p);
+  double thr = (double)p * 4294967296.0;
+  a.drop_below = thr >= 4294967295.0 ? 4294967295u : (uint32_t)thr;
+}
+
+static void gat_fixup(const mgx_spmm_plan* plan, int L, const float* partial, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(gat_rows_fixup_kernel, dim3((unsigned)((plan->num_hubs + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s,
+                     plan->hub_row, plan->hub_slot_ptr, plan->num_hubs, L, partial, out);
+}
+
+}  // namespace mgx
+
+extern "C" int64_t mgx_gat_fused_workspace(const mgx_spmm_plan* plan, int64_t H, int64_t F) {
+  const int64_t slots = plan ? plan->num_slots : 0;
+  int64_t per = H * F + H;          // gather kernels: [slots, D] + [slots, H]
+  if (2 * H > per) per = 2 * H;     // stats kernel: [slots, 2H]
+  return slots * per * (int64_t)sizeof(float);
+}
+
+extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, int64_t F, const float* feat,
+                                     const float* el, const float* er, float negative_slope, float drop_p, uint64_t seed,
+                                     float* out, float* nstat, void* workspace, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  int32_t st = gat_check(csr, plan, H, F, csr ? csr->num_cols : 0, drop_p, "mgx_gat_fused_fwd");
+  if (st != MGX_OK) return st;
+  if (csr->num_rows == 0) return MGX_OK;
+  MGX_CHECK_ARG(el && er && out && nstat && (feat || csr->nnz == 0), "mgx_gat_fused_fwd: NULL pointer");
+  MGX_CHECK_ARG((uintptr_t)feat % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)nstat % 16 == 0, "mgx_gat_fused_fwd: pointers must be 16-byte aligned");
+  const bool hubs = plan && plan->num_slots > 0;
+  MGX_CHECK_ARG(!hubs || workspace, "mgx_gat_fused_fwd: plan has split rows but no workspace");
+  hipStream_t s = (hipStream_t)stream;
+  GatArgs a;
+  gat_fill(a, csr, plan, H, F, negative_slope, drop_p, seed);
+  a.el = el; a.er = er; a.nstat_w = nstat; a.partial_h = (float*)workspace;
+  int LH = 1;
+  while (LH < H) LH <<= 1;
+  const dim3 grid((unsigned)a.nblocks), block(kBlock);
+  switch (LH) {
+#define MGX_GAT_ST(L) case L: hipLaunchKernelGGL((gat_stats_kernel<L>), grid, block, 0, s, a); break;
+    MGX_GAT_ST(1) MGX_GAT_ST(2) MGX_GAT_ST(4) MGX_GAT_ST(8) MGX_GAT_ST(16) MGX_GAT_ST(32)
+    default: hipLaunchKernelGGL((gat_stats_kernel<64>), grid, block, 0, s, a); break;
+#undef MGX_GAT_ST
+  }
+  MGX_CHECK_LAUNCH();
+  if (hubs) {
+    hipLaunchKernelGGL(gat_stats_combine_kernel, dim3((unsigned)((plan->num_hubs * H + kBlock - 1) / kBlock)), block, 0, s, plan->hub_row,
+                       plan->hub_slot_ptr, plan->num_hubs, (int)H, er, (const float*)workspace, nstat);
+    MGX_CHECK_LAUNCH();
+  }
+  a.gat = feat; a.nstat = nstat; a.out = out; a.partial = (float*)workspace; a.partial_h = nullptr;
+  if (!gat_launch<GAT_FWD>(a, drop_p > 0.f, s)) MGX_UNSUPPORTED("mgx_gat_fused_fwd: unsupported head layout H = %lld, F = %lld", (long long)H, (long long)F);
+  MGX_CHECK_LAUNCH();
+  if (hubs) {
+    gat_fixup(plan, a.D, (const float*)workspace, out, s);
+    MGX_CHECK_LAUNCH();
+  }
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan, const mgx_csr* csr, const mgx_spmm_plan* csr_plan,
+                                     int64_t H, int64_t F, const float* feat, const float* el, float negative_slope, float drop_p,
+                                     uint64_t seed, const float* out, const float* d_out, float* nstat, float* d_feat, float* d_el,
+                                     float* d_er, void* workspace, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  int32_t st = gat_check(csc, csc_plan, H, F, csc ? csc->num_cols : 0, drop_p, "mgx_gat_fused_bwd");
+  if (st != MGX_OK) return st;
+  st = gat_check(csr, csr_plan, H, F, csr ? csr->num_cols : 0, drop_p, "mgx_gat_fused_bwd");
+  if (st != MGX_OK) return st;
+  MGX_CHECK_ARG(csc->num_rows == csr->num_cols && csc->num_cols == csr->num_rows && csc->nnz == csr->nnz,
+                "mgx_gat_fused_bwd: the two CSRs are not transposes of each other");
+  if (csc->num_rows == 0 || csr->num_rows == 0) return MGX_OK;
+  MGX_CHECK_ARG(feat && el && out && d_out && nstat && d_er && (d_feat || !d_el || true), "mgx_gat_fused_bwd: NULL pointer");
+  MGX_CHECK_ARG((uintptr_t)feat % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)d_out % 16 == 0 && (uintptr_t)nstat % 16 == 0 &&
+                (!d_feat || (uintptr_t)d_feat % 16 == 0), "mgx_gat_fused_bwd: pointers must be 16-byte aligned");
+  const bool hubs_dst = csc_plan && csc_plan->num_slots > 0, hubs_src = csr_plan && csr_plan->num_slots > 0;
+  MGX_CHECK_ARG(!(hubs_dst || hubs_src) || workspace, "mgx_gat_fused_bwd: plan has split rows but no workspace");
+  hipStream_t s = (hipStream_t)stream;
+  const int D = (int)(H * F);
+  {  // destination side: t[v,h] and d er
+    GatArgs a;
+    gat_fill(a, csc, csc_plan, H, F, negative_slope, drop_p, seed);
+    a.gat = feat; a.el = el; a.nstat = nstat; a.nstat_w = nstat; a.rowa = d_out; a.rowb = out; a.out_h = d_er;
+    a.partial_h = (float*)workspace;
+    if (!gat_launch<GAT_BWD_DST>(a, drop_p > 0.f, s)) MGX_UNSUPPORTED("mgx_gat_fused_bwd: unsupported head layout");
+    MGX_CHECK_LAUNCH();
+    if (hubs_dst) {
+      gat_fixup(csc_plan, (int)H, (const float*)workspace, d_er, s);
+      MGX_CHECK_LAUNCH();
+    }
+  }
+  if (d_feat || d_el) {  // source side: d feat and d el (needs t of every destination: after the launch above, same stream)
+    MGX_CHECK_ARG(d_feat && d_el, "mgx_gat_fused_bwd: d_feat and d_el come together");
+    GatArgs a;
+    gat_fill(a, csr, csr_plan, H, F, negative_slope, drop_p, seed);
+    a.gat = d_out; a.el = el; a.nstat = nstat; a.rowa = feat; a.out = d_feat; a.out_h = d_el;
+    float* ws = (float*)workspace;
+    a.partial = ws;
+    a.partial_h = ws ? ws + (csr_plan ? csr_plan->num_slots : 0) * (int64_t)D : nullptr;
+    if (!gat_launch<GAT_BWD_SRC>(a, drop_p > 0.f, s)) MGX_UNSUPPORTED("mgx_gat_fused_bwd: unsupported head layout");
+    MGX_CHECK_LAUNCH();
+    if (hubs_src) {
+      gat_fixup(csr_plan, D, a.partial, d_feat, s);
+      gat_fixup(csr_plan, (int)H, a.partial_h, d_el, s);
+      MGX_CHECK_LAUNCH();
+    }
+  }
+  return MGX_OK;
+}

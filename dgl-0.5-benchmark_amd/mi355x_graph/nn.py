@@ -139,15 +139,22 @@ class GATConv(nn.Module):
             else:
                 el = (feat_src * self.attn_l).sum(dim=-1).unsqueeze(-1)
                 er = (feat_dst * self.attn_r).sum(dim=-1).unsqueeze(-1)
+            rst = None
+            if not get_attention and ops.gat_fused_supported(graph, feat_src):
+                # the whole block u_add_v -> leaky_relu -> edge_softmax -> attn_drop -> u_mul_e/sum without any E x H tensor
+                rst = ops.gat_fused(graph, feat_src, el, er, self.leaky_relu.negative_slope, self.attn_drop.p, self.training)
             # e and a are internal to the module: keep them in in-CSR (destination-major) edge order so that
             # u_add_v, edge_softmax and u_mul_e/sum stream them instead of gathering by edge id
-            cidx, perm = graph._index.canonical()
-            if int(el.shape[1]) <= 64:  # fused u_add_v -> leaky_relu -> edge_softmax: the logits are never materialised
+            cidx, perm = graph._index.canonical() if rst is None else (None, None)
+            if rst is not None:
+                pass
+            elif int(el.shape[1]) <= 64:  # fused u_add_v -> leaky_relu -> edge_softmax: the logits are never materialised
                 a = self.attn_drop(ops.gat_attention(cidx, el, er, self.leaky_relu.negative_slope))
             else:
                 e = self.leaky_relu(ops.gsddmm(cidx, "add", el, er, "u", "v"))
                 a = self.attn_drop(ops.edge_softmax(cidx, e))
-            rst = ops.gspmm(cidx, "mul", "sum", feat_src, a)
+            if rst is None:
+                rst = ops.gspmm(cidx, "mul", "sum", feat_src, a)
             if self.res_fc is not None:
                 resval = self.res_fc(h_dst).view(h_dst.shape[0], -1, self._out_feats)
                 rst = rst + resval

@@ -18,7 +18,7 @@ from ._lib import DGLError
 from . import sparse
 from .graph import DGLGraph, GraphIndex
 
-__all__ = ["gspmm", "gsddmm", "edge_softmax", "gat_attention", "segment_reduce", "copy_u_sum", "copy_u_mean", "u_mul_e_sum",
+__all__ = ["gspmm", "gsddmm", "edge_softmax", "gat_attention", "gat_fused", "segment_reduce", "copy_u_sum", "copy_u_mean", "u_mul_e_sum",
            "copy_e_sum", "u_add_v", "u_dot_v"]
 
 
@@ -249,6 +249,62 @@ def gat_attention(graph, el, er, negative_slope=0.2):
     if el.shape[1:] != er.shape[1:]:
         raise DGLError("gat_attention: el %s and er %s disagree" % (tuple(el.shape[1:]), tuple(er.shape[1:])))
     return GATAttention.apply(_gidx(graph), el, er, negative_slope)
+
+
+class GATFused(torch.autograd.Function):
+    """out[v,h,:] = sum_e dropout(softmax_{e->v}(leaky_relu(el[u] + er[v])))[e,h] * feat[u,h,:] -- GATConv's whole
+    message-passing block (main_dgl_reddit_gat.py:31-55) in two launches forward and two backward, with no E-sized
+    tensor: the attention of an edge is rebuilt from per-node statistics where it is needed (csrc/gatfused.hip)."""
+
+    _calls = 0  # advances the counter-based generator: a new mask per call, reproducible after torch.manual_seed
+
+    @staticmethod
+    def forward(ctx, gidx, feat, el, er, slope, p):
+        csc = gidx.csc()
+        H, F = int(feat.shape[1]), int(feat.shape[2])
+        if el.shape[0] != csc.num_cols or er.shape[0] != csc.num_rows or feat.shape[0] != csc.num_cols:
+            raise DGLError("gat_fused: expected feat / el with %d source rows and er with %d destination rows, got %d / %d / %d"
+                           % (csc.num_cols, csc.num_rows, feat.shape[0], el.shape[0], er.shape[0]))
+        feat = feat.contiguous()
+        el2, er2 = el.contiguous().view(el.shape[0], H), er.contiguous().view(er.shape[0], H)
+        seed = 0
+        if p > 0.0:
+            seed = ((torch.initial_seed() & (2 ** 64 - 1)) ^ ((GATFused._calls * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)))
+            GATFused._calls += 1
+        out, nstat = sparse.backend_for(feat).gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed)
+        ctx.backward_cache = gidx, float(slope), float(p), seed, el.shape, er.shape
+        ctx.save_for_backward(feat, el2, out, nstat)
+        return out
+
+    @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
+    def backward(ctx, d_out):
+        gidx, slope, p, seed, el_shape, er_shape = ctx.backward_cache
+        feat, el2, out, nstat = ctx.saved_tensors
+        need_src = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        d_feat, d_el, d_er = sparse.backend_for(feat).gat_fused_bwd(gidx.csc(), gidx.csr(), feat, el2, slope, p, seed, out,
+                                                                     d_out.contiguous(), nstat, need_src)
+        return (None, d_feat if ctx.needs_input_grad[1] else None,
+                d_el.view(el_shape) if (d_el is not None and ctx.needs_input_grad[2]) else None,
+                d_er.view(er_shape) if ctx.needs_input_grad[3] else None, None, None)
+
+
+def gat_fused_supported(graph, feat):
+    gidx = _gidx(graph)
+    return (feat.dim() == 3 and feat.dtype == torch.float32 and feat.is_cuda and os.environ.get("MGX_GAT_FUSED", "1") == "1"
+            and sparse.backend_for(feat).name == "hip"
+            and sparse.backend_for(feat).gat_fused_supported(gidx.csc(), int(feat.shape[1]), int(feat.shape[2])))
+
+
+def gat_fused(graph, feat, el, er, negative_slope=0.2, attn_drop=0.0, training=True):
+    """GATConv's u_add_v -> leaky_relu -> edge_softmax -> attn_drop -> u_mul_e/sum block.  feat (N_src, H, F),
+    el (N_src, H[, 1]), er (N_dst, H[, 1]) -> (N_dst, H, F).  Check gat_fused_supported() first."""
+    if feat.dtype != torch.float32 or el.dtype != torch.float32 or er.dtype != torch.float32:
+        raise DGLError("gat_fused expects float32 inputs")
+    p = float(attn_drop) if training else 0.0
+    if not 0.0 <= p < 1.0:
+        raise DGLError("gat_fused: attn_drop must be in [0, 1), got %g" % p)
+    return GATFused.apply(_gidx(graph), feat, el, er, negative_slope, p)
 
 
 class HeadDot(torch.autograd.Function):

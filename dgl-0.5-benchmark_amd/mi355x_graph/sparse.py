@@ -326,6 +326,51 @@ class HipBackend(object):
         return de
 
     @staticmethod
+    def gat_fused_supported(csr, H, F):
+        """Shapes mgx_gat_fused_* takes: F a power of two >= 4, H*F <= 256, 32-bit indices and byte offsets."""
+        return (F >= 4 and F % 4 == 0 and ((F // 4) & (F // 4 - 1)) == 0 and H * F <= 256 and csr.idx_bits == 32
+                and max(csr.num_cols, csr.num_rows) * H * max(F * 4, 16) < 2 ** 32 and csr.nnz < 2 ** 31)
+
+    @staticmethod
+    def _plan_ptr(plan):
+        return None if plan is None else ctypes.byref(plan.c_struct())
+
+    def _gat_ws(self, plans, H, F, dev):
+        L = _lib.lib()
+        need = max([L.mgx_gat_fused_workspace(self._plan_ptr(p), H, F) for p in plans] + [0])
+        return torch.empty(need // 4, dtype=torch.float32, device=dev) if need else None
+
+    def gat_fused_fwd(self, csc, feat3d, el2d, er2d, slope, p, seed):
+        """feat3d [n_src, H, F], el2d [n_src, H], er2d [n_dst, H] -> (out [n_dst, H, F], nstat [n_dst, H, 4])."""
+        dev = self._check_dev(csc.indptr, feat3d, el2d, er2d)
+        H, F = int(feat3d.shape[1]), int(feat3d.shape[2])
+        out = torch.empty((csc.num_rows, H, F), dtype=torch.float32, device=dev)
+        nstat = torch.empty((csc.num_rows, H, 4), dtype=torch.float32, device=dev)
+        plan = csc.plan()
+        ws = self._gat_ws([plan], H, F, dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_gat_fused_fwd(ctypes.byref(csc.c_struct()), self._plan_ptr(plan), H, F, _ptr(feat3d), _ptr(el2d),
+                                                    _ptr(er2d), ctypes.c_float(slope), ctypes.c_float(p), ctypes.c_uint64(seed),
+                                                    _ptr(out), _ptr(nstat), _ptr(ws), _stream(dev)))
+        return out, nstat
+
+    def gat_fused_bwd(self, csc, csr, feat3d, el2d, slope, p, seed, out3d, d_out3d, nstat, need_src):
+        """-> (d_feat | None, d_el | None, d_er); nstat[..., 3] is overwritten with <out, d_out> per head."""
+        dev = self._check_dev(csc.indptr, csr.indptr, feat3d, el2d, out3d, d_out3d, nstat)
+        H, F = int(feat3d.shape[1]), int(feat3d.shape[2])
+        d_er = torch.empty((csc.num_rows, H), dtype=torch.float32, device=dev)
+        d_feat = torch.empty_like(feat3d) if need_src else None
+        d_el = torch.empty((csc.num_cols, H), dtype=torch.float32, device=dev) if need_src else None
+        p_dst, p_src = csc.plan(), csr.plan()
+        ws = self._gat_ws([p_dst, p_src], H, F, dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_gat_fused_bwd(ctypes.byref(csc.c_struct()), self._plan_ptr(p_dst), ctypes.byref(csr.c_struct()),
+                                                    self._plan_ptr(p_src), H, F, _ptr(feat3d), _ptr(el2d), ctypes.c_float(slope),
+                                                    ctypes.c_float(p), ctypes.c_uint64(seed), _ptr(out3d), _ptr(d_out3d), _ptr(nstat),
+                                                    _ptr(d_feat), _ptr(d_el), _ptr(d_er), _ptr(ws), _stream(dev)))
+        return d_feat, d_el, d_er
+
+    @staticmethod
     def head_dot_supported(H, F):
         return H * F <= 256 and (F <= 64 or F in (128, 256))
 

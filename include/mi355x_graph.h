@@ -197,6 +197,29 @@ int32_t mgx_gat_attention_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* m
                               const float* el, const float* er, float negative_slope,
                               const float* a, const float* da, float* de, float* ws, void* stream);
 
+/* One GAT layer's message passing with NO E-sized tensor (GATConv between its projection and its bias,
+ * main_dgl_reddit_gat.py:10,31-55: apply_edges(fn.u_add_v) -> leaky_relu -> edge_softmax -> attn_drop ->
+ * update_all(fn.u_mul_e, fn.sum)):
+ *   fwd: out[v,h,:] = sum_{e:(u->v)} keep(e,h)/(1-p) * a[e,h] * feat[u,h,:],  a = softmax_{e->v}(leaky_relu(el[u,h] + er[v,h]))
+ *        nstat[v,h,0..3] = (er, row max, 1 / row sum, -) is what the backward rebuilds a[e,h] from; `a` is never written.
+ *   bwd: d_er[v,h], then d_feat[u,h,:] and d_el[u,h] (both or neither); `csc` is the in-CSR the forward ran on, `csr` its
+ *        transpose (rows = source nodes) whose eids map to the in-CSR's edge ids (NULL eids = positions) so that both walks
+ *        regenerate the same dropout bit for an edge; nstat[.,.,3] receives t = <out, d_out> per head.
+ * feat [num_cols, H*F], el [num_cols, H], er [num_rows, H], out / d_out [num_rows, H*F], nstat [num_rows, H, 4], 16-byte
+ * aligned; F in {4, 8, ..., 256}, H*F <= 256, 32-bit indices (else MGX_ERR_UNSUPPORTED: callers fall back to
+ * mgx_gat_attention_* + mgx_spmm_csr).  keep(e,h) = hash(seed, e*H + h) >= p * 2^32 (counter based; drop_p = 0: no mask).
+ * workspace: max over the plans passed of mgx_gat_fused_workspace(plan, H, F) bytes (NULL when no plan splits rows).
+ * Deterministic: no atomics, hub partial sums combined in slot order. */
+int64_t mgx_gat_fused_workspace(const mgx_spmm_plan* plan /* may be NULL */, int64_t H, int64_t F);
+int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int64_t H, int64_t F,
+                          const float* feat, const float* el, const float* er, float negative_slope, float drop_p,
+                          uint64_t seed, float* out, float* nstat, void* workspace, void* stream);
+int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan /* may be NULL */, const mgx_csr* csr,
+                          const mgx_spmm_plan* csr_plan /* may be NULL */, int64_t H, int64_t F, const float* feat,
+                          const float* el, float negative_slope, float drop_p, uint64_t seed, const float* out,
+                          const float* d_out, float* nstat, float* d_feat /* may be NULL with d_el */, float* d_el,
+                          float* d_er, void* workspace, void* stream);
+
 /* ------------------------------------------------------------------ GAT attention terms
  * el[n,h] = sum_f feat[n,h,f] * attn[h,f] -- GATConv's `(feat * attn_l).sum(-1)` (main_dgl_reddit_gat.py:10, UPSTREAM
  * dgl.nn.pytorch.GATConv.forward), one pass; attn_b/out_b (may be NULL) apply a second attention vector to the same

@@ -1,0 +1,194 @@
+"""GPU suite: the fused GAT message-passing block (mgx_gat_fused_fwd/bwd, csrc/gatfused.hip) against the CPU oracle's
+composition  sddmm(add) -> leaky_relu -> edge_softmax -> spmm(mul, sum)  -- the chain GATConv runs at
+main_dgl_reddit_gat.py:31-55 -- and, for the gradients, against the library's own unfused operators (which are held to
+the oracle in test_gpu_parity.py).  Tolerance: 1e-4 relative (north_star), stated at each assert."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mi355x_graph as mg
+from mi355x_graph import ops
+from conftest import random_graph
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+DEV = "cuda:0"
+
+
+def mk(n_src, n_dst, src, dst):
+    return mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=torch.int32, device=DEV)
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def hubby_graph(n, nnz, seed, hub_deg=3000):
+    """random graph + one hub destination (chunked rows) + one hub source + a few nodes without in-edges"""
+    src, dst = random_graph(n, n, nnz, seed=seed)
+    rng = np.random.default_rng(seed)
+    keep = dst >= 5                      # nodes 0..4 receive nothing
+    src, dst = src[keep], dst[keep]
+    hs = rng.integers(0, n, hub_deg)
+    src = np.concatenate([src, hs, np.full(hub_deg, 7)])
+    dst = np.concatenate([dst, np.full(hub_deg, 11), rng.integers(5, n, hub_deg)])
+    return src.astype(np.int64), dst.astype(np.int64)
+
+
+def unfused(g, feat, el, er, slope):
+    a = ops.edge_softmax(g, F.leaky_relu(ops.gsddmm(g, "add", el, er, "u", "v"), slope))
+    return ops.gspmm(g, "mul", "sum", feat, a)
+
+
+@pytest.mark.parametrize("n,H,Fd", [(900, 1, 16), (900, 8, 16), (700, 4, 8), (500, 2, 64), (300, 1, 4), (600, 3, 16), (400, 1, 256),
+                                    (400, 16, 4), (350, 2, 128)])
+def test_fused_forward_matches_oracle_composition(oracle, n, H, Fd):
+    nnz = 40 * n
+    src, dst = hubby_graph(n, nnz, seed=H * 100 + Fd)
+    E = src.shape[0]
+    g = mk(n, n, src, dst)
+    rng = np.random.default_rng(H + Fd)
+    feat = rng.standard_normal((n, H, Fd)).astype(np.float32)
+    el = (rng.standard_normal((n, H, 1)) * 2).astype(np.float32)
+    er = (rng.standard_normal((n, H, 1)) * 2).astype(np.float32)
+    assert ops.gat_fused_supported(g, T(feat))
+    out = ops.gat_fused(g, T(feat), T(el), T(er), 0.2, 0.0, True)
+    assert out.shape == (n, H, Fd)
+    ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+    z = oracle.sddmm(src, dst, "add", el, er)
+    z = np.where(z > 0, z, 0.2 * z).astype(np.float32)
+    a = oracle.edge_softmax_fwd(ip, ei, z.reshape(E, H))
+    ref = oracle.spmm(ip, ix, ei, "mul", "sum", feat, a.reshape(E, H, 1))
+    got = out.cpu().numpy()
+    # signed sums cancel: error relative to the row's sum of |terms| (<= max |feat| since the weights sum to 1)
+    scale = np.abs(feat).max()
+    assert float(np.abs(got - ref).max()) < RTOL * scale, float(np.abs(got - ref).max())
+    assert np.all(got[:5] == 0.0)  # nodes without in-edges aggregate to exactly 0
+
+
+@pytest.mark.parametrize("n,H,Fd", [(900, 8, 16), (800, 1, 16), (500, 2, 64), (600, 3, 16), (300, 4, 4)])
+def test_fused_gradients_match_unfused_operators(n, H, Fd):
+    nnz = 40 * n
+    src, dst = hubby_graph(n, nnz, seed=H * 7 + Fd)
+    g = mk(n, n, src, dst)
+    torch.manual_seed(H + Fd)
+    feat0 = torch.randn(n, H, Fd, device=DEV)
+    el0, er0 = torch.randn(n, H, 1, device=DEV) * 2, torch.randn(n, H, 1, device=DEV) * 2
+    w = torch.randn(n, H, Fd, device=DEV)
+    ins1 = [t.clone().requires_grad_(True) for t in (feat0, el0, er0)]
+    ins2 = [t.clone().requires_grad_(True) for t in (feat0, el0, er0)]
+    o1 = ops.gat_fused(g, ins1[0], ins1[1], ins1[2], 0.2, 0.0, True)
+    o2 = unfused(g, ins2[0], ins2[1], ins2[2], 0.2)
+    assert float((o1 - o2).detach().abs().max()) < RTOL * float(feat0.abs().max())
+    (o1 * w).sum().backward()
+    (o2 * w).sum().backward()
+    for name, x, y in zip(("d_feat", "d_el", "d_er"), ins1, ins2):
+        err, ref = float((x.grad - y.grad).abs().max()), float(y.grad.abs().max())
+        assert err < RTOL * max(ref, 1e-6), (name, err, ref)  # 1e-4 of the gradient tensor's scale (hub rows sum 3000 terms)
+    # second backward through the same saved tensors (nstat[..., 3] is rewritten, not accumulated)
+    ins3 = [t.clone().requires_grad_(True) for t in (feat0, el0, er0)]
+    o3 = ops.gat_fused(g, ins3[0], ins3[1], ins3[2], 0.2, 0.0, True)
+    (o3 * w).sum().backward(retain_graph=True)
+    first = [t.grad.clone() for t in ins3]
+    for t in ins3:
+        t.grad = None
+    (o3 * w).sum().backward()
+    for a_, b_ in zip(first, ins3):
+        assert torch.equal(a_, b_.grad)  # bitwise: no atomics anywhere
+
+
+def test_fused_only_er_needs_grad_and_no_grad_paths():
+    n, H, Fd = 400, 2, 8
+    src, dst = hubby_graph(n, 30 * n, seed=3)
+    g = mk(n, n, src, dst)
+    feat, el = torch.randn(n, H, Fd, device=DEV), torch.randn(n, H, 1, device=DEV)
+    er = torch.randn(n, H, 1, device=DEV, requires_grad=True)
+    o = ops.gat_fused(g, feat, el, er, 0.2, 0.0, True)
+    o.sum().backward()
+    er2 = er.detach().clone().requires_grad_(True)
+    unfused(g, feat, el, er2, 0.2).sum().backward()
+    assert float((er.grad - er2.grad).abs().max()) < RTOL * max(float(er2.grad.abs().max()), 1e-3)
+    with torch.no_grad():
+        assert torch.equal(ops.gat_fused(g, feat, el, er, 0.2, 0.0, True), o.detach())
+
+
+@pytest.mark.parametrize("p", [0.3, 0.6])
+def test_fused_attention_dropout_is_consistent(p):
+    """attn_drop inside the kernels: reproducible for a seed, a fresh mask per call, the forward and both backward walks
+    regenerate the SAME mask (adjointness of the linear map feat -> out, and sum_v d_er = sum_u d_el), keep rate 1 - p,
+    evaluation mode = no mask."""
+    n, H, Fd = 1200, 4, 16
+    src, dst = hubby_graph(n, 40 * n, seed=17)
+    g = mk(n, n, src, dst)
+    torch.manual_seed(5)
+    feat = torch.randn(n, H, Fd, device=DEV)
+    el, er = torch.randn(n, H, 1, device=DEV), torch.randn(n, H, 1, device=DEV)
+    full = ops.gat_fused(g, feat, el, er, 0.2, 0.0, True)
+    assert torch.equal(ops.gat_fused(g, feat, el, er, 0.2, p, False), full)        # evaluation: identity
+    torch.manual_seed(123)
+    ops.GATFused._calls = 0
+    d1 = ops.gat_fused(g, feat, el, er, 0.2, p, True)
+    d2 = ops.gat_fused(g, feat, el, er, 0.2, p, True)
+    torch.manual_seed(123)
+    ops.GATFused._calls = 0
+    d1b = ops.gat_fused(g, feat, el, er, 0.2, p, True)
+    assert torch.equal(d1, d1b) and not torch.equal(d1, d2)
+    # E[dropout(a)] = a: with feat = 1 the output is sum_e keep/(1-p) a, mean 1 over many rows
+    ones = torch.ones(n, H, Fd, device=DEV)
+    frac = ops.gat_fused(g, ones, el, er, 0.2, p, True)[5:, :, 0]
+    assert abs(float(frac.mean()) - 1.0) < 0.05, float(frac.mean())
+    # same mask in forward and backward: <A x, y> == <x, A^T y> for the linear map x -> out at fixed (el, er, mask)
+    x = torch.randn(n, H, Fd, device=DEV, requires_grad=True)
+    y = torch.randn(n, H, Fd, device=DEV)
+    elg, erg = el.clone().requires_grad_(True), er.clone().requires_grad_(True)
+    torch.manual_seed(77)
+    ops.GATFused._calls = 0
+    out = ops.gat_fused(g, x, elg, erg, 0.2, p, True)
+    lhs = float((out.double() * y.double()).sum())
+    (out * y).sum().backward()
+    rhs = float((x.detach().double() * x.grad.double()).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
+    # every edge's d z lands once in d_el (out-CSR walk) and once in d_er (in-CSR walk)
+    s_el, s_er = elg.grad.double().sum(0).flatten(), erg.grad.double().sum(0).flatten()
+    assert float((s_el - s_er).abs().max()) < 1e-3 * max(float(elg.grad.abs().sum(0).max()), 1e-3), (s_el, s_er)
+
+
+def test_gatconv_uses_the_fused_block_and_matches_the_unfused_module(monkeypatch):
+    """dgl.nn.pytorch.GATConv (the module main_dgl_reddit_gat.py builds): fused and unfused paths give the same outputs
+    and parameter gradients; get_attention falls back to the unfused path."""
+    from mi355x_graph.nn import GATConv
+    n = 1500
+    src, dst = hubby_graph(n, 30 * n, seed=23)
+    loops = np.arange(n)
+    g = mk(n, n, np.concatenate([src, loops]), np.concatenate([dst, loops]))
+    torch.manual_seed(0)
+    conv = GATConv(24, 16, 8, 0.0, 0.0, 0.2, activation=F.elu).to(DEV)
+    x = torch.randn(n, 24, device=DEV)
+    calls = []
+    real = ops.gat_fused
+    monkeypatch.setattr(ops, "gat_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    y1 = conv(g, x)
+    assert calls, "GATConv did not take the fused path"
+    y1.square().sum().backward()
+    g1 = [p.grad.clone() for p in conv.parameters()]
+    conv.zero_grad()
+    monkeypatch.setenv("MGX_GAT_FUSED", "0")
+    y2 = conv(g, x)
+    y2.square().sum().backward()
+    assert float((y1 - y2).abs().max()) < RTOL * float(y2.abs().max())
+    for a_, b_ in zip(g1, [p.grad for p in conv.parameters()]):
+        assert float((a_ - b_).abs().max()) < 2e-4 * float(b_.abs().max()) + 1e-6
+    monkeypatch.setenv("MGX_GAT_FUSED", "1")
+    y3, att = conv(g, x, get_attention=True)
+    assert att.shape == (g.number_of_edges(), 8, 1) and float((y3 - y1).abs().max()) < RTOL * float(y1.abs().max())
+
+
+def test_fused_rejects_mismatched_rows():
+    n = 100
+    src, dst = random_graph(n, n, 1000, seed=1)
+    g = mk(n, n, src, dst)
+    feat = torch.randn(n, 2, 8, device=DEV)
+    with pytest.raises(mg.DGLError):
+        ops.gat_fused(g, feat, torch.randn(n - 1, 2, 1, device=DEV), torch.randn(n, 2, 1, device=DEV))
+    assert not ops.gat_fused_supported(g, torch.randn(n, 1, 41, device=DEV))   # ragged width: the unfused path
