@@ -46,6 +46,8 @@ struct SddmmArgs {
   float* out;
   int64_t l_len, r_len, out_len, reduce_size;
   int op, lhs_target, rhs_target;
+  int coo_chunk;   // COO walk: edges per chunk (<= 64) ...
+  int coo_chunks;  // ... and chunks per wave, chosen on the host so that small edge lists still fill the chip
 };
 
 __device__ __forceinline__ int64_t pick_target(int t, int64_t u, int64_t e, int64_t v) {
@@ -65,7 +67,8 @@ __device__ __forceinline__ V sddmm_op(int op, V l, V r) {
 }
 
 constexpr int kUn = 4;          // edges in flight per lane group
-constexpr int kCooChunks = 8;   // COO: 64-edge chunks per wave
+constexpr int kCooChunks = 8;   // COO: at most this many 64-edge chunks per wave (large edge lists)
+constexpr int kCooTargetWaves = 4096;  // small edge lists: shrink the per-wave share until about this many waves exist
 constexpr int kCsrItems = 16;   // CSR: work items per workgroup
 
 // element-wise body: kUn edges (u, v, e), e < 0 = idle.  DIRECT: operands used as-is (VEC-wide).
@@ -149,23 +152,25 @@ __global__ __launch_bounds__(kBlock) void sddmm_coo_kernel(const SddmmArgs<Idx> 
   const int sub = lane / G, l = lane % G;
   const int kc = (blockIdx.y * G + l) * VEC;
   const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
-  const int64_t e0 = wave_id * (kWave * kCooChunks);
+  const int chunk = a.coo_chunk, nchunks = a.coo_chunks;
+  const int64_t e0 = wave_id * ((int64_t)chunk * nchunks);
   if (e0 >= a.nnz) return;
   const bool need_u = a.lhs_target == MGX_TARGET_U || a.rhs_target == MGX_TARGET_U;
   const bool need_v = a.lhs_target == MGX_TARGET_V || a.rhs_target == MGX_TARGET_V;
   auto load_ids = [&](int64_t base, Idx& mu, Idx& mv) {
     const int64_t q = base + lane;
-    mu = (need_u && q < a.nnz) ? __builtin_nontemporal_load(&a.src[q]) : (Idx)0;  // id streams: read once
-    mv = (need_v && q < a.nnz) ? __builtin_nontemporal_load(&a.dst[q]) : (Idx)0;
+    const bool in = lane < chunk && q < a.nnz;
+    mu = (need_u && in) ? __builtin_nontemporal_load(&a.src[q]) : (Idx)0;  // id streams: read once
+    mv = (need_v && in) ? __builtin_nontemporal_load(&a.dst[q]) : (Idx)0;
   };
   Idx mu, mv;
   load_ids(e0, mu, mv);
-  for (int c = 0; c < kCooChunks; ++c) {
-    const int64_t base = e0 + (int64_t)c * kWave;
+  for (int c = 0; c < nchunks; ++c) {
+    const int64_t base = e0 + (int64_t)c * chunk;
     if (base >= a.nnz) break;  // wave-uniform
     Idx nu = 0, nv = 0;
-    if (c + 1 < kCooChunks) load_ids(base + kWave, nu, nv);
-    const int cnt = (int)((a.nnz - base) < kWave ? (a.nnz - base) : kWave);
+    if (c + 1 < nchunks) load_ids(base + chunk, nu, nv);
+    const int cnt = (int)((a.nnz - base) < chunk ? (a.nnz - base) : chunk);
     for (int k = 0; k < cnt; k += NB * kUn) {  // wave-uniform trip count
       int64_t u[kUn], v[kUn], e[kUn];
 #pragma unroll
@@ -382,9 +387,18 @@ static void launch_one(const SddmmArgs<Idx>& a, hipStream_t s) {
   if (CSR) {
     hipLaunchKernelGGL((sddmm_csr_kernel<Idx, VEC, G, DIRECT, DOT>), dim3((unsigned)a.nblocks, gy), dim3(kBlock), 0, s, a);
   } else {
-    const int64_t per_block = (int64_t)kWavesPerBlock * kWave * kCooChunks;
+    // a wave's share of the edge list: 512 edges on big graphs; on small ones (a batch of molecules: 14 k edges at D = 256
+    // ran on 27 waves, each a serial chain of 128 dependent gathers = 262 us) halved until ~kCooTargetWaves waves exist,
+    // but never below one fully unrolled step of the lane layout
+    SddmmArgs<Idx> b = a;
+    constexpr int kMinShare = (kWave / G) * kUn;
+    int64_t share = (int64_t)kWave * kCooChunks;
+    while (share > kMinShare && (a.nnz + share - 1) / share < kCooTargetWaves) share >>= 1;
+    b.coo_chunk = share < kWave ? (int)share : kWave;
+    b.coo_chunks = share < kWave ? 1 : (int)(share / kWave);
+    const int64_t per_block = (int64_t)kWavesPerBlock * share;
     const int64_t nb = (a.nnz + per_block - 1) / per_block;
-    hipLaunchKernelGGL((sddmm_coo_kernel<Idx, VEC, G, DIRECT, DOT>), dim3((unsigned)nb, gy), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((sddmm_coo_kernel<Idx, VEC, G, DIRECT, DOT>), dim3((unsigned)nb, gy), dim3(kBlock), 0, s, b);
   }
 }
 
@@ -501,7 +515,7 @@ extern "C" int32_t mgx_sddmm_coo(int64_t num_src, int64_t num_dst, int64_t nnz, 
   MGX_CHECK_ARG(nnz == 0 || (src && dst), "mgx_sddmm_coo: src/dst is NULL");
   int32_t st = check_common(op, lhs, rhs, lhs_target, rhs_target, l_len, r_len, out_len, out, nnz);
   if (st != MGX_OK) return st;
-  MGX_CHECK_ARG(nnz / (kWavesPerBlock * kWave * kCooChunks) < (int64_t(1) << 31) - 2, "mgx_sddmm_coo: nnz too large");
+  MGX_CHECK_ARG(nnz / (kWavesPerBlock * 4) < (int64_t(1) << 31) - 2, "mgx_sddmm_coo: nnz too large");
   if (idx_bits == 32)
     return run_coo<int32_t>(nnz, src, dst, op, lhs, rhs, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size,
                             l_off, r_off, out, (hipStream_t)stream);

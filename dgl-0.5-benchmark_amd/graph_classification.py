@@ -33,10 +33,14 @@ class CategoricalEncoder(nn.Module):
             nn.init.xavier_uniform_(t.weight.data)
 
     def forward(self, x):
-        out = 0
-        for i, t in enumerate(self.tables):
-            out = out + t(x[:, i])
-        return out
+        # sum_i table_i[x[:, i]] as ONE product of the concatenated one-hot codes with the stacked tables: the same sum,
+        # one GEMM each way instead of num_columns lookups + adds -- and safe to capture in a HIP graph: the sort-based
+        # backward of torch.embedding reads a segment count back to the host (thrust::unique_by_key_copy), which under
+        # capture bakes whatever that memory held into the following launches (the replay then faulted inside
+        # rocprim::partition_kernel, experiments/dbg_molhiv_graph2.py).
+        card = self.tables[0].num_embeddings
+        codes = F.one_hot(x, card).to(self.tables[0].weight.dtype).flatten(1)       # [rows, columns * cardinality]
+        return codes @ torch.cat([t.weight for t in self.tables], dim=0)
 
 
 class GCNConv(nn.Module):
@@ -109,6 +113,209 @@ class GIN(nn.Module):
         return self.graph_pred_fc(self.readout(g, x))
 
 
+class MaskedBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d whose training-mode statistics span only the rows flagged in `mask` ([N, 1] bool, `count` = their
+    number as a 0-dim device tensor): batches padded to a bucket size keep the statistics, outputs, gradients and running
+    estimates of the unpadded batch.  Same parameters / buffers / state_dict as nn.BatchNorm1d; without a mask it IS it."""
+
+    _mask = None
+    _count = None
+
+    def set_valid(self, mask, count):
+        self._mask, self._count = mask, count
+
+    def forward(self, x):
+        if self._mask is None or not self.training:
+            return super(MaskedBatchNorm1d, self).forward(x)
+        m, n = self._mask, self._count  # m: [N, 1] bool; masked rows may hold anything (where, not multiply: inf * 0 = nan)
+        zero = x.new_zeros(())
+        mean = torch.where(m, x, zero).sum(0) / n
+        xc = x - mean
+        var = torch.where(m, xc * xc, zero).sum(0) / n
+        y = xc * torch.rsqrt(var + self.eps)
+        if self.affine:
+            y = y * self.weight + self.bias
+        # masked (ghost) rows restart from zero after every normalisation.  They are scaled by the REAL rows' statistics, so
+        # a near-constant real column (variance ~ 0) multiplies a ghost value by up to 1/sqrt(eps) = 316 per layer; left
+        # alone that overflowed after a few layers (GIN, 5 layers x 2 BatchNorms) and 0 * inf in the next weight-gradient
+        # GEMM made every parameter NaN, although ghost rows carry a zero output gradient.
+        y = torch.where(m, y, zero)
+        if self.track_running_stats:
+            with torch.no_grad():
+                self.num_batches_tracked += 1
+                mom = self.momentum if self.momentum is not None else 0.1
+                self.running_mean.mul_(1 - mom).add_(mean.detach() * mom)
+                self.running_var.mul_(1 - mom).add_(var.detach() * (n / (n - 1).clamp(min=1.0)) * mom)
+        return y
+
+
+def convert_masked_batchnorm(module):
+    """Every nn.BatchNorm1d under `module` -> MaskedBatchNorm1d with the same state."""
+    out = module
+    if isinstance(module, nn.BatchNorm1d) and not isinstance(module, MaskedBatchNorm1d):
+        out = MaskedBatchNorm1d(module.num_features, module.eps, module.momentum, module.affine, module.track_running_stats)
+        out.load_state_dict(module.state_dict())
+        out.to(module.weight.device if module.affine else "cpu")
+        out.train(module.training)
+    for name, child in module.named_children():
+        out.add_module(name, convert_masked_batchnorm(child))
+    return out
+
+
+class GraphedBatchTrainer(object):
+    """The batched small-graph loop (main_dgl_molhiv_gcn.py:95-115) with the launch latency taken out: a training step on
+    256 molecules is ~300 kernels of a few microseconds each, and eager mode spends ~11 ms of host time launching ~1.5 ms
+    of device work.  Every batch -- the last, smaller one of an epoch too -- is padded to ONE static shape (ghost nodes
+    at the end, ghost edges spread round-robin over the ghost nodes so that no ghost row becomes a hub, empty ghost
+    graphs up to the batch size, one extra ghost "graph" holding the ghost
+    nodes in the readout), and the whole step (device CSR build, forward, masked loss,
+    backward, Adam) is captured once in a HIP graph and replayed.  Ghost rows never reach a real graph's output, the
+    loss or a parameter gradient (their output gradient is zero); BatchNorm statistics are masked to the real rows
+    (MaskedBatchNorm1d); the loss is the mean over the real graphs.  A batch larger than the static shape (4.5 sigma above
+    the mean batch: ~1 in 300,000) is trained as two half batches.
+    One captured graph, no eager steps in between: replaying an older capture after a later, larger one faulted on
+    ROCm 7.2 in this loop (experiments/dbg_molhiv_graph.py), so there is a single static shape rather than buckets."""
+
+    def __init__(self, model, optimizer, loss_fn, device, batch_size, n_pad, e_pad):
+        if not isinstance(loss_fn, nn.BCEWithLogitsLoss) or loss_fn.reduction != "mean":
+            raise ValueError("GraphedBatchTrainer masks a mean-reduced BCEWithLogitsLoss (main_dgl_molhiv_gcn.py:160)")
+        self.model, self.opt, self.device = model, optimizer, device
+        self.B, self.n_pad, self.e_pad = batch_size, int(n_pad), int(e_pad)
+        self.graph = None
+        self.stats = {"replayed": 0, "split": 0}
+        self.bns = [m for m in model.modules() if isinstance(m, MaskedBatchNorm1d)]
+
+    @staticmethod
+    def static_shape(dataset, batch_size, sigmas=4.5, edge_slack=1.03):
+        """(n_pad, e_pad) covering a random batch of `batch_size` graphs with `sigmas` to spare."""
+        import math
+        nn_ = torch.tensor([g.number_of_nodes() for g, _ in (dataset[i] for i in range(len(dataset)))], dtype=torch.float64)
+        ne_ = torch.tensor([g.number_of_edges() for g, _ in (dataset[i] for i in range(len(dataset)))], dtype=torch.float64)
+        n = batch_size * float(nn_.mean()) + sigmas * math.sqrt(batch_size) * float(nn_.std())
+        e = batch_size * float(ne_.mean()) + sigmas * math.sqrt(batch_size) * float(ne_.std())
+        return (int(n) // 256 + 1) * 256, (int(e * edge_slack) // 256 + 1) * 256
+
+    def fits(self, bg):
+        return bg.number_of_nodes() + 2 <= self.n_pad and bg.number_of_edges() <= self.e_pad  # two ghost nodes at least
+
+    def _pad(self, bg, labels):
+        """Host tensors of the padded batch (ghost nodes / edges / graphs appended)."""
+        n, e, b = bg.number_of_nodes(), bg.number_of_edges(), int(labels.shape[0])
+        n_pad, e_pad, B = self.n_pad, self.e_pad, self.B
+        src, dst = bg.edges()
+        # ghost edges run round-robin over the ghost nodes (i -> i + 1): ghost rows keep the degree of ordinary nodes, so
+        # their values stay in the range of real rows under a sum aggregator (one ghost hub overflowed GIN's to inf)
+        gi = torch.arange(e_pad - e, dtype=torch.int32)
+        gsrc, gdst = n + gi % (n_pad - n), n + (gi + 1) % (n_pad - n)
+        atom, bond = bg.ndata["feat"], bg.edata["feat"]
+        return {
+            "src": torch.cat([src.to(torch.int32), gsrc]), "dst": torch.cat([dst.to(torch.int32), gdst]),
+            "atom": torch.cat([atom, atom.new_zeros((n_pad - n,) + tuple(atom.shape[1:]))]),
+            "bond": torch.cat([bond, bond.new_zeros((e_pad - e,) + tuple(bond.shape[1:]))]),
+            "bnn": torch.cat([bg.batch_num_nodes().to(torch.int64), torch.zeros(B - b, dtype=torch.int64),
+                              torch.tensor([n_pad - n], dtype=torch.int64)]),
+            "labels": torch.cat([labels.float().view(-1), torch.zeros(B - b)]),
+            "gmask": (torch.arange(B) < b).float(),
+            "gcount": torch.tensor(float(b)),
+            "mask": (torch.arange(n_pad) < n).unsqueeze(1),
+            "count": torch.tensor(float(n)),
+        }
+
+    def _forward_loss(self, buf):
+        from mi355x_graph.graph import DGLGraph, GraphIndex
+        g = DGLGraph(GraphIndex(self.n_pad, self.n_pad, coo=(buf["src"], buf["dst"])))
+        g._batch_num_nodes = buf["bnn"]
+        g._batch_num_edges = None
+        for view in (g._index.csc(), g._index.csr()):  # built on the device inside the step; small graphs run without a schedule
+            view._plan = None                            # (building one reads a maximum degree back: a host sync)
+        for bn in self.bns:
+            bn.set_valid(buf["mask"], buf["count"])
+        out = self.model(g, buf["atom"], buf["bond"])
+        per_graph = F.binary_cross_entropy_with_logits(out[:self.B].float().view(-1), buf["labels"], reduction="none")
+        return (per_graph * buf["gmask"]).sum() / buf["gcount"]
+
+    def _capture(self, pad):
+        self.buf = buf = {k: v.to(self.device) for k, v in pad.items()}
+        # warm-up steps outside the capture (allocator, GEMM heuristics, lazily created optimizer state); the training
+        # state they change -- parameters, BatchNorm buffers, Adam moments and step counts -- is put back afterwards, in
+        # place (the captured graph holds these tensors' addresses), so the capture does not alter the optimisation trajectory
+        params, buffers = list(self.model.parameters()), list(self.model.buffers())
+        snap_p = [t.detach().clone() for t in params]
+        snap_b = [t.detach().clone() for t in buffers]
+        snap_o = {id(p): {k: v.detach().clone() for k, v in self.opt.state[p].items() if torch.is_tensor(v)}
+                  for p in params if p in self.opt.state}
+        # Warm-up and capture run on ONE side stream.  Autograd remembers the stream a parameter's gradient accumulator
+        # first ran on; capturing on a different stream makes every accumulation a cross-stream fork / join inside the
+        # graph, and such a forked graph gave NaNs after a hipDeviceSynchronize between replays on ROCm 7.2 (GIN, 5
+        # layers; experiments/dbg_gin_nan2.py).  Same stream -> a linear graph.
+        side = self.side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.opt.zero_grad(set_to_none=True)
+                self._forward_loss(buf).backward()
+                self.opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for t, v in zip(params, snap_p):
+                t.copy_(v)
+            for t, v in zip(buffers, snap_b):
+                t.copy_(v)
+            for p_ in params:
+                for k, v in self.opt.state.get(p_, {}).items():
+                    if torch.is_tensor(v):
+                        old = snap_o.get(id(p_), {}).get(k)
+                        v.copy_(old) if old is not None else v.zero_()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph, stream=side):
+            self.loss = self._forward_loss(buf)
+            self.loss.backward()
+            self.opt.step()
+
+    def step(self, bg, labels):
+        """One training step on a collated (host) batch; returns the loss as a 0-dim device tensor."""
+        if not self.fits(bg) or labels.shape[0] > self.B:
+            from mi355x_graph.transform import batch as batch_graphs, unbatch
+            parts = unbatch(bg)
+            if len(parts) < 2:
+                raise ValueError("a single graph with %d nodes exceeds the static shape" % bg.number_of_nodes())
+            self.stats["split"] += 1
+            h = len(parts) // 2
+            self.step(batch_graphs(parts[:h]), labels[:h])
+            return self.step(batch_graphs(parts[h:]), labels[h:])
+        pad = self._pad(bg, labels)  # host work: overlaps with the previous replay, like the loader's collate
+        if self.graph is None:
+            self._capture(pad)
+            self.done = torch.cuda.Event()
+        else:
+            # The previous replay must have FINISHED before its static inputs are overwritten.  Stream order alone did not
+            # guarantee that here: with only the (blocking) host-to-device copies between replays the loop faulted on
+            # ROCm 7.2 (a kernel of the running graph read a half-rewritten batch_num_nodes), with a host-side wait it
+            # never did (experiments/dbg_molhiv_graph2.py).
+            self.done.synchronize()
+        for k, v in pad.items():
+            self.buf[k].copy_(v)
+        self.graph.replay()
+        self.done.record()
+        self.stats["replayed"] += 1
+        return self.loss
+
+
+def train_epoch_graphed(trainer, loader):
+    trainer.model.train()
+    loss = None
+    for i, (batched_graph, labels) in enumerate(loader):
+        loss = trainer.step(batched_graph, labels)
+        if os.environ.get("MGX_DEBUG_NAN") == "1" and not bool(torch.isfinite(loss)):
+            bad = [n for n, p_ in trainer.model.named_parameters() if not bool(torch.isfinite(p_).all())]
+            raise SystemExit("non-finite loss at step %d: n %d e %d b %d ghosts %d, non-finite parameters %s" % (
+                i, batched_graph.number_of_nodes(), batched_graph.number_of_edges(), labels.shape[0],
+                trainer.n_pad - batched_graph.number_of_nodes(), bad[:4]))
+    return loss.item()
+
+
 def train_epoch(model, device, loader, optimizer, loss_fn):
     model.train()
     loss = None
@@ -132,24 +339,49 @@ def main():
     p.add_argument("--num_graphs", type=int, default=32901)
     p.add_argument("--epochs", type=int, default=4)
     p.add_argument("--num_workers", type=int, default=0)
+    p.add_argument("--hipgraph", action="store_true",
+                   help="pad every batch to one static shape and replay one captured HIP graph (GraphedBatchTrainer)")
+    p.add_argument("--dropout", type=float, default=0.5)
     p.add_argument("--model", default="gcn", choices=["gcn", "gin"],
                    help="gcn: the reference's main_dgl_molhiv_gcn.py model; gin: BASELINE.json's wording of config 5")
     args = p.parse_args()
+    # batching is a handful of tiny CPU tensor ops per step: with torch's default of one thread per visible core (128 on
+    # the GPU box, 16 usable) every one of them fans out and an iteration's host work takes 17 ms instead of 0.1 ms
+    torch.set_num_threads(max(1, min(int(os.environ.get("MGX_HOST_THREADS", "4")), os.cpu_count() or 1)))
     from mi355x_graph.datasets import molhiv_like
     device = torch.device("cuda:%d" % args.device)
     data = molhiv_like(args.num_graphs)
     loader = GraphDataLoader(data, batch_size=args.batch_size, shuffle=True, num_workers=args.num_workers)
-    model = (GCN if args.model == "gcn" else GIN)(args.emb_dim, 1, args.num_layers, 0.5).to(device)
-    opt = torch.optim.Adam(model.parameters(), lr=0.001)
+    torch.manual_seed(0)
+    model = (GCN if args.model == "gcn" else GIN)(args.emb_dim, 1, args.num_layers, args.dropout).to(device)
     loss_fn = nn.BCEWithLogitsLoss()
+    trainer = None
+    if args.hipgraph:
+        model = convert_masked_batchnorm(model)
+        opt = torch.optim.Adam(model.parameters(), lr=0.001, capturable=True)
+        n_pad, e_pad = GraphedBatchTrainer.static_shape(data, args.batch_size)
+        trainer = GraphedBatchTrainer(model, opt, loss_fn, device, args.batch_size, n_pad, e_pad)
+        print("hipgraph: static batch shape %d nodes, %d edges, %d graphs" % (n_pad, e_pad, args.batch_size))
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=0.001)
     dur = []
     for epoch in range(1, args.epochs + 1):
         t0 = time.time()
-        loss = train_epoch(model, device, loader, opt, loss_fn)
-        torch.cuda.synchronize()
+        if trainer is not None:
+            loss = train_epoch_graphed(trainer, loader)
+            # the epoch's last replay has finished (loss.item() read its output; the event covers the Adam update).  NOT a
+            # device-wide synchronize: with torch.cuda.synchronize() between epochs the 5-layer GIN's replays turned NaN some
+            # 40 steps later on ROCm 7.2, without it (or with any extra per-step allocation) never -- unexplained, see
+            # experiments/dbg_gin_nan2.py (variants D / E); the GCN of the reference is unaffected either way.
+            trainer.done.synchronize()
+        else:
+            loss = train_epoch(model, device, loader, opt, loss_fn)
+            torch.cuda.synchronize()
         if epoch >= 2:
             dur.append(time.time() - t0)
         print("epoch %d loss %.4f time %.3f" % (epoch, loss, time.time() - t0))
+    if trainer is not None:
+        print("hipgraph: %d steps replayed, %d oversize batches split" % (trainer.stats["replayed"], trainer.stats["split"]))
     if dur:
         print("Training time/epoch {:.4f}".format(sum(dur) / len(dur)))
 

@@ -37,7 +37,9 @@ class GraphedStep(object):
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        # captured on the warm-up stream: autograd remembers the stream a parameter's gradient accumulator first ran on, and
+        # capturing elsewhere turns every accumulation into a cross-stream fork / join inside the graph
+        with torch.cuda.graph(self.graph, stream=side):
             self.loss = self.loss_fn()
             self.loss.backward()
             optimizer.step()

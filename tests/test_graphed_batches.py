@@ -1,0 +1,73 @@
+"""GPU suite: the batched small-graph loop captured in a HIP graph (graph_classification.GraphedBatchTrainer,
+main_dgl_molhiv_gcn.py:95-115) trains exactly like the eager loop: same per-step losses at dropout 0 (padding to the
+static shape, ghost nodes / edges / graphs, masked BatchNorm statistics and the masked loss change nothing), including
+the smaller last batch of the epoch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dgl-0.5-benchmark_amd")
+DEV = "cuda:0"
+
+
+def _setup(model_name, seed=0):
+    sys.path.insert(0, PKG)
+    import graph_classification as gc
+    from mi355x_graph.datasets import molhiv_like
+    from dgl.dataloading import GraphDataLoader
+    data = molhiv_like(700, seed=11)
+    loader = GraphDataLoader(data, batch_size=128, shuffle=False)   # 5 full batches + one of 60 graphs
+    torch.manual_seed(seed)
+    net = gc.GCN if model_name == "gcn" else gc.GIN
+    model = net(64, 1, 3, 0.0).to(DEV)
+    return gc, data, loader, model
+
+
+@pytest.mark.parametrize("model_name", ["gcn", "gin"])
+def test_graphed_loop_matches_eager_loop(model_name):
+    gc, data, loader, eager = _setup(model_name)
+    loss_fn = nn.BCEWithLogitsLoss()
+    opt = torch.optim.Adam(eager.parameters(), lr=1e-3)
+    eager.train()
+    ref = []
+    for bg, labels in loader:
+        g = bg.to(DEV).int().formats("coo")
+        opt.zero_grad()
+        out = eager(g, g.ndata["feat"], g.edata["feat"])
+        loss = loss_fn(out.float().view(-1), labels.to(DEV).float().view(-1))
+        loss.backward()
+        opt.step()
+        ref.append(float(loss.detach()))
+    gc2, data2, loader2, model = _setup(model_name)
+    model = gc2.convert_masked_batchnorm(model)
+    opt2 = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    n_pad, e_pad = gc2.GraphedBatchTrainer.static_shape(data2, 128)
+    tr = gc2.GraphedBatchTrainer(model, opt2, loss_fn, torch.device(DEV), 128, n_pad, e_pad)
+    model.train()
+    got = [float(tr.step(bg, labels)) for bg, labels in loader2]
+    assert tr.stats["replayed"] == len(ref) and tr.stats["split"] == 0
+    assert len(got) == 6
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert abs(a - b) < 2e-4 * max(abs(b), 1.0), (i, a, b)   # fp32: other summation orders in BatchNorm / readout / Adam
+    # the trained parameters agree too (6 Adam steps of lr 1e-3).  Adam's first steps move every weight by ~lr whatever the
+    # size of its gradient, so a weight whose gradient is rounding noise may differ by 2 lr per step; the bulk may not.
+    for (n1, p1), (n2, p2) in zip(eager.named_parameters(), model.named_parameters()):
+        assert n1 == n2
+        d = (p1.detach() - p2.detach()).abs()
+        assert float(d.max()) <= 2.5e-3 * 6 and float(d.mean()) < 5e-4, (n1, float(d.max()), float(d.mean()))
+
+
+def test_oversize_batch_is_split_not_dropped():
+    gc, data, loader, model = _setup("gcn")
+    model = gc.convert_masked_batchnorm(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+    tr = gc.GraphedBatchTrainer(model, opt, nn.BCEWithLogitsLoss(), torch.device(DEV), 128, 2304, 5120)  # too small for 128 graphs
+    model.train()
+    bg, labels = next(iter(loader))
+    assert not tr.fits(bg)
+    loss = tr.step(bg, labels)
+    assert tr.stats["split"] >= 1 and tr.stats["replayed"] >= 2 and bool(torch.isfinite(loss))
