@@ -22,6 +22,23 @@ __all__ = ["gspmm", "gsddmm", "edge_softmax", "gat_attention", "gat_fused", "seg
            "copy_e_sum", "u_add_v", "u_dot_v"]
 
 
+def _torch_ops():
+    """MGX_TORCH_OPS=1: the raw primitives go through torch.ops.mi355x_graph.* (torch.library registrations over the same
+    C ABI, mi355x_graph/torch_ops.py) instead of the direct ctypes wrappers."""
+    if os.environ.get("MGX_TORCH_OPS", "0") != "1":
+        return None
+    from . import torch_ops
+    return torch_ops
+
+
+def _raw_gspmm(csr, op, reduce_op, X, Y, want_arg=False):
+    t = _torch_ops()
+    if t is None or not (X if X is not None else Y).is_cuda:
+        return sparse.gspmm_raw(csr, op, reduce_op, X, Y, want_arg=want_arg)
+    out, au, ae = torch.ops.mi355x_graph.gspmm(*t.csr_args(csr), op, reduce_op, X, Y)
+    return out, (au if au.numel() else None), (ae if ae.numel() else None)
+
+
 def _gidx(g):
     if isinstance(g, DGLGraph):
         return g._index
@@ -58,7 +75,7 @@ class GSpMM(torch.autograd.Function):
     def forward(ctx, gidx, op, reduce_op, X, Y):
         csc = gidx.csc()
         want_arg = reduce_op in ("max", "min")
-        out, argX, argY = sparse.gspmm_raw(csc, op, reduce_op, X, Y, want_arg=want_arg)
+        out, argX, argY = _raw_gspmm(csc, op, reduce_op, X, Y, want_arg=want_arg)
         ctx.backward_cache = gidx, op, reduce_op
         ctx.x_shape = None if X is None else X.shape
         ctx.y_shape = None if Y is None else Y.shape
@@ -89,9 +106,9 @@ class GSpMM(torch.autograd.Function):
             if op != "copy_rhs" and ctx.needs_input_grad[3]:
                 rev = gidx.csr()  # rows = src: the reversed graph's in-CSR
                 if op == "mul":
-                    dX, _, _ = sparse.gspmm_raw(rev, "mul", "sum", dZs, Y)
+                    dX, _, _ = _raw_gspmm(rev, "mul", "sum", dZs, Y)
                 else:  # add, copy_lhs
-                    dX, _, _ = sparse.gspmm_raw(rev, "copy_lhs", "sum", dZs, None)
+                    dX, _, _ = _raw_gspmm(rev, "copy_lhs", "sum", dZs, None)
                 dX = _reduce_grad(dX, ctx.x_shape)
             if op != "copy_lhs" and ctx.needs_input_grad[4]:
                 if op == "mul":
@@ -197,7 +214,12 @@ class EdgeSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gidx, score, norm_by):
         view = gidx.csc() if norm_by == "dst" else gidx.csr()
-        out = sparse.edge_softmax_fwd_raw(view, score)
+        t = _torch_ops()
+        if t is not None and score.is_cuda:
+            with torch.no_grad():
+                out = torch.ops.mi355x_graph.edge_softmax_fwd(*t.csr_args(view), score.contiguous())
+        else:
+            out = sparse.edge_softmax_fwd_raw(view, score)
         ctx.backward_cache = view
         ctx.save_for_backward(out)
         return out

@@ -39,7 +39,7 @@ def _prod(shape):
 class CsrView(object):
     """An immutable CSR over torch tensors (in-CSR: rows = destination nodes)."""
 
-    __slots__ = ("num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan", "_sm_plan",
+    __slots__ = ("__weakref__", "num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan", "_sm_plan",
                  "_row_order", "dst_is_src_prefix")
 
     def __init__(self, num_rows, num_cols, indptr, indices, eids):

@@ -54,3 +54,12 @@ for _ in range(2000):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+
+# ---- the same raw call through the torch.library registration (torch.ops.mi355x_graph.gspmm)
+from mi355x_graph import torch_ops
+args = torch_ops.csr_args(g._index.csc())
+host, total = loop(lambda: torch.ops.mi355x_graph.gspmm(*args, "copy_lhs", "sum", x, None))
+print("%-28s host %6.1f us/call   end-to-end %6.1f us/call" % ("torch.ops gspmm copy_u/sum", host, total))
+os.environ["MGX_TORCH_OPS"] = "1"
+host, total = loop(lambda: ops.gspmm(g, "copy_lhs", "sum", x, None))
+print("%-28s host %6.1f us/call   end-to-end %6.1f us/call" % ("ops.gspmm via torch.ops", host, total))
