@@ -346,6 +346,8 @@ def main():
     # dominant one, D = hidden (4 of the 5 launches per epoch)
     D = cfg["hidden"]
     kernels = []
+    sparse_recs = [r for r in records if r.get("variant") == "row-sparse"]
+    records = [r for r in records if r.get("variant") != "row-sparse"]
     for width in sorted({r["out_len"] for r in records if r["op"] == "copy_lhs"}):
         sel = [r for r in records if r["op"] == "copy_lhs" and r["out_len"] == width]
         durs = [r["start"].elapsed_time(r["end"]) * 1e-3 for r in sel]
@@ -360,6 +362,18 @@ def main():
                         "no_reuse_gather_bytes_per_launch": int(algo - 4 * r0["n_cols"] * width + 4 * r0["nnz"] * width),
                         "avg_launch_ms": round(avg * 1e3, 4), "launches_timed": len(durs),
                         "launches_per_epoch": len(durs) // max(args.steps, 1), "rows": r0["n_rows"], "nnz": r0["nnz"]})
+
+    # backward aggregations of a GRADIENT go through the row-sparse kernel (zero rows skipped): listed apart, never mixed into
+    # the dense launches' average -- the compulsory-bytes formula assumes every source row is read
+    row_sparse = None
+    if sparse_recs:
+        durs = sorted(r["start"].elapsed_time(r["end"]) for r in sparse_recs)
+        per_epoch = len(durs) // max(args.steps, 1)
+        row_sparse = {"kernel": "g-SpMM copy_u/sum of a gradient, zero rows skipped (mgx_row_nonzero_bits + mgx_spmm_copy_u_masked)",
+                      "launches_per_epoch": per_epoch, "ms_fastest": round(durs[0], 4), "ms_slowest": round(durs[-1], 4),
+                      "ms_mean": round(sum(durs) / len(durs), 4),
+                      "note": "products trains on 8 % of the nodes: the last layer's gradient has 92 % zero rows (fast launches); "
+                              "earlier layers' gradients are dense (slow launches = the dense kernel + the row flagging pass)"}
 
     epoch = elapsed / args.steps
     agg_edges = full_graph.spmm_edges_per_epoch(cfg["num_layers"], num_edges)
@@ -400,6 +414,7 @@ def main():
     roofline = dict(head) if head else None
     if roofline is not None:
         roofline["kernels"] = kernels
+        roofline["row_sparse_backward"] = row_sparse
         if single and args.dataset == "products" and not args.no_controls:
             import kernel_controls as kc
             try:

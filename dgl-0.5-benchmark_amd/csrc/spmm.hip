@@ -34,6 +34,7 @@ struct SpmmFastArgs {
   const float* w;          // MODE_MUL_EDGE: [num_edges, H] weights addressed by edge id
   const float* src_scale;  // optional, per gathered row
   const float* dst_scale;  // optional, per output row
+  const uint32_t* src_bits; // optional (lean copy_lhs kernel): bit u set = gathered row u may be non-zero; clear rows are skipped
   float* out;
   // optional schedule (mgx_spmm_plan): work items instead of natural row order
   const int32_t* item_row;  // >= 0: row written directly; < 0: partial slot -(v+1)
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave_kernel(const SpmmFastArgs
 // RAGGED (VEC = 4, D % 4 != 0, e.g. the 41-class output layer of the reddit GAT): rows are still gathered 16 bytes per lane
 // (dword-aligned accesses); the lane that owns the last 1-3 columns loads the LAST FOUR floats of the row instead -- no
 // read past the row, its own columns are the tail components of that window -- and only the epilogue distinguishes it.
-template <int VEC, int G, int MODE, int WMODE, bool LANEMASK, bool RAGGED = false>
+template <int VEC, int G, int MODE, int WMODE, bool LANEMASK, bool RAGGED = false, bool MASKED = false>
 #ifndef MGX_RW32_WAVES
 #define MGX_RW32_WAVES 1
 #endif
@@ -354,11 +355,17 @@ __global__ __launch_bounds__(kBlock, MGX_RW32_WAVES) void spmm_rowwave32_kernel(
     }
   };
   // lane j's slice of the edge list: byte offset of the gathered row, edge id, per-edge scalar
-  auto load_ids = [&](int32_t base, int32_t end, uint32_t& goff, int32_t& eid, float& sc) {
+  // `cnt`: edges of this 64-edge chunk to gather.  MASKED (row-sparse gathered matrix, e.g. the gradient of a loss taken on
+  // 8 % of the nodes): load_ids only fetches the ids (`gid`, -1 past the end); the flag word of every source row is fetched
+  // by mask_fetch once the ids are there, and mask_compact drops the lanes whose row is all-zero and compacts the live
+  // offsets to lanes 0..cnt-1 (stable partition through ds_permute) -- three stages so that the NEXT item's flag gather can
+  // be issued behind the current item's row gathers and be consumed only after its epilogue.
+  auto load_ids = [&](int32_t base, int32_t end, uint32_t& goff, int32_t& eid, float& sc, int& cnt, int32_t& gidx) {
     const int32_t q = base + lane;
     goff = 0;
     eid = 0;
     sc = 1.f;
+    gidx = -1;
     if (q < end) {
       int32_t gid;
       if (MODE == MODE_COPY_RHS) {
@@ -372,7 +379,21 @@ __global__ __launch_bounds__(kBlock, MGX_RW32_WAVES) void spmm_rowwave32_kernel(
         if (WMODE == 1 && a.src_scale) sc *= a.src_scale[gid];
       }
       goff = (uint32_t)gid * rowbytes;
+      gidx = gid;
     }
+    cnt = (end - base) < kWave ? (end - base) : kWave;
+  };
+  auto mask_fetch = [&](int32_t gidx) -> uint32_t {
+    return gidx >= 0 ? a.src_bits[(uint32_t)gidx >> 5] : 0u;
+  };
+  auto mask_compact = [&](uint32_t word, int32_t gidx, uint32_t& goff, int& cnt) {
+    const bool live = gidx >= 0 && ((word >> ((uint32_t)gidx & 31u)) & 1u) != 0u;
+    const uint64_t b = __ballot(live);
+    const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+    const int nlive = __popcll(b);
+    const int dest = live ? below : nlive + (lane - below);  // a permutation of 0..63: live lanes first, order kept
+    goff = (uint32_t)__builtin_amdgcn_ds_permute(dest * 4, (int)goff);
+    cnt = nlive;
   };
 
   // gathers of one step (STEP edges starting at edge k of the current 64-edge chunk); lanes past the end of
@@ -418,7 +439,10 @@ __global__ __launch_bounds__(kBlock, MGX_RW32_WAVES) void spmm_rowwave32_kernel(
   uint32_t goff;
   int32_t eid;
   float sc;
-  load_ids(beg, end, goff, eid, sc);
+  int cnt0 = 0;
+  int32_t gidx = -1;
+  load_ids(beg, end, goff, eid, sc, cnt0, gidx);
+  if (MASKED) mask_compact(mask_fetch(gidx), gidx, goff, cnt0);
 
   for (;;) {
     const int rn = r + kWavesPerBlock;
@@ -427,14 +451,20 @@ __global__ __launch_bounds__(kBlock, MGX_RW32_WAVES) void spmm_rowwave32_kernel(
     int32_t nbeg = 0, nend = 0, neid = 0;
     uint32_t ngoff = 0;
     float nsc = 1.f;
+    int ncnt0 = 0;
+    int32_t ngidx = -1;
     if (has_next) {
       load_meta(item_base + rn, nrow, nbeg, nend);
-      load_ids(nbeg, nend, ngoff, neid, nsc);
+      load_ids(nbeg, nend, ngoff, neid, nsc, ncnt0, ngidx);
     }
     V acc = (V)(0.f);
     for (int32_t cbase = beg; cbase < end; cbase += kWave) {
-      if (cbase != beg) load_ids(cbase, end, goff, eid, sc);
-      const int cnt = (end - cbase) < kWave ? (end - cbase) : kWave;
+      int cnt = cnt0;
+      if (cbase != beg) {
+        load_ids(cbase, end, goff, eid, sc, cnt, gidx);
+        if (MASKED) mask_compact(mask_fetch(gidx), gidx, goff, cnt);
+      }
+      if (MASKED && cnt == 0) continue;  // every source row of this chunk is zero
       // Two value buffers in ping-pong: the gathers of step k+1 are issued before step k is summed, so
       // consecutive steps of a row overlap instead of paying one memory round trip each.
       V va[U], vb[U];
@@ -452,6 +482,9 @@ __global__ __launch_bounds__(kBlock, MGX_RW32_WAVES) void spmm_rowwave32_kernel(
         k += STEP;
       }
     }
+    // the next item's flag words: its ids arrived during the gathers above; this load travels under the epilogue below
+    uint32_t nword = 0;
+    if (MASKED && has_next) nword = mask_fetch(ngidx);
 #pragma unroll
     for (int off = G; off < kWave; off <<= 1) acc += vec_shfl_xor<VEC>(acc, off);
     if (factive && sub == 0) {
@@ -484,6 +517,8 @@ __global__ __launch_bounds__(kBlock, MGX_RW32_WAVES) void spmm_rowwave32_kernel(
     r = rn;
     row = nrow; beg = nbeg; end = nend;
     goff = ngoff; eid = neid; sc = nsc;
+    cnt0 = ncnt0;
+    if (MASKED) mask_compact(nword, ngidx, goff, cnt0);
   }
 }
 
@@ -609,6 +644,11 @@ static bool launch_rowwave32(const SpmmFastArgs<int32_t>& a, int64_t src_rows, d
   int wmode = 0;
   if (MODE == MODE_MUL_EDGE) wmode = a.H == 1 ? 1 : 2;
   else if (a.src_scale) wmode = 1;
+  if (MODE == MODE_COPY_LHS && a.src_bits && wmode == 0) {  // row-sparse gathered matrix: skip rows flagged all-zero
+    if (lanemask) hipLaunchKernelGGL((spmm_rowwave32_kernel<VEC, G, MODE, 0, true, false, true>), grid, dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((spmm_rowwave32_kernel<VEC, G, MODE, 0, false, false, true>), grid, dim3(kBlock), 0, s, a);
+    return true;
+  }
   if (MODE == MODE_MUL_EDGE && a.H > 1 && a.src_scale) return false;  // not needed by any caller
 #define MGX_RW32(W, LM) hipLaunchKernelGGL((spmm_rowwave32_kernel<VEC, G, MODE, W, LM>), grid, dim3(kBlock), 0, s, a)
   if (wmode == 0) { if (lanemask) MGX_RW32(0, true); else MGX_RW32(0, false); }
@@ -686,7 +726,7 @@ template <typename Idx>
 static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* partial_ws, int accumulate, int32_t op, int32_t reduce, const float* U, const float* E,
                          int64_t u_len, int64_t e_len, int64_t out_len, const int64_t* u_off,
                          const int64_t* e_off, const float* src_scale, const float* dst_scale, float* out,
-                         void* arg_u, void* arg_e, hipStream_t s) {
+                         void* arg_u, void* arg_e, hipStream_t s, const uint32_t* src_bits = nullptr) {
   const int64_t n_rows = csr->num_rows;
   if (n_rows == 0 || out_len == 0) return MGX_OK;
   const int64_t nblocks = round_up((n_rows + kRowsPerBlock - 1) / kRowsPerBlock, kXcds);
@@ -706,6 +746,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     SpmmFastArgs<Idx> a;
     a.indptr = (const Idx*)csr->indptr; a.indices = (const Idx*)csr->indices; a.eids = (const Idx*)csr->eids;
     a.w = nullptr; a.src_scale = src_scale; a.dst_scale = dst_scale; a.out = out;
+    a.src_bits = src_bits;
     a.n_rows = n_rows; a.nblocks = nblocks; a.D = (int)out_len; a.H = 1; a.F = (int)out_len;
     a.mean = reduce == MGX_REDUCE_MEAN;
     a.accum = accumulate;
@@ -760,7 +801,79 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
   return MGX_OK;
 }
 
+// bits[r / 32] bit (r % 32) = row r of x [n, D] has a non-zero element.  Lanes along the row (16-byte loads), 64 / G rows
+// per wave-instruction; a wave owns 64 consecutive rows = two output words.
+template <int G>
+__global__ __launch_bounds__(kBlock) void row_nonzero_bits_kernel(int64_t n, int D, const float* __restrict__ x, uint32_t* __restrict__ bits) {
+  constexpr int NB = kWave / G;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int sub = lane / G, l = lane % G;
+  const int64_t w = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int64_t r0 = w * kWave;
+  if (r0 >= n) return;
+  uint64_t word = 0;
+  for (int k = 0; k < kWave; k += NB) {
+    const int64_t r = r0 + k + sub;
+    bool nz = false;
+    if (r < n) {
+      for (int f = l * 4; f < D; f += G * 4) {
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(x + r * D + f));
+        nz = nz || v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
+      }
+    }
+    const uint64_t b = __ballot(nz);
+#pragma unroll
+    for (int g = 0; g < NB; ++g) {
+      const uint64_t gm = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (g * G);
+      if (b & gm) word |= 1ull << (k + g);
+    }
+  }
+  if (lane == 0) {
+    bits[2 * w] = (uint32_t)word;
+    if (r0 + 32 < n) bits[2 * w + 1] = (uint32_t)(word >> 32);
+  }
+}
+
 }  // namespace mgx
+
+extern "C" int32_t mgx_row_nonzero_bits(int64_t n, int64_t D, const float* x, uint32_t* bits, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(n >= 0 && D >= 4 && D % 4 == 0, "mgx_row_nonzero_bits: D must be a positive multiple of 4 (got %lld)", (long long)D);
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(x && bits && (uintptr_t)x % 16 == 0, "mgx_row_nonzero_bits: NULL or unaligned pointer");
+  const dim3 grid((unsigned)((n + (int64_t)kWave * kWavesPerBlock - 1) / ((int64_t)kWave * kWavesPerBlock))), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+  int G = 1;
+  while (G * 4 < D && G < kWave) G <<= 1;
+  switch (G) {
+    case 1: hipLaunchKernelGGL((row_nonzero_bits_kernel<1>), grid, block, 0, s, n, (int)D, x, bits); break;
+    case 2: hipLaunchKernelGGL((row_nonzero_bits_kernel<2>), grid, block, 0, s, n, (int)D, x, bits); break;
+    case 4: hipLaunchKernelGGL((row_nonzero_bits_kernel<4>), grid, block, 0, s, n, (int)D, x, bits); break;
+    case 8: hipLaunchKernelGGL((row_nonzero_bits_kernel<8>), grid, block, 0, s, n, (int)D, x, bits); break;
+    case 16: hipLaunchKernelGGL((row_nonzero_bits_kernel<16>), grid, block, 0, s, n, (int)D, x, bits); break;
+    case 32: hipLaunchKernelGGL((row_nonzero_bits_kernel<32>), grid, block, 0, s, n, (int)D, x, bits); break;
+    default: hipLaunchKernelGGL((row_nonzero_bits_kernel<64>), grid, block, 0, s, n, (int)D, x, bits); break;
+  }
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_spmm_copy_u_masked(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t reduce, const float* ufeat,
+                                          int64_t D, const uint32_t* src_bits, const float* dst_scale, float* out,
+                                          float* partial_ws, int32_t flags, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(csr != nullptr && src_bits != nullptr, "mgx_spmm_copy_u_masked: NULL pointer");
+  MGX_CHECK_ARG(reduce == MGX_REDUCE_SUM || reduce == MGX_REDUCE_MEAN, "mgx_spmm_copy_u_masked: SUM or MEAN only");
+  if (csr->idx_bits != 32 || D % 4 != 0 || csr->num_cols * D * 4 >= (int64_t(1) << 32) || (uintptr_t)ufeat % 16 || (uintptr_t)out % 16)
+    MGX_UNSUPPORTED("mgx_spmm_copy_u_masked: needs 32-bit indices, D %% 4 == 0, 16-byte aligned operands below 4 GiB");
+  MGX_CHECK_ARG(csr->num_rows == 0 || csr->indptr, "mgx_spmm_copy_u_masked: indptr is NULL");
+  MGX_CHECK_ARG(csr->nnz == 0 || (csr->indices && ufeat), "mgx_spmm_copy_u_masked: indices / ufeat is NULL");
+  MGX_CHECK_ARG(out != nullptr || csr->num_rows == 0 || D == 0, "mgx_spmm_copy_u_masked: out is NULL");
+  return spmm_impl<int32_t>(csr, plan, partial_ws, (flags & MGX_SPMM_ACCUMULATE) ? 1 : 0, MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0, D,
+                            nullptr, nullptr, nullptr, dst_scale, out, nullptr, nullptr, (hipStream_t)stream, src_bits);
+}
 
 extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t op, int32_t reduce,
                                 const float* ufeat, const float* efeat, int64_t u_len, int64_t e_len,

@@ -367,11 +367,11 @@ class DistCopyU(torch.autograd.Function):
         feat = tuple(dZ.shape[1:])
         back = torch.empty((plan.send_idx.shape[0],) + feat, dtype=dZ.dtype, device=dZ.device)
         if plan.n_halo:
-            g_halo, _, _ = sparse.gspmm_raw(plan.halo.csr(), "copy_lhs", "sum", dZ, None)
+            g_halo = sparse.gspmm_grad_raw(plan.halo.csr(), dZ)
         else:
             g_halo = torch.empty((0,) + feat, dtype=dZ.dtype, device=dZ.device)
         work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
-        gx, _, _ = sparse.gspmm_raw(plan.loc.csr(), "copy_lhs", "sum", dZ, None)
+        gx = sparse.gspmm_grad_raw(plan.loc.csr(), dZ)
         work.wait()
         plan.add_returned_rows(gx, back)
         return gx, None, None, None, None

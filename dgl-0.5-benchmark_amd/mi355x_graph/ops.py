@@ -107,8 +107,8 @@ class GSpMM(torch.autograd.Function):
                 rev = gidx.csr()  # rows = src: the reversed graph's in-CSR
                 if op == "mul":
                     dX, _, _ = _raw_gspmm(rev, "mul", "sum", dZs, Y)
-                else:  # add, copy_lhs
-                    dX, _, _ = _raw_gspmm(rev, "copy_lhs", "sum", dZs, None)
+                else:  # add, copy_lhs: aggregation of a gradient -- skips its all-zero rows (sparse.gspmm_grad_raw)
+                    dX = sparse.gspmm_grad_raw(rev, dZs) if _torch_ops() is None else _raw_gspmm(rev, "copy_lhs", "sum", dZs, None)[0]
                 dX = _reduce_grad(dX, ctx.x_shape)
             if op != "copy_lhs" and ctx.needs_input_grad[4]:
                 if op == "mul":

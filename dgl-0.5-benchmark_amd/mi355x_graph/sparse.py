@@ -270,6 +270,38 @@ class HipBackend(object):
                 PROFILE.append(rec)
         return out, arg_u, arg_e
 
+    def row_nonzero_bits(self, x2d):
+        """Bitmap of the rows of x2d [n, D] that hold a non-zero (uint32 words, n padded to 64 rows)."""
+        dev = self._check_dev(x2d)
+        n, D = x2d.shape
+        bits = torch.empty(2 * ((n + 63) // 64), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_row_nonzero_bits(n, D, _ptr(x2d), _ptr(bits), _stream(dev)))
+        return bits
+
+    def spmm_copy_u_masked(self, csr, reduce, U2d, bits, dst_scale=None, accumulate_into=None):
+        """copy_u / sum|mean that skips source rows whose bit is clear (exact when those rows are zero)."""
+        dev = self._check_dev(csr.indptr, U2d, bits, dst_scale, accumulate_into)
+        D = int(U2d.shape[1])
+        out = accumulate_into.view(csr.num_rows, D) if accumulate_into is not None else \
+            torch.empty((csr.num_rows, D), dtype=torch.float32, device=dev)
+        plan = csr.plan()
+        partial = torch.empty((plan.num_slots, D), dtype=torch.float32, device=dev) if plan is not None and plan.num_slots else None
+        with torch.cuda.device(dev):
+            rec = None
+            if PROFILE is not None:
+                rec = {"op": "copy_lhs", "reduce": reduce, "out_len": D, "n_rows": csr.num_rows, "n_cols": csr.num_cols,
+                       "nnz": csr.nnz, "variant": "row-sparse", "start": torch.cuda.Event(enable_timing=True),
+                       "end": torch.cuda.Event(enable_timing=True)}
+                rec["start"].record(torch.cuda.current_stream(dev))
+            _lib.check(_lib.lib().mgx_spmm_copy_u_masked(
+                ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,
+                _ptr(bits), _ptr(dst_scale), _ptr(out), _ptr(partial), 1 if accumulate_into is not None else 0, _stream(dev)))
+            if rec is not None:
+                rec["end"].record(torch.cuda.current_stream(dev))
+                PROFILE.append(rec)
+        return out
+
     def sddmm(self, graph_index, op, L, R, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size, l_off, r_off):
         """graph_index supplies either COO (edge-id order) or the in-CSR."""
         nnz = graph_index.num_edges()
@@ -613,6 +645,29 @@ def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=Fa
     if arg_e is not None:
         arg_e = arg_e.view(shape)
     return out, arg_u, arg_e
+
+
+# nnz below which a separate pass over the gradient to flag its zero rows cannot pay
+_SPARSE_GRAD_MIN_NNZ = int(os.environ.get("MGX_SPARSE_GRAD_MIN_NNZ", 2_000_000))
+
+
+def gspmm_grad_raw(csr, dZ, dst_scale=None, accumulate_into=None):
+    """copy_u / sum over `csr` of a GRADIENT matrix dZ [num_cols, ...]: the backward aggregation of copy_u (dX = A^T dZ).
+    Gradients of a loss taken on a subset of the nodes are zero in most rows at the last layer (ogbn-products: 92 %), so the
+    rows of dZ are flagged first (one streaming pass) and the aggregation skips the all-zero ones -- same sum, fewer gathers.
+    OFF by default (MGX_SPARSE_GRAD=1 enables it): measured on the products epoch the 92 %-zero launch drops only from
+    2.41 to 1.65 ms (2.66 M work items of ~4 live edges each are bound by the per-item chain meta -> ids -> flags -> rows ->
+    store, not by bytes) while the dense-gradient launch of the layer below pays 0.55 ms for the flagging pass and the flag
+    gathers: no net gain (23.4 vs 23.5 ms).  Exact either way; kept with its test as a measured variant."""
+    be = backend_for(dZ)
+    flat = dZ.contiguous().view(dZ.shape[0], -1)
+    if (os.environ.get("MGX_SPARSE_GRAD", "0") == "1" and be.name == "hip" and csr.nnz >= _SPARSE_GRAD_MIN_NNZ and csr.idx_bits == 32
+            and flat.shape[1] % 4 == 0 and flat.shape[1] >= 4 and dZ.dtype == torch.float32 and dZ.shape[0] == csr.num_cols
+            and csr.num_cols * flat.shape[1] * 4 < 2 ** 32 and flat.data_ptr() % 16 == 0):
+        bits = be.row_nonzero_bits(flat)
+        out = be.spmm_copy_u_masked(csr, "sum", flat, bits, dst_scale, accumulate_into)
+        return out.view((csr.num_rows,) + tuple(dZ.shape[1:]))
+    return gspmm_raw(csr, "copy_lhs", "sum", dZ, None, dst_scale=dst_scale, accumulate_into=accumulate_into)[0]
 
 
 def gsddmm_raw(gidx, op, L, R, lhs_target="u", rhs_target="v"):

@@ -146,6 +146,17 @@ int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NUL
                      float* partial_ws /* [plan->num_slots * out_len] or NULL */,
                      int32_t flags /* MGX_SPMM_ACCUMULATE: out += result (SUM/MEAN only) */, void* stream);
 
+/* Row-sparse gathered matrix (round 2).  The gradient of a loss taken on a subset of the nodes (ogbn-products trains on 8 %,
+ * main_dgl_product_sage.py:105-106) is zero in every other row, so the backward aggregation of the last layer gathers rows that
+ * are 92 % zeros.  mgx_row_nonzero_bits flags the non-zero rows of x [n, D] (bit r of a ceil(n / 32)-word bitmap, n padded to 64
+ * rows); mgx_spmm_copy_u_masked is mgx_spmm_csr(COPY_LHS, SUM | MEAN) that skips gathers of rows whose bit is clear -- the same
+ * sum, fewer terms (exact: the skipped terms are zeros).  32-bit indices, D % 4 == 0, operands below 4 GiB, else
+ * MGX_ERR_UNSUPPORTED (call mgx_spmm_csr).  plan / partial_ws / flags as for mgx_spmm_csr. */
+int32_t mgx_row_nonzero_bits(int64_t n, int64_t D, const float* x, uint32_t* bits /* [2 * ceil(n / 64)] */, void* stream);
+int32_t mgx_spmm_copy_u_masked(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int32_t reduce,
+                               const float* ufeat, int64_t D, const uint32_t* src_bits, const float* dst_scale /* may be NULL */,
+                               float* out, float* partial_ws, int32_t flags, void* stream);
+
 /* ------------------------------------------------------------------ g-SDDMM
  * Replaces _CAPI_DGLKernelSDDMM as reached by dgl.ops.gsddmm (kernel/dgl-new.py:39),
  * apply_edges(fn.u_add_v) inside GATConv (main_dgl_reddit_gat.py:10) and fn.u_dot_v

@@ -731,3 +731,45 @@ def test_batch_norm_large_mean_small_std(n, C):
     gscale = float(x2.grad.abs().max())
     assert float((x1.grad - x2.grad).abs().max()) < 2e-2 * gscale, (float((x1.grad - x2.grad).abs().max()), gscale)
     assert float((ours.weight.grad - ref.weight.grad).abs().max()) < 2e-3 * float(ref.weight.grad.abs().max()) + 1e-2
+
+
+@pytest.mark.parametrize("D,density", [(64, 0.08), (64, 1.0), (100, 0.3), (8, 0.0), (256, 0.5), (4, 0.02)])
+def test_row_sparse_gradient_aggregation(oracle, D, density, monkeypatch):
+    """mgx_row_nonzero_bits + mgx_spmm_copy_u_masked (the backward aggregation of copy_u when most gradient rows are zero,
+    main_dgl_product_sage.py:105-106 trains on 8 % of the nodes): bitmap bit-exact, result == the plain g-SpMM == oracle,
+    with hub rows (chunked path), every density incl. all-zero and dense, and through autograd."""
+    monkeypatch.setenv("MGX_SPARSE_GRAD_MIN_NNZ", "0")
+    monkeypatch.setenv("MGX_SPARSE_GRAD", "1")
+    n, nnz = 3000, 90000
+    src, dst = random_graph(n, n, nnz, seed=D)
+    src[:4000], dst[:2500] = 7, 11                       # a hub source and a hub destination
+    g = mk(n, n, src, dst)
+    rng = np.random.default_rng(D)
+    X = rng.standard_normal((n, D)).astype(np.float32)
+    keep = rng.random(n) < density
+    X[~keep] = 0.0
+    if density > 0:
+        X[5, 1] = 1e-30                                    # a row whose only non-zero is tiny still counts
+        keep[5] = True
+    x = T(X)
+    be = sparse.backend_for(x)
+    bits = be.row_nonzero_bits(x).cpu().numpy().view(np.uint32)
+    got = ((bits[np.arange(n) // 32] >> (np.arange(n) % 32)) & 1).astype(bool)
+    assert np.array_equal(got, (X != 0).any(1))
+    csr = g._index.csr()                                   # rows = sources: the backward aggregation walks this one
+    out = sparse.gspmm_grad_raw(csr, x)
+    plain, _, _ = sparse.gspmm_raw(csr, "copy_lhs", "sum", x, None)
+    rp, rx, re = oracle.coo_to_csr(n, src, dst)
+    ref = oracle.spmm(rp, rx, re, "copy_lhs", "sum", X, None)
+    scale = oracle.spmm(rp, rx, re, "copy_lhs", "sum", np.abs(X), None)
+    assert float(np.max(np.abs(out.cpu().numpy() - ref) - RTOL * scale)) <= 1e-12
+    assert float((out - plain).abs().max()) <= 1e-5 * max(float(plain.abs().max()), 1.0)
+    # through autograd: d/dx of sum over the destination rows selected by a mask (the training-split pattern)
+    h = T(rng.standard_normal((n, D)).astype(np.float32)).requires_grad_(True)
+    sel = torch.from_numpy(np.nonzero(keep)[0]).to(DEV)
+    w = torch.randn(sel.shape[0], D, device=DEV)
+    (ops.gspmm(g, "copy_lhs", "mean", h, None)[sel] * w).sum().backward()
+    h2 = h.detach().clone().requires_grad_(True)
+    monkeypatch.setenv("MGX_SPARSE_GRAD", "0")
+    (ops.gspmm(g, "copy_lhs", "mean", h2, None)[sel] * w).sum().backward()
+    assert float((h.grad - h2.grad).abs().max()) <= 1e-5 * max(float(h2.grad.abs().max()), 1e-6)
