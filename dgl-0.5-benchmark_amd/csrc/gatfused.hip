@@ -24,6 +24,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace mgx {
@@ -173,8 +175,14 @@ struct GatUnroll {
 };
 
 // G lanes cover one H*F row (16 bytes each); LPH = F / 4 lanes share a head.
-template <int G, int LPH, int MODE, bool DROP>
+// RAGGED (one head, F % 4 != 0, e.g. the 41-class output layer of main_dgl_reddit_gat.py): rows are still moved 16 bytes per
+// lane with dword-aligned accesses; the lane that owns the last 1-3 columns works on the row's LAST four floats instead --
+// nothing is read past a row -- with the components that belong to its neighbour zeroed in the row-constant operand (dot
+// products) and left out of the store (the same windows as spmm.hip / sddmm.hip use).
+template <int G, int LPH, int MODE, bool DROP, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
+  typedef v4f v4u __attribute__((aligned(4)));
+  typedef typename std::conditional<RAGGED, v4u, v4f>::type V4;
   constexpr int NB = kWave / G;
   constexpr int U = GatUnroll<G>::value;
   constexpr int STEP = NB * U;
@@ -186,7 +194,18 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
   const bool fact = f < D;
   const int head = fact ? l / LPH : 0;
   const uint32_t rowbytes = (uint32_t)D * 4u;
-  const uint32_t f4 = fact ? (uint32_t)f * 4u : 0u;  // idle feature lanes re-read the row start, never stored
+  const int nvalid = RAGGED ? (D - f < 4 ? D - f : 4) : 4;   // columns this lane owns (RAGGED: the last active lane < 4)
+  const bool tail = RAGGED && fact && nvalid < 4;
+  const int fw = tail ? D - 4 : f;                            // first column of this lane's 16-byte window
+  const uint32_t f4 = fact ? (uint32_t)fw * 4u : 0u;  // idle feature lanes re-read the row start, never stored
+  auto clip = [&](v4f v) -> v4f {  // the window components that belong to the previous lane count for nothing
+    if (tail) {
+      if (nvalid < 4) v.x = 0.f;
+      if (nvalid < 3) v.y = 0.f;
+      if (nvalid < 2) v.z = 0.f;
+    }
+    return v;
+  };
   const uint32_t hbytes = (uint32_t)H * (MODE == GAT_BWD_SRC ? 16u : 4u);  // per-node stride of the small per-head array
   const uint32_t h4 = (uint32_t)head * (MODE == GAT_BWD_SRC ? 16u : 4u);
   const char* __restrict__ gatb = reinterpret_cast<const char*>(a.gat);
@@ -220,8 +239,8 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
     if (MODE == GAT_BWD_DST) {
       v4f ov = (v4f)(0.f);
       if (fact) {
-        ra = *reinterpret_cast<const v4f*>(a.rowa + row * D + f);  // d out[v]
-        ov = *reinterpret_cast<const v4f*>(a.rowb + row * D + f);  // out[v]
+        ra = clip((v4f)*reinterpret_cast<const V4*>(a.rowa + row * D + fw));  // d out[v]
+        ov = (v4f)*reinterpret_cast<const V4*>(a.rowb + row * D + fw);        // out[v]
       }
       float t = ra.x * ov.x + ra.y * ov.y + ra.z * ov.z + ra.w * ov.w;  // idle lanes take part with zeros
 #pragma unroll
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
       if (fact && (l % LPH) == 0 && sub == 0) a.nstat_w[(row * H + head) * 4 + 3] = t;
     }
     if (MODE == GAT_BWD_SRC && fact) {
-      ra = *reinterpret_cast<const v4f*>(a.rowa + row * D + f);  // feat[u]
+      ra = clip((v4f)*reinterpret_cast<const V4*>(a.rowa + row * D + fw));  // feat[u]
       c_el = a.el[row * H + head];
     }
     v4f acc = (v4f)(0.f);
@@ -259,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
           const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)goff) + f4;
           const uint32_t so = (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)soff) + h4;
           ee[u] = DROP ? __builtin_amdgcn_ds_bpermute(bi, eid) : 0;
-          val[u] = *reinterpret_cast<const v4f*>(gatb + off);
+          val[u] = (v4f)*reinterpret_cast<const V4*>(gatb + off);
           if (MODE == GAT_BWD_SRC) sm[u] = *reinterpret_cast<const v4f*>(smallb + so);
           else sm[u].x = *reinterpret_cast<const float*>(smallb + so);
         }
@@ -310,7 +329,12 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
     if (fact && sub == 0) {
       if (MODE != GAT_BWD_DST) {
         float* op = irow >= 0 ? a.out + row * (int64_t)D + f : a.partial + (-(irow + 1)) * (int64_t)D + f;
-        *reinterpret_cast<v4f*>(op) = acc;
+        if (!tail) {
+          *reinterpret_cast<V4*>(op) = acc;
+        } else {  // own columns f .. f+nvalid-1 are components 4-nvalid .. 3 of the window
+          const float* av = reinterpret_cast<const float*>(&acc);
+          for (int j = 0; j < nvalid; ++j) op[j] = av[4 - nvalid + j];
+        }
       }
       if (MODE != GAT_FWD && (l % LPH) == 0) {
         float* op = irow >= 0 ? a.out_h + row * (int64_t)H + head : a.partial_h + (-(irow + 1)) * (int64_t)H + head;
@@ -328,6 +352,13 @@ static void gat_launch_drop(const GatArgs& a, bool drop, hipStream_t s) {
 }
 
 template <int G, int MODE>
+static void gat_launch_ragged(const GatArgs& a, bool drop, hipStream_t s) {  // one head: the whole lane group is the head
+  const dim3 grid((unsigned)a.nblocks), block(kBlock);
+  if (drop) hipLaunchKernelGGL((gat_fused_kernel<G, G, MODE, true, true>), grid, block, 0, s, a);
+  else hipLaunchKernelGGL((gat_fused_kernel<G, G, MODE, false, true>), grid, block, 0, s, a);
+}
+
+template <int G, int MODE>
 static bool gat_launch_lph(const GatArgs& a, int lph, bool drop, hipStream_t s) {
   switch (lph) {
 #define MGX_GAT_LPH(L) case L: if (L <= G) { gat_launch_drop<G, (L <= G ? L : G), MODE>(a, drop, s); return true; } return false;
@@ -341,6 +372,17 @@ template <int MODE>
 static bool gat_launch(const GatArgs& a, bool drop, hipStream_t s) {
   int G = 1;
   while (G * 4 < a.D) G <<= 1;
+  if (a.F % 4 != 0 || ((a.F / 4) & (a.F / 4 - 1)) != 0) {  // gat_check admitted it: H == 1, 4 < F <= 256 (whole lane group = the head)
+    switch (G) {
+      case 2: gat_launch_ragged<2, MODE>(a, drop, s); return true;
+      case 4: gat_launch_ragged<4, MODE>(a, drop, s); return true;
+      case 8: gat_launch_ragged<8, MODE>(a, drop, s); return true;
+      case 16: gat_launch_ragged<16, MODE>(a, drop, s); return true;
+      case 32: gat_launch_ragged<32, MODE>(a, drop, s); return true;
+      case 64: gat_launch_ragged<64, MODE>(a, drop, s); return true;
+      default: return false;
+    }
+  }
   const int lph = a.F / 4;
   switch (G) {
     case 1: return gat_launch_lph<1, MODE>(a, lph, drop, s);
@@ -367,8 +409,10 @@ static int32_t gat_check(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t 
   MGX_CHECK_ARG(csr != nullptr, "%s: csr is NULL", who);
   if (csr->idx_bits != 32) MGX_UNSUPPORTED("%s: 32-bit graph indices only (got %d)", who, csr->idx_bits);
   MGX_CHECK_ARG(H >= 1 && F >= 1, "%s: H and F must be positive", who);
-  if (F % 4 != 0 || ((F / 4) & (F / 4 - 1)) != 0 || H * F > 256)
-    MGX_UNSUPPORTED("%s: needs F in {4, 8, 16, ..., 256} and H*F <= 256 (got H = %lld, F = %lld)", who, (long long)H, (long long)F);
+  const bool ragged_ok = H == 1 && F > 4 && F <= 256;  // one head of any width: the ragged-window kernels
+  if (!ragged_ok && (F % 4 != 0 || ((F / 4) & (F / 4 - 1)) != 0 || H * F > 256))
+    MGX_UNSUPPORTED("%s: needs F in {4, 8, 16, ..., 256} and H*F <= 256, or one head with 4 < F <= 256 (got H = %lld, F = %lld)", who,
+                    (long long)H, (long long)F);
   if (gathered_rows * H * F * 4 >= (int64_t(1) << 32) || gathered_rows * H * 16 >= (int64_t(1) << 32) || csr->nnz >= (int64_t(1) << 31))
     MGX_UNSUPPORTED("%s: operands beyond 32-bit byte offsets", who);
   MGX_CHECK_ARG(p >= 0.f && p < 1.f, "%s: dropout probability %g outside [0, 1)", who, (double)p);

@@ -359,8 +359,11 @@ class HipBackend(object):
 
     @staticmethod
     def gat_fused_supported(csr, H, F):
-        """Shapes mgx_gat_fused_* takes: F a power of two >= 4, H*F <= 256, 32-bit indices and byte offsets."""
-        return (F >= 4 and F % 4 == 0 and ((F // 4) & (F // 4 - 1)) == 0 and H * F <= 256 and csr.idx_bits == 32
+        """Shapes mgx_gat_fused_* takes: F a power of two >= 4 with H*F <= 256, or ONE head of any width 4 < F <= 256;
+        32-bit indices and byte offsets."""
+        regular = F >= 4 and F % 4 == 0 and ((F // 4) & (F // 4 - 1)) == 0 and H * F <= 256
+        ragged = H == 1 and 4 < F <= 256
+        return ((regular or ragged) and csr.idx_bits == 32
                 and max(csr.num_cols, csr.num_rows) * H * max(F * 4, 16) < 2 ** 32 and csr.nnz < 2 ** 31)
 
     @staticmethod

@@ -217,8 +217,9 @@ int32_t mgx_gat_attention_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* m
  *        transpose (rows = source nodes) whose eids map to the in-CSR's edge ids (NULL eids = positions) so that both walks
  *        regenerate the same dropout bit for an edge; nstat[.,.,3] receives t = <out, d_out> per head.
  * feat [num_cols, H*F], el [num_cols, H], er [num_rows, H], out / d_out [num_rows, H*F], nstat [num_rows, H, 4], 16-byte
- * aligned; F in {4, 8, ..., 256}, H*F <= 256, 32-bit indices (else MGX_ERR_UNSUPPORTED: callers fall back to
- * mgx_gat_attention_* + mgx_spmm_csr).  keep(e,h) = hash(seed, e*H + h) >= p * 2^32 (counter based; drop_p = 0: no mask).
+ * aligned; F in {4, 8, ..., 256} with H*F <= 256, or ONE head of any width 4 < F <= 256 (e.g. a 41-class output layer: rows moved
+ * in dword-aligned 16-byte windows); 32-bit indices (else MGX_ERR_UNSUPPORTED: callers fall back to mgx_gat_attention_* +
+ * mgx_spmm_csr).  keep(e,h) = hash(seed, e*H + h) >= p * 2^32 (counter based; drop_p = 0: no mask).
  * workspace: max over the plans passed of mgx_gat_fused_workspace(plan, H, F) bytes (NULL when no plan splits rows).
  * Deterministic: no atomics, hub partial sums combined in slot order. */
 int64_t mgx_gat_fused_workspace(const mgx_spmm_plan* plan /* may be NULL */, int64_t H, int64_t F);

@@ -42,7 +42,7 @@ def unfused(g, feat, el, er, slope):
 
 
 @pytest.mark.parametrize("n,H,Fd", [(900, 1, 16), (900, 8, 16), (700, 4, 8), (500, 2, 64), (300, 1, 4), (600, 3, 16), (400, 1, 256),
-                                    (400, 16, 4), (350, 2, 128)])
+                                    (400, 16, 4), (350, 2, 128), (800, 1, 41), (500, 1, 7), (400, 1, 100), (300, 1, 5), (300, 1, 253)])
 def test_fused_forward_matches_oracle_composition(oracle, n, H, Fd):
     nnz = 40 * n
     src, dst = hubby_graph(n, nnz, seed=H * 100 + Fd)
@@ -67,7 +67,8 @@ def test_fused_forward_matches_oracle_composition(oracle, n, H, Fd):
     assert np.all(got[:5] == 0.0)  # nodes without in-edges aggregate to exactly 0
 
 
-@pytest.mark.parametrize("n,H,Fd", [(900, 8, 16), (800, 1, 16), (500, 2, 64), (600, 3, 16), (300, 4, 4)])
+@pytest.mark.parametrize("n,H,Fd", [(900, 8, 16), (800, 1, 16), (500, 2, 64), (600, 3, 16), (300, 4, 4), (800, 1, 41), (500, 1, 7),
+                                    (400, 1, 102)])
 def test_fused_gradients_match_unfused_operators(n, H, Fd):
     nnz = 40 * n
     src, dst = hubby_graph(n, nnz, seed=H * 7 + Fd)
@@ -191,4 +192,6 @@ def test_fused_rejects_mismatched_rows():
     feat = torch.randn(n, 2, 8, device=DEV)
     with pytest.raises(mg.DGLError):
         ops.gat_fused(g, feat, torch.randn(n - 1, 2, 1, device=DEV), torch.randn(n, 2, 1, device=DEV))
-    assert not ops.gat_fused_supported(g, torch.randn(n, 1, 41, device=DEV))   # ragged width: the unfused path
+    assert ops.gat_fused_supported(g, torch.randn(n, 1, 41, device=DEV))       # one head of any width: ragged windows
+    assert not ops.gat_fused_supported(g, torch.randn(n, 2, 41, device=DEV))   # several ragged heads: the unfused path
+    assert not ops.gat_fused_supported(g, torch.randn(n, 1, 3, device=DEV))
