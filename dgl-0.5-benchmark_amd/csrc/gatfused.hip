@@ -7,9 +7,10 @@
 // `a` (E x H), its gradient and the logit gradient.  Here the attention weight of an edge is REBUILT in registers
 // wherever it is needed from four per-node numbers (er, row max m, 1 / row sum, t = <out, d out>):
 //
-//   forward   gat_stats_kernel          per destination row and head: m = max_e z, s = sum_e exp(z - m),
-//                                       z = leaky_relu(el[u] + er[v])            -> nstat[v,h] = (er, m, 1/s, .)
-//             gat_fused_kernel<FWD>     out[v,h,:] = sum_e keep(e,h)/(1-p) * exp(z - m) / s * feat[u,h,:]
+//   forward   gat_fused_kernel<FWD>     ONE walk of the in-CSR with an online softmax: every lane keeps a running maximum m and
+//                                       sum s of exp(z - m), z = leaky_relu(el[u] + er[v]), and rescales its accumulator when m
+//                                       grows; out[v,h,:] = sum_e keep(e,h)/(1-p) exp(z - m) feat[u,h,:] / s,
+//                                       nstat[v,h] = (er, m, 1/s, .) is written for the backward
 //   backward  gat_fused_kernel<BWD_DST> walks the in-CSR again (gathers feat[u]): d a = <feat[u,h,:], d out[v,h,:]>,
 //                                       d z = a (d a - t) leaky_relu'(.), d er[v,h] = sum_e d z; also writes t[v,h]
 //             gat_fused_kernel<BWD_SRC> walks the out-CSR (gathers d out[v] and nstat[v]): d feat[u,h,:] = sum_e a' d out[v,h,:]
@@ -66,88 +67,42 @@ struct GatArgs {
   float* partial_h;     // [slots, H] (stats: [slots, 2H])
 };
 
-// ---------------------------------------------------------------------------------------------- row statistics
-// lanes = (edge slot j, head h); every lane keeps an online (max, sum) pair, merged across slots at the end.
-template <int LH>
-__global__ __launch_bounds__(kBlock) void gat_stats_kernel(const GatArgs a) {
-  constexpr int EPI = kWave / LH;
+// ---------------------------------------------------------------------------------------------- hub rows of the forward
+// A hub row's chunks each leave (running max m_c, sum s_c) per head in partial_h [slot, 2H] and an accumulator relative to
+// m_c in partial [slot, D]; merged here in slot order: m = max m_c, s = sum s_c e^(m_c - m), out = sum acc_c e^(m_c - m) / s.
+__global__ __launch_bounds__(kBlock) void gat_online_fixup_kernel(const int32_t* hub_row, const int32_t* hub_slot_ptr, int64_t n_hubs,
+                                                                  int H, int F, const float* er, const float* partial,
+                                                                  const float* partial_h, float* out, float* nstat) {
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int j = lane / LH, h = lane % LH;
-  const bool hact = h < a.H;
-  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * a.rpb;
-  for (int r = wave; r < a.rpb; r += kWavesPerBlock) {
-    const int64_t item = item_base + r;
-    if (item >= a.n_items) break;
-    int64_t row, irow;
-    int32_t beg, end;
-    if (a.item_row) {
-      irow = a.item_row[item];
-      row = a.item_node[item];
-      beg = a.item_beg[item];
-      end = a.item_end[item];
-    } else {
-      irow = row = item;
-      beg = a.indptr[item];
-      end = a.indptr[item + 1];
-    }
-    const float er_v = hact ? a.er[row * a.H + h] : 0.f;
-    float m = -INFINITY, s = 0.f;
-    for (int32_t p = beg + j; p < end; p += EPI) {
-      if (hact) {
-        const float t = a.el[(int64_t)a.indices[p] * a.H + h] + er_v;
-        const float z = t > 0.f ? t : t * a.slope;
-        const float mn = fmaxf(m, z);
-        s = s * __expf(m - mn) + __expf(z - mn);  // m = -inf: exp(-inf) = 0
-        m = mn;
+  const int64_t hb = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  if (hb >= n_hubs) return;
+  const int64_t row = hub_row[hb];
+  const int s0 = hub_slot_ptr[hb], s1 = hub_slot_ptr[hb + 1];
+  const int D = H * F;
+  for (int k = lane; k < D; k += kWave) {
+    const int h = k / F;
+    float m = -INFINITY;
+    for (int s = s0; s < s1; ++s) m = fmaxf(m, partial_h[(int64_t)s * 2 * H + h]);
+    float sum = 0.f, acc = 0.f;
+    for (int s = s0; s < s1; ++s) {
+      const float mc = partial_h[(int64_t)s * 2 * H + h];
+      if (mc > -INFINITY) {
+        const float fct = __expf(mc - m);
+        sum += partial_h[(int64_t)s * 2 * H + H + h] * fct;
+        acc += partial[(int64_t)s * D + k] * fct;
       }
     }
-#pragma unroll
-    for (int off = LH; off < kWave; off <<= 1) {
-      const float mo = __shfl_xor(m, off, kWave), so = __shfl_xor(s, off, kWave);
-      const float mn = fmaxf(m, mo);
-      s = (m > -INFINITY ? s * __expf(m - mn) : 0.f) + (mo > -INFINITY ? so * __expf(mo - mn) : 0.f);
-      m = mn;
-    }
-    if (j == 0 && hact) {
-      if (irow >= 0) {
-        v4f st;
-        st.x = er_v;
-        st.y = m > -INFINITY ? m : 0.f;
-        st.z = s > 0.f ? 1.f / s : 0.f;  // rows without in-edges aggregate to 0
-        st.w = 0.f;
-        *reinterpret_cast<v4f*>(a.nstat_w + (row * a.H + h) * 4) = st;
-      } else {
-        const int64_t slot = -(irow + 1);
-        a.partial_h[slot * 2 * a.H + h] = m;
-        a.partial_h[slot * 2 * a.H + a.H + h] = s;
-      }
+    const float is = sum > 0.f ? 1.f / sum : 0.f;
+    out[row * D + k] = acc * is;
+    if (k % F == 0) {
+      v4f st;
+      st.x = er[row * H + h];
+      st.y = m > -INFINITY ? m : 0.f;
+      st.z = is;
+      st.w = 0.f;
+      *reinterpret_cast<v4f*>(nstat + (row * H + h) * 4) = st;
     }
   }
-}
-
-// per hub row and head: merge the chunk statistics in slot order
-__global__ __launch_bounds__(kBlock) void gat_stats_combine_kernel(const int32_t* hub_row, const int32_t* hub_slot_ptr, int64_t n_hubs,
-                                                                   int H, const float* er, const float* partial, float* nstat) {
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= n_hubs * H) return;
-  const int64_t hub = t / H;
-  const int h = (int)(t % H);
-  const int s0 = hub_slot_ptr[hub], s1 = hub_slot_ptr[hub + 1];
-  float m = -INFINITY;
-  for (int s = s0; s < s1; ++s) m = fmaxf(m, partial[(int64_t)s * 2 * H + h]);
-  float sum = 0.f;
-  for (int s = s0; s < s1; ++s) {
-    const float mc = partial[(int64_t)s * 2 * H + h];
-    if (mc > -INFINITY) sum += partial[(int64_t)s * 2 * H + H + h] * __expf(mc - m);
-  }
-  const int64_t row = hub_row[hub];
-  v4f st;
-  st.x = er[row * H + h];
-  st.y = m > -INFINITY ? m : 0.f;
-  st.z = sum > 0.f ? 1.f / sum : 0.f;
-  st.w = 0.f;
-  *reinterpret_cast<v4f*>(nstat + (row * H + h) * 4) = st;
 }
 
 // out[hub_row[h], k] = sum over the hub's slots, in slot order, of partial[slot, k]
@@ -230,12 +185,14 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
     // ---- row constants
     v4f ra = (v4f)(0.f);
     float c_er = 0.f, c_m = 0.f, c_is = 0.f, c_t = 0.f, c_el = 0.f;
-    if (MODE == GAT_FWD || MODE == GAT_BWD_DST) {
+    if (MODE == GAT_BWD_DST) {
       if (fact) {
         const v4f st = *reinterpret_cast<const v4f*>(a.nstat + (row * H + head) * 4);
         c_er = st.x; c_m = st.y; c_is = st.z;
       }
     }
+    if (MODE == GAT_FWD && fact) c_er = a.er[row * H + head];
+    float run_m = -INFINITY, run_s = 0.f;  // FWD: online softmax state of this lane's head (per lane group)
     if (MODE == GAT_BWD_DST) {
       v4f ov = (v4f)(0.f);
       if (fact) {
@@ -293,9 +250,12 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
           if (MODE == GAT_FWD) {
             const float t = sm[u].x + c_er;
             const float z = t > 0.f ? t : t * a.slope;
-            float w = __expf(z - c_m) * c_is * keep;
-            w = live ? w : 0.f;
-            acc += val[u] * w;
+            const float mn = live ? fmaxf(run_m, z) : run_m;
+            const float rescale = run_m > -INFINITY ? __expf(run_m - mn) : 0.f;   // 1 while the maximum stands
+            const float pe = live ? __expf(z - mn) : 0.f;
+            run_s = run_s * rescale + pe;
+            acc = acc * rescale + val[u] * (pe * keep);
+            run_m = mn;
           } else {
             const float t = MODE == GAT_BWD_DST ? sm[u].x + c_er : c_el + sm[u].x;
             const float mm = MODE == GAT_BWD_DST ? c_m : sm[u].y;
@@ -318,7 +278,34 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
       }
     }
     // ---- combine the lane groups, write the row (or the partial slot of a hub chunk)
-    if (MODE != GAT_BWD_DST) {
+    if (MODE == GAT_FWD) {
+#pragma unroll
+      for (int off = G; off < kWave; off <<= 1) {
+        const float mo = __shfl_xor(run_m, off, kWave), so = __shfl_xor(run_s, off, kWave);
+        const v4f ao = vec_shfl_xor<4>(acc, off);
+        const float mn = fmaxf(run_m, mo);
+        const float f1 = run_m > -INFINITY ? __expf(run_m - mn) : 0.f, f2 = mo > -INFINITY ? __expf(mo - mn) : 0.f;
+        run_s = run_s * f1 + so * f2;
+        acc = acc * f1 + ao * f2;
+        run_m = mn;
+      }
+      if (irow >= 0) {
+        const float is = run_s > 0.f ? 1.f / run_s : 0.f;  // rows without in-edges aggregate to 0
+        acc = acc * is;
+        if (fact && sub == 0 && (l % LPH) == 0) {
+          v4f st;
+          st.x = c_er;
+          st.y = run_m > -INFINITY ? run_m : 0.f;
+          st.z = is;
+          st.w = 0.f;
+          *reinterpret_cast<v4f*>(a.nstat_w + (row * H + head) * 4) = st;
+        }
+      } else if (fact && sub == 0 && (l % LPH) == 0) {  // hub chunk: statistics travel with the unnormalised partial row
+        const int64_t slot = -(irow + 1);
+        a.partial_h[slot * 2 * H + head] = run_m;
+        a.partial_h[slot * 2 * H + H + head] = run_s;
+      }
+    } else if (MODE != GAT_BWD_DST) {
 #pragma unroll
       for (int off = G; off < kWave; off <<= 1) acc += vec_shfl_xor<4>(acc, off);
     }
@@ -453,8 +440,7 @@ static void gat_fixup(const mgx_spmm_plan* plan, int L, const float* partial, fl
 
 extern "C" int64_t mgx_gat_fused_workspace(const mgx_spmm_plan* plan, int64_t H, int64_t F) {
   const int64_t slots = plan ? plan->num_slots : 0;
-  int64_t per = H * F + H;          // gather kernels: [slots, D] + [slots, H]
-  if (2 * H > per) per = 2 * H;     // stats kernel: [slots, 2H]
+  const int64_t per = H * F + 2 * H;  // [slots, D] partial rows + [slots, 2H] chunk statistics (forward) / [slots, H] (backward)
   return slots * per * (int64_t)sizeof(float);
 }
 
@@ -473,27 +459,17 @@ extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* pl
   hipStream_t s = (hipStream_t)stream;
   GatArgs a;
   gat_fill(a, csr, plan, H, F, negative_slope, drop_p, seed);
-  a.el = el; a.er = er; a.nstat_w = nstat; a.partial_h = (float*)workspace;
-  int LH = 1;
-  while (LH < H) LH <<= 1;
-  const dim3 grid((unsigned)a.nblocks), block(kBlock);
-  switch (LH) {
-#define MGX_GAT_ST(L) case L: hipLaunchKernelGGL((gat_stats_kernel<L>), grid, block, 0, s, a); break;
-    MGX_GAT_ST(1) MGX_GAT_ST(2) MGX_GAT_ST(4) MGX_GAT_ST(8) MGX_GAT_ST(16) MGX_GAT_ST(32)
-    default: hipLaunchKernelGGL((gat_stats_kernel<64>), grid, block, 0, s, a); break;
-#undef MGX_GAT_ST
-  }
-  MGX_CHECK_LAUNCH();
-  if (hubs) {
-    hipLaunchKernelGGL(gat_stats_combine_kernel, dim3((unsigned)((plan->num_hubs * H + kBlock - 1) / kBlock)), block, 0, s, plan->hub_row,
-                       plan->hub_slot_ptr, plan->num_hubs, (int)H, er, (const float*)workspace, nstat);
-    MGX_CHECK_LAUNCH();
-  }
-  a.gat = feat; a.nstat = nstat; a.out = out; a.partial = (float*)workspace; a.partial_h = nullptr;
+  a.el = el; a.er = er; a.nstat_w = nstat;
+  a.gat = feat; a.nstat = nstat; a.out = out;
+  float* ws = (float*)workspace;  // [slots, D] partial rows, then [slots, 2H] chunk statistics
+  a.partial = ws;
+  a.partial_h = hubs ? ws + plan->num_slots * (int64_t)a.D : nullptr;
   if (!gat_launch<GAT_FWD>(a, drop_p > 0.f, s)) MGX_UNSUPPORTED("mgx_gat_fused_fwd: unsupported head layout H = %lld, F = %lld", (long long)H, (long long)F);
   MGX_CHECK_LAUNCH();
   if (hubs) {
-    gat_fixup(plan, a.D, (const float*)workspace, out, s);
+    hipLaunchKernelGGL(gat_online_fixup_kernel, dim3((unsigned)((plan->num_hubs + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s,
+                       plan->hub_row, plan->hub_slot_ptr, plan->num_hubs, (int)H, (int)F, er, (const float*)a.partial,
+                       (const float*)a.partial_h, out, nstat);
     MGX_CHECK_LAUNCH();
   }
   return MGX_OK;
