@@ -27,7 +27,10 @@ RUNS = [  # name, launcher, arguments (reference script each one stands for)
     ("gat_reddit", "full_graph.py", ["--model", "gat", "--dataset", "reddit", "--heads", "1", "--num-layers", "3",
                                      "--num-hidden", "16", "--epochs", "20"]),                            # main_dgl_reddit_gat.py
     ("sage_products", "full_graph.py", ["--model", "sage", "--dataset", "products", "--epochs", "20"]),  # main_dgl_product_sage.py
+    ("gat8_reddit_small", "full_graph.py", ["--model", "gat", "--dataset", "reddit-small", "--heads", "8", "--num-layers", "2",
+                                            "--epochs", "20"]),                                          # BASELINE config 3 (ns-gat shape)
     ("gcn_molhiv", "graph_classification.py", ["--epochs", "3"]),                                         # main_dgl_molhiv_gcn.py
+    ("gcn_molhiv_hipgraph", "graph_classification.py", ["--epochs", "4", "--hipgraph"]),                  # same loop, one captured HIP graph
     ("gin_molhiv", "graph_classification.py", ["--model", "gin", "--epochs", "3"]),                       # BASELINE config 5 wording
     ("ns_sage_reddit", "sampling_sage.py", ["--num-epochs", "8"]),                                        # reddit/ns-sage-dgl.py
     ("gcmc_ml-1m", "link_prediction.py", ["--data_name", "ml-1m", "--train_max_iter", "30"]),             # gcmc_dgl/train.py
