@@ -320,7 +320,7 @@ template <int VEC, int G, int MODE, int WMODE, bool LANEMASK, bool RAGGED = fals
 #ifndef MGX_RW32_WAVES
 #define MGX_RW32_WAVES 1
 #endif
-__global__ __launch_bounds__(kBlock, MGX_RW32_WAVES) void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
+__global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
   typedef typename VecT<VEC>::type VA;
   typedef VA VU __attribute__((aligned(4)));  // RAGGED: gathers / stores are only dword-aligned
   typedef typename std::conditional<RAGGED, VU, VA>::type V;

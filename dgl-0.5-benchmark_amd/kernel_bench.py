@@ -77,6 +77,10 @@ def main():
         print("SPMM\n----------------------------")
         with torch.no_grad():
             for n_hid in [int(h) for h in args.hidden.split(",")]:
+                # every width measured on freshly placed operands: inside a sweep that reuses the allocator's cached blocks
+                # the proteins D = 128 launch took 6.4 ms against 2.07 ms on its own (same kernel, same sizes; only the
+                # placement of the 68 / 153 / 68 MB operands differs -- observed twice, not understood)
+                torch.cuda.empty_cache()
                 nfeat = torch.rand(n_src, n_hid, device=ctx)
                 efeat = torch.rand(nnz, n_hid, device=ctx) if args.spmm_binary != "copy_lhs" else None
                 avg, best = time_op(lambda: dgl.ops.gspmm(g, args.spmm_binary, args.spmm_reduce, nfeat, efeat))
