@@ -389,7 +389,7 @@ def main():
                                 "1 GPU" if world == 1 else "edge-cut partition over %d GPUs, RCCL all_to_all halo" % world),
                    "spmm_per_epoch": 2 * cfg["num_layers"] - 1, "final_loss": loss,
                    "schedule": os.environ.get("MGX_SCHEDULE", "auto"), "partition": part_stats,
-                   "model": "full_graph.GraphSAGE (reference module graph; dense layers with this package's gradient helpers)",
+                   "module_graph": "full_graph.GraphSAGE: the reference module graph; dense layers with this package's gradient helpers",
                    "dense_gemm_selection": tunable.status()},
     }
 

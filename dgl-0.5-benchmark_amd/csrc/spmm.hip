@@ -317,10 +317,15 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave_kernel(const SpmmFastArgs
 // (dword-aligned accesses); the lane that owns the last 1-3 columns loads the LAST FOUR floats of the row instead -- no
 // read past the row, its own columns are the tail components of that window -- and only the epilogue distinguishes it.
 template <int VEC, int G, int MODE, int WMODE, bool LANEMASK, bool RAGGED = false, bool MASKED = false>
-#ifndef MGX_RW32_WAVES
-#define MGX_RW32_WAVES 1
+#ifndef MGX_RW32_WAVES  // -DMGX_RW32_WAVES=8: the occupancy experiment of profiles/r02_spmm_variants.txt (64 VGPRs, spills)
+#define MGX_RW32_WAVES 0
 #endif
-__global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
+#if MGX_RW32_WAVES > 0
+#define MGX_RW32_BOUNDS __launch_bounds__(kBlock, MGX_RW32_WAVES)
+#else
+#define MGX_RW32_BOUNDS __launch_bounds__(kBlock)
+#endif
+__global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
   typedef typename VecT<VEC>::type VA;
   typedef VA VU __attribute__((aligned(4)));  // RAGGED: gathers / stores are only dword-aligned
   typedef typename std::conditional<RAGGED, VU, VA>::type V;
