@@ -40,7 +40,8 @@ def _power_law_degrees(n, total, max_deg, gen, device, alpha=2.1):
     return d.clamp(min=0.5, max=float(max_deg))
 
 
-def synthetic_edges(n, m, max_deg, seed, device="cpu", mixing=0.25, symmetric=True, permute=True, avg_comm=None):
+def synthetic_edges(n, m, max_deg, seed, device="cpu", mixing=0.25, symmetric=True, permute=True, avg_comm=None,
+                    return_communities=False):
     """m edges over n nodes: endpoints drawn proportionally to a power-law weight; a fraction
     (1 - mixing) of the edges stays inside the source's planted community.  Returns int64 (src, dst);
     when `symmetric`, both directions are stored (2m directed edges, like OGB's DGL graphs)."""
@@ -78,6 +79,13 @@ def synthetic_edges(n, m, max_deg, seed, device="cpu", mixing=0.25, symmetric=Tr
         src, dst = perm[src], perm[dst]
     if symmetric:
         src, dst = torch.cat([src, dst]), torch.cat([dst, src])
+    if return_communities:  # planted community of every (relabelled) node -- experiments only (ground truth for the schedules)
+        comm_of = torch.searchsorted(ends, torch.arange(n, device=device), right=True).clamp(max=n_comm - 1)
+        if permute:
+            out = torch.empty_like(comm_of)
+            out[perm] = comm_of
+            comm_of = out
+        return src, dst, comm_of
     return src, dst
 
 

@@ -24,6 +24,7 @@ del src, dst
 csc = g._index.csc()
 X = torch.rand(n, D, device=dev)
 base_ms = kc.time_spmm(csc, X)
+kc._marker(dev)
 ref, _, _ = sparse.gspmm_raw(csc, "copy_lhs", "sum", X, None)
 print(json.dumps({"variant": "baseline", "ms": round(base_ms, 4), "items": csc.plan().num_items if csc.plan() else n}), flush=True)
 
@@ -116,6 +117,7 @@ for B in [int(b) for b in os.environ.get("B", "8192,16384").split(",")]:
     build_s = time.perf_counter() - t0
     out, _, _ = sparse.gspmm_raw(csr2, "copy_lhs", "sum", X, None)
     err = float(((out - ref).abs().max() / ref.abs().max()).item())
+    kc._marker(dev)   # closes the block that holds the reference / check launches
     ms = kc.time_spmm(csr2, X)
     kc._marker(dev)
     print(json.dumps({"variant": "tiled", "B": B, "ms": round(ms, 4), "items": int(item_row.shape[0]), "slots": num_slots,
