@@ -66,6 +66,43 @@ __device__ __forceinline__ int64_t xcd_remap(int64_t b, int64_t nb) {
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int ilog2_ceil(int64_t x) { int l = 0; while ((int64_t(1) << l) < x) ++l; return l; }
 
+// Per-XCD stretches of a schedule of `n_items` work items, `rpb` items per workgroup.  Block b serves XCD b % 8 (observed
+// round-robin placement; speed only) and takes the (b / 8)-th group of rpb items of that XCD's stretch.  Stretch boundaries:
+// the plan's edge-balanced ones (read from device memory) or equal item counts (`per` items each).
+struct XcdRanges {
+  const int64_t* start_dev;  // [9] or NULL
+  int64_t per;               // equal split: items per XCD (a multiple of rpb)
+  int64_t n_items;
+};
+static inline int64_t xcd_ranges(const mgx_spmm_plan* plan, int64_t n_items, int rpb, XcdRanges& r) {
+  const bool have = plan && plan->xcd_item_start_dev && plan->xcd_item_start[kXcds] == n_items && plan->xcd_item_start[0] == 0;
+  r.per = round_up((n_items + kXcds - 1) / kXcds, rpb);
+  r.n_items = n_items;
+  r.start_dev = have ? plan->xcd_item_start_dev : nullptr;
+  int64_t most = (r.per + rpb - 1) / rpb;
+  if (have) {
+    most = 0;
+    for (int x = 0; x < kXcds; ++x) {
+      const int64_t len = plan->xcd_item_start[x + 1] - plan->xcd_item_start[x];
+      const int64_t blocks = ((len > 0 ? len : 0) + rpb - 1) / rpb;
+      if (blocks > most) most = blocks;
+    }
+  }
+  return (most > 0 ? most : 1) * kXcds;  // grid size
+}
+__device__ __forceinline__ void xcd_stretch(const XcdRanges& r, int64_t& first, int64_t& stop) {
+  const int xcd = blockIdx.x % kXcds;
+  if (r.start_dev) {
+    first = r.start_dev[xcd];
+    stop = r.start_dev[xcd + 1];
+  } else {
+    first = (int64_t)xcd * r.per;
+    stop = first + r.per;
+    if (first > r.n_items) first = r.n_items;
+    if (stop > r.n_items) stop = r.n_items;
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_shfl_xor(T v, int mask) { return __shfl_xor(v, mask, kWave); }
 

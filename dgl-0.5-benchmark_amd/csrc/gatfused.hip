@@ -47,6 +47,7 @@ struct GatArgs {
   const int32_t* item_end;
   const int32_t* item_node;
   int64_t n_items;
+  XcdRanges xcd;    // item stretch of every XCD (edge balanced when the plan says so)
   int64_t nblocks;
   int rpb;
   int H, F, D;
@@ -165,11 +166,13 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
   const uint32_t h4 = (uint32_t)head * (MODE == GAT_BWD_SRC ? 16u : 4u);
   const char* __restrict__ gatb = reinterpret_cast<const char*>(a.gat);
   const char* __restrict__ smallb = reinterpret_cast<const char*>(MODE == GAT_BWD_SRC ? a.nstat : a.el);
-  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * a.rpb;
+  int64_t item_base, item_stop;
+  xcd_stretch(a.xcd, item_base, item_stop);
+  item_base += (int64_t)(blockIdx.x / kXcds) * a.rpb;
 
   for (int r = wave; r < a.rpb; r += kWavesPerBlock) {
     const int64_t item = item_base + r;
-    if (item >= a.n_items) break;
+    if (item >= item_stop) break;
     int64_t row, irow;
     int32_t beg, end;
     if (a.item_row) {
@@ -423,7 +426,7 @@ static void gat_fill(GatArgs& a, const mgx_csr* csr, const mgx_spmm_plan* plan, 
     a.item_node = plan->item_node; a.n_items = plan->num_items;
   }
   a.rpb = gat_rows_per_block();
-  a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);
+  a.nblocks = xcd_ranges(plan, a.n_items, a.rpb, a.xcd);
   a.H = (int)H; a.F = (int)F; a.D = (int)(H * F);
   a.slope = slope; a.seed = seed;
   a.keep_scale = 1.f / (1.f - p);

@@ -44,6 +44,8 @@ struct SpmmFastArgs {
   int64_t n_items;  // == n_rows without a plan
   int64_t src_rows; // rows of the gathered matrix (num_cols, or nnz for copy_rhs)
   int64_t n_rows;
+  XcdRanges xcd;    // lean kernel: item stretch of every XCD (edge balanced when the plan says so)
+  const mgx_spmm_plan* plan;  // host side only
   int64_t nblocks;  // logical blocks, multiple of kXcds
   int rpb;          // work items per workgroup
   int D;            // elements per feature row
@@ -339,7 +341,10 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
   const int f = (blockIdx.y * G + l) * VEC;
   const bool factive = LANEMASK ? (f < a.D) : true;
   const int head = (WMODE == 2 && factive) ? f / a.F : 0;
-  const int64_t item_base = xcd_remap(blockIdx.x, a.nblocks) * a.rpb;
+  // block b serves XCD b % 8 (observed round-robin placement; speed only): its (b / 8)-th group of rpb items of that XCD's stretch
+  int64_t item_base, item_stop;
+  xcd_stretch(a.xcd, item_base, item_stop);
+  item_base += (int64_t)(blockIdx.x / kXcds) * a.rpb;
   const uint32_t rowbytes = (uint32_t)a.D * 4u;
   const int nvalid = RAGGED ? (a.D - f < VEC ? a.D - f : VEC) : VEC;  // columns this lane owns (RAGGED: the last lane < 4)
   const bool tail = RAGGED && factive && nvalid < VEC;
@@ -437,7 +442,7 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
   };
 
   int r = wave;
-  if (r >= a.rpb || item_base + r >= a.n_items) return;
+  if (r >= a.rpb || item_base + r >= item_stop) return;
   int64_t row;
   int32_t beg, end;
   load_meta(item_base + r, row, beg, end);
@@ -451,7 +456,7 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
 
   for (;;) {
     const int rn = r + kWavesPerBlock;
-    const bool has_next = rn < a.rpb && item_base + rn < a.n_items;
+    const bool has_next = rn < a.rpb && item_base + rn < item_stop;
     int64_t nrow = 0;
     int32_t nbeg = 0, nend = 0, neid = 0;
     uint32_t ngoff = 0;
@@ -673,7 +678,10 @@ static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, hipStream_t s) {
   if (!split && a.rpb < kWavesPerBlock * NB) a.rpb = kWavesPerBlock * NB;  // one item per lane group
   a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);
   dim3 grid((unsigned)a.nblocks, (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
-  if (split && launch_rowwave32<VEC, G, MODE>(a, a.src_rows, grid, s)) return;
+  {  // lean kernel: per-XCD stretches of the schedule
+    const dim3 lgrid((unsigned)xcd_ranges(a.plan, a.n_items, a.rpb, a.xcd), grid.y);
+    if (split && launch_rowwave32<VEC, G, MODE>(a, a.src_rows, lgrid, s)) return;
+  }
   if (split) hipLaunchKernelGGL((spmm_rowwave_kernel<Idx, VEC, G, MODE>), grid, dim3(kBlock), 0, s, a);
   else hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, false>), grid, dim3(kBlock), 0, s, a);
 }
@@ -757,6 +765,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     a.accum = accumulate;
     a.ragged = 0;
     a.item_row = nullptr; a.item_beg = nullptr; a.item_end = nullptr; a.partial = nullptr; a.n_items = n_rows;
+    a.plan = plan;
     if (plan) {
       a.item_row = plan->item_row; a.item_beg = (const Idx*)plan->item_beg; a.item_end = (const Idx*)plan->item_end;
       a.partial = partial_ws; a.n_items = plan->num_items;

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC_DIR, "libmi355x_graph.so")
+LIB_PATH = os.environ.get("MGX_LIB_PATH") or os.path.join(CSRC_DIR, "libmi355x_graph.so")  # MGX_LIB_PATH: A/B against another build
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "mi355x_graph.h"))
 
 

@@ -11,7 +11,7 @@ processed changes, so results and the DGL-visible numbering are unaffected.
   * split: rows with more than `split` edges become several work items whose partial sums are
     combined in a fixed order (deterministic), so a 17k-edge hub never serialises on one wavefront;
   * order: semi-synchronous label propagation (a few rounds of sort + run-length on the device)
-    groups rows into clusters; the schedule is the rows sorted by (final label, earlier labels).
+    groups rows into clusters (8 rounds; MGX_LP_ROUNDS); the schedule is the rows sorted by (final label, earlier labels).
 """
 import ctypes
 import os
@@ -33,6 +33,8 @@ class MgxSpmmPlan(ctypes.Structure):
         ("num_slots", ctypes.c_int64),
         ("slot_item", ctypes.c_void_p),
         ("item_node", ctypes.c_void_p),
+        ("xcd_item_start", ctypes.c_int64 * 9),
+        ("xcd_item_start_dev", ctypes.c_void_p),
     ]
 
 
@@ -45,6 +47,24 @@ class SpmmPlan(object):
         self.item_node = item_node
         self.order_kind = order_kind
         self._c = None
+        self.xcd_item_start = self._balance_xcds()
+        self._xcd_dev = (torch.tensor(self.xcd_item_start, dtype=torch.int64, device=item_row.device)
+                         if self.xcd_item_start[-1] and item_row.is_cuda else None)
+
+    def _balance_xcds(self, xcds=8, granule=16):
+        """Cut the schedule into 8 contiguous stretches of equal EDGE count (one per XCD), boundaries on multiples of the
+        workgroup's item count.  One device cumsum + 7 searches + one host read, once per plan."""
+        n = int(self.item_row.shape[0])
+        if n < xcds * granule * 4 or os.environ.get("MGX_XCD_BALANCE", "1") != "1":
+            return [0] * (xcds + 1)
+        ln = (self.item_end - self.item_beg).to(torch.int64) + 1  # +1: an empty item still costs its fixed overhead
+        csum = torch.cumsum(ln, 0)
+        targets = (torch.arange(1, xcds, device=csum.device, dtype=torch.float64) * (float(csum[-1]) / xcds)).to(torch.int64)
+        cuts = (torch.searchsorted(csum, targets) // granule * granule).clamp(max=n).tolist()
+        out = [0] + [int(c) for c in cuts] + [n]
+        for i in range(1, len(out)):
+            out[i] = max(out[i], out[i - 1])
+        return out
 
     @property
     def num_items(self):
@@ -61,7 +81,9 @@ class SpmmPlan(object):
                                   self.hub_row.data_ptr() if self.num_hubs else None,
                                   self.hub_slot_ptr.data_ptr() if self.num_hubs else None, self.num_slots,
                                   self.slot_item.data_ptr() if self.num_slots else None,
-                                  None if self.item_node is None else self.item_node.data_ptr())
+                                  None if self.item_node is None else self.item_node.data_ptr(),
+                                  (ctypes.c_int64 * 9)(*self.xcd_item_start),
+                                  None if self._xcd_dev is None else self._xcd_dev.data_ptr())
         return self._c
 
 
@@ -104,7 +126,7 @@ def label_propagation(indptr, indices, n, rounds=5, seed=0, node_w=None, max_wei
     return history
 
 
-def locality_order(csr, rounds=5):
+def locality_order(csr, rounds=int(os.environ.get("MGX_LP_ROUNDS", "8"))):
     """Row permutation placing rows of one (nested) cluster next to each other."""
     n = csr.num_rows
     if n > csr.num_cols:

@@ -94,6 +94,13 @@ typedef struct mgx_spmm_plan {
   int64_t num_slots;            /* partial_ws holds num_slots * out_len floats */
   const int32_t* slot_item;     /* [num_slots] index of the work item that owns each partial slot */
   const int32_t* item_node;     /* [num_items] the row of EVERY item (direct or split); used by mgx_sddmm_csr */
+  /* Optional (HOST values): items [xcd_item_start[x], xcd_item_start[x+1]) are walked by XCD x.  Each XCD (own L2) gets a
+   * CONTIGUOUS stretch of the schedule; equal item counts leave the XCDs unequal WORK on skewed graphs (R-MAT: 151 % vs 0.1 %
+   * of the mean edge count), so the builder cuts the schedule at equal EDGE counts.  All zero: equal item counts.
+   * xcd_item_start_dev: the same nine numbers in device memory (kernels read their two from there: a by-value array indexed
+   * by blockIdx costs scalar registers and, through them, resident workgroups). */
+  int64_t xcd_item_start[9];
+  const int64_t* xcd_item_start_dev;
 } mgx_spmm_plan;
 
 /* Device-side construction of the plan tables (hub-row splitting over an optional row order; NULL = natural order).
