@@ -269,15 +269,20 @@ def main():
         t0 = time.perf_counter()
         block, hplan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
         g = mdist.DistGraph(block, hplan)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         own_cpu = own.cpu()
         x, y = feats[own_cpu].to(device), labels[own_cpu].to(device)
         g.set_static_input(x)  # the layer-1 input is constant: its halo rows are exchanged once and stay resident
         train_idx = torch.nonzero(train_mask[own_cpu]).flatten().to(device)
         total_train = float(train_mask.sum())
+        t2 = time.perf_counter()
         mdist.broadcast_parameters(model)
         bucket = mdist.GradBucket(model)
         torch.cuda.synchronize()
-        part_stats["build_local_s_rank0"] = round(time.perf_counter() - t0, 2)
+        part_stats["build_local_s_rank0"] = round(t1 - t0, 2)
+        part_stats["slice_features_s_rank0"] = round(t2 - t1, 2)
+        part_stats["broadcast_parameters_s_rank0"] = round(time.perf_counter() - t2, 2)
         # per-rank halo statistics, gathered on every rank (tiny)
         mine = torch.tensor([hplan.n_own, hplan.n_halo, int(sum(hplan.send_splits)), block.number_of_edges(),
                              int(hplan.halo.num_edges())], dtype=torch.int64, device=device)
