@@ -223,6 +223,12 @@ def main():
         print("warning: --gpus %d but the process group has %d rank(s); reporting n_gpus=%d" % (args.gpus, world, world),
               file=sys.stderr)
 
+    t_start = time.perf_counter()
+
+    def progress(msg):  # rank 0, stderr: where a multi-rank run spends its set-up time (never on stdout: that is the JSON line)
+        if rank == 0 and world > 1:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
     import dgl
     import full_graph
     from mi355x_graph import dist as mdist, sparse
@@ -234,6 +240,8 @@ def main():
     m = max(64, int(spec["m"] * args.scale))
     src, dst = synthetic_edges(n, m, min(spec["max_deg"], n - 1), spec["seed"], device, symmetric=spec["symmetric"])
     num_edges = int(src.shape[0])
+    torch.cuda.synchronize()
+    progress("graph generated on the device (%d edges)" % num_edges)
     gen = torch.Generator(device="cpu").manual_seed(spec["seed"] + 100)
     feats = torch.rand(n, spec["feat"], generator=gen)
     labels = torch.randint(0, spec["classes"], (n,), generator=gen)
@@ -244,6 +252,7 @@ def main():
         return full_graph.GraphSAGE(spec["feat"], cfg["hidden"], spec["classes"], cfg["num_layers"], cfg["dropout"],
                                     cfg["batch_norm"], cfg["neigh_bias"], plain=plain).to(device)
 
+    progress("host features / labels drawn")
     model = make_model()
     part_stats = {}
     bucket = None
@@ -265,12 +274,15 @@ def main():
         else:
             assign = torch.empty(n, dtype=torch.int64, device=device)
         part_stats["partition_s_rank0"] = round(time.perf_counter() - t0, 2)
+        progress("partitioned")
         mdist.broadcast(assign, 0)
+        progress("assignment broadcast")
         t0 = time.perf_counter()
         block, hplan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
         g = mdist.DistGraph(block, hplan)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
+        progress("local partition built")
         own_cpu = own.cpu()
         x, y = feats[own_cpu].to(device), labels[own_cpu].to(device)
         g.set_static_input(x)  # the layer-1 input is constant: its halo rows are exchanged once and stay resident
@@ -283,6 +295,7 @@ def main():
         part_stats["build_local_s_rank0"] = round(t1 - t0, 2)
         part_stats["slice_features_s_rank0"] = round(t2 - t1, 2)
         part_stats["broadcast_parameters_s_rank0"] = round(time.perf_counter() - t2, 2)
+        progress("features sliced, parameters broadcast")
         # per-rank halo statistics, gathered on every rank (tiny)
         mine = torch.tensor([hplan.n_own, hplan.n_halo, int(sum(hplan.send_splits)), block.number_of_edges(),
                              int(hplan.halo.num_edges())], dtype=torch.int64, device=device)
@@ -338,7 +351,9 @@ def main():
             records, sparse.PROFILE = sparse.PROFILE, None
         return elapsed, loss, records
 
+    progress("starting warm-up + timed steps")
     elapsed, loss, records = timed(make_step(model, opt, bucket), args.steps, args.warmup, True)
+    progress("timed region done")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         mdist.all_reduce(t, op=dist.ReduceOp.MAX)
