@@ -14,10 +14,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
 
 
-def run(script, *args, root=REF, **extra_env):
+def run(script, *args, root=REF, cwd=HERE, **extra_env):
     env = dict(os.environ, OMP_NUM_THREADS="4", **extra_env)
     p = subprocess.run([sys.executable, os.path.join(HERE, "run_reference_script.py"), os.path.join(root, script)] + list(args),
-                       capture_output=True, text=True, timeout=600, env=env, cwd=HERE)
+                       capture_output=True, text=True, timeout=600, env=env, cwd=cwd)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     return p.stdout
 
@@ -96,6 +96,41 @@ def test_more_neighbor_sampling_scripts_run_unmodified(script, args):
     out = run(script, "--gpu", "-1", "--num-epochs", "2", "--num-workers", "0", "--eval-every", "1", *args,
               root=REF_SAMPLING, MGX_DATASET_SCALE="0.005")
     assert "Avg epoch time" in out and "Eval Acc" in out, out[-1500:]
+
+
+_CLUSTER_CACHE = """
+import os, sys, numpy as np
+sys.path[:0] = [%r, %r, %r, %r]
+import oracle_backend; oracle_backend.install()
+import dgl
+from dgl.transform import metis_partition
+from ogb.nodeproppred import DglNodePropPredDataset
+g, _ = DglNodePropPredDataset(name='ogbn-products')[0]
+parts = metis_partition(g, %d)
+cache = np.empty(len(parts), dtype=object)
+for k, sub in parts.items():
+    cache[k] = sub.ndata[dgl.NID].numpy()
+os.makedirs('datasets', exist_ok=True)
+np.save('datasets/ogbn-products_%d.npy', cache, allow_pickle=True)
+"""
+
+
+@pytest.mark.timeout(900)
+def test_cluster_sampling_script_runs_unmodified(tmp_path):
+    """SURVEY 8f rank 1 (Cluster-GCN flavour): ogbn-product/cluster-sage/dgl/main.py (metis_partition -> g.subgraph ->
+    create_formats_ -> dglnn.SAGEConv on the induced cluster, full-graph inference on CPU) on a 0.5 %-scale products
+    stand-in.  sampler.py:41 np.save()s a ragged list, which NumPy >= 1.24 refuses whatever the framework, so the
+    partition cache the script looks for (sampler.py:35-37) is written first -- with this repo's metis_partition, through
+    the same calls partition_utils.py:9-15 makes -- and the script itself still runs unmodified."""
+    psize = 64
+    root = os.path.dirname(HERE)
+    code = _CLUSTER_CACHE % (os.path.join(HERE, "shims"), os.path.join(root, "dgl-0.5-benchmark_amd"), root, HERE, psize, psize)
+    env = dict(os.environ, OMP_NUM_THREADS="4", MGX_DATASET_SCALE="0.005")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = run("ogbn-product/cluster-sage/dgl/main.py", "--gpu", "-1", "--num-epochs", "6", "--num_partitions", str(psize),
+              "--batch-size", "4", root=REF_SAMPLING, cwd=str(tmp_path), MGX_DATASET_SCALE="0.005")
+    assert "Avg epoch time" in out and "Best Eval Acc" in out and out.count("Average test accuracy") == 10, out[-1500:]
 
 
 @pytest.mark.timeout(900)
