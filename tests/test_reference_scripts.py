@@ -116,20 +116,26 @@ np.save('datasets/ogbn-products_%d.npy', cache, allow_pickle=True)
 
 
 @pytest.mark.timeout(900)
-def test_cluster_sampling_script_runs_unmodified(tmp_path):
-    """SURVEY 8f rank 1 (Cluster-GCN flavour): ogbn-product/cluster-sage/dgl/main.py (metis_partition -> g.subgraph ->
-    create_formats_ -> dglnn.SAGEConv on the induced cluster, full-graph inference on CPU) on a 0.5 %-scale products
-    stand-in.  sampler.py:41 np.save()s a ragged list, which NumPy >= 1.24 refuses whatever the framework, so the
-    partition cache the script looks for (sampler.py:35-37) is written first -- with this repo's metis_partition, through
-    the same calls partition_utils.py:9-15 makes -- and the script itself still runs unmodified."""
+@pytest.mark.parametrize("script,extra", [
+    ("ogbn-product/cluster-sage/dgl/main.py", []),
+    # 2-head GATConv on the induced cluster (self-loops re-added, sampler.py:56-57), layer-wise block inference through
+    # dgl.sampling.MultiLayerNeighborSampler([None]) / NodeDataLoader (main.py:88-96)
+    ("ogbn-product/cluster-gat/dgl/main.py", ["--num-workers", "0", "--num-hidden", "16", "--num-heads", "2"]),
+], ids=["cluster-sage", "cluster-gat"])
+def test_cluster_sampling_script_runs_unmodified(tmp_path, script, extra):
+    """SURVEY 8f rank 1 (Cluster-GCN flavour): ogbn-product/cluster-{sage,gat}/dgl/main.py (metis_partition -> g.subgraph
+    -> create_formats_ -> dglnn.SAGEConv / GATConv on the induced cluster, full-graph inference on CPU) on a 0.5 %-scale
+    products stand-in.  sampler.py np.save()s a ragged list, which NumPy >= 1.24 refuses whatever the framework, so the
+    partition cache the script looks for (cluster-sage/dgl/sampler.py:35-37) is written first -- with this repo's
+    metis_partition, through the same calls partition_utils.py:9-15 makes -- and the script itself still runs unmodified."""
     psize = 64
     root = os.path.dirname(HERE)
     code = _CLUSTER_CACHE % (os.path.join(HERE, "shims"), os.path.join(root, "dgl-0.5-benchmark_amd"), root, HERE, psize, psize)
     env = dict(os.environ, OMP_NUM_THREADS="4", MGX_DATASET_SCALE="0.005")
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
     assert p.returncode == 0, p.stderr[-3000:]
-    out = run("ogbn-product/cluster-sage/dgl/main.py", "--gpu", "-1", "--num-epochs", "6", "--num_partitions", str(psize),
-              "--batch-size", "4", root=REF_SAMPLING, cwd=str(tmp_path), MGX_DATASET_SCALE="0.005")
+    out = run(script, "--gpu", "-1", "--num-epochs", "6", "--num_partitions", str(psize), "--batch-size", "4", *extra,
+              root=REF_SAMPLING, cwd=str(tmp_path), MGX_DATASET_SCALE="0.005")
     assert "Avg epoch time" in out and "Best Eval Acc" in out and out.count("Average test accuracy") == 10, out[-1500:]
 
 
