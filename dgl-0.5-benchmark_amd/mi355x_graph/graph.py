@@ -9,6 +9,7 @@ Mirrors the part of the DGLGraph surface the benchmark scripts touch (SURVEY App
 Sparse formats are built lazily and cached on a shared GraphIndex: the in-CSR ("csc", rows =
 destination nodes) feeds the forward g-SpMM, the out-CSR ("csr") the backward pass.
 """
+from collections import namedtuple
 from collections.abc import MutableMapping
 from contextlib import contextmanager
 
@@ -262,6 +263,9 @@ class Frame(MutableMapping):
         return Frame(self._n, {k: v.to(device) for k, v in self._d.items()}, self._kind)
 
 
+Scheme = namedtuple("Scheme", ["shape", "dtype"])
+
+
 class DGLGraph(object):
     """Homogeneous graph (or bipartite block) with the DGLGraph message-passing surface."""
 
@@ -453,6 +457,13 @@ class DGLGraph(object):
 
     def set_batch_num_edges(self, val):
         self._batch_num_edges = torch.as_tensor(val, dtype=torch.int64, device=self.device)
+
+    def node_attr_schemes(self, ntype=None):
+        """{feature name: (shape of one row, dtype)} of the node frame (cluster_gcn_dgl.py:242 iterates its keys)."""
+        return {k: Scheme(tuple(v.shape[1:]), v.dtype) for k, v in self.ndata.items()}
+
+    def edge_attr_schemes(self, etype=None):
+        return {k: Scheme(tuple(v.shape[1:]), v.dtype) for k, v in self.edata.items()}
 
     def in_degree(self, v):
         return int(self.in_degrees(torch.as_tensor([v]))[0])

@@ -159,6 +159,10 @@ class NodeDataLoader(object):
 def node_subgraph(g, nodes):
     """g.subgraph(nodes | mask): induced subgraph with relabelled nodes; node features are sliced."""
     dev = g.device
+    if isinstance(nodes, dict):  # {ntype: ids} of a graph with one node type (dgl_cluster_sampler.py:99)
+        if len(nodes) != 1:
+            raise DGLError("subgraph: a homogeneous graph takes the nodes of exactly one type")
+        nodes = next(iter(nodes.values()))
     nodes = torch.as_tensor(nodes, device=dev)
     if nodes.dtype == torch.bool:
         nodes = torch.nonzero(nodes).flatten()

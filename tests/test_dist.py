@@ -285,6 +285,13 @@ def test_metis_partition_api_for_cluster_gcn():
     assert g.in_degree(0) == int((dst == 0).sum()) and g.out_degree(0) == int((src == 0).sum())
     fs, fd = g.find_edges(0)
     assert int(fs[0]) == int(src[0]) and int(fd[0]) == int(dst[0])
+    # dgl_cluster_sampler.py:99-101: the {ntype: ids} spelling and the feature-name listing
+    g2 = g.subgraph({"_U": batch})
+    assert torch.equal(g2.edges()[0], s1) and torch.equal(g2.edges()[1], d1)
+    schemes = g.node_attr_schemes()
+    assert set(schemes) == set(g.ndata.keys()) and schemes["feat"].shape == tuple(g.ndata["feat"].shape[1:])
+    with pytest.raises(dgl.DGLError):
+        g.subgraph({"a": batch, "b": batch})
 
 
 def test_cached_partition_roundtrip(tmp_path):

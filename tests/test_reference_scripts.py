@@ -139,6 +139,41 @@ def test_cluster_sampling_script_runs_unmodified(tmp_path, script, extra):
     assert "Avg epoch time" in out and "Best Eval Acc" in out and out.count("Average test accuracy") == 10, out[-1500:]
 
 
+_LINK_CACHE = """
+import os, sys, numpy as np
+sys.path[:0] = [%r, %r, %r, %r]
+import oracle_backend; oracle_backend.install()
+import dgl
+from ogb.linkproppred import DglLinkPropPredDataset
+g = dgl.to_bidirected(dgl.add_self_loop(DglLinkPropPredDataset(name='ogbl-citation')[0]))
+group = dgl.transform.metis_partition_assignment(g, %d).numpy()
+cache = np.empty(%d, dtype=object)
+for k in range(len(cache)):
+    cache[k] = np.argwhere(group == k)
+os.makedirs('datasets', exist_ok=True)
+np.save('datasets/ogbl-citation_%d.npy', cache, allow_pickle=True)
+"""
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("gnn", ["gcn", "gat"])
+def test_cluster_link_prediction_script_runs_unmodified(tmp_path, gnn):
+    """sampling/link-prediction/cluster_gcn_dgl.py (SURVEY row 15, a5's second u_dot_v caller): metis_partition_assignment
+    -> g.subgraph({'_U': nids}) -> dglnn.GraphConv(norm='none') / GATConv on the cluster -> apply_edges(fn.u_dot_v) on the
+    cluster and on a negative-sample graph.  The script exit(0)s after its first epoch (cluster_gcn_dgl.py:160); the ragged
+    np.save of dgl_cluster_sampler.py:67 is sidestepped as above by writing the cache it looks for."""
+    psize = 32
+    root = os.path.dirname(HERE)
+    code = _LINK_CACHE % (os.path.join(HERE, "shims"), os.path.join(root, "dgl-0.5-benchmark_amd"), root, HERE, psize, psize, psize)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, OMP_NUM_THREADS="4"), cwd=str(tmp_path))
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = run("cluster_gcn_dgl.py", "--num_partitions", str(psize), "--batch_size", "4", "--num_workers", "0",
+              "--hidden_channels", "32", "--gnn_type", gnn, "--negs", "2", root="/root/reference/end_to_end/sampling/link-prediction",
+              cwd=str(tmp_path))
+    assert "epoch time:" in out and "dec2_time" in out, out[-1500:]
+
+
 @pytest.mark.timeout(900)
 def test_gcmc_script_runs_unmodified(tmp_path):
     """gcmc_dgl/train.py (dgl.bipartite + hetero_from_relations, graph[etype], nodes[ntype].data,
