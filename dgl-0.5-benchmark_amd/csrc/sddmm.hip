@@ -188,6 +188,91 @@ __global__ __launch_bounds__(kBlock) void sddmm_coo_kernel(const SddmmArgs<Idx> 
   }
 }
 
+// Lean COO walk (element-wise ops, both operands as wide as the output, int32 ids, operands addressable with 32-bit byte
+// offsets): the same edge-parallel layout as sddmm_coo_kernel, but the lane that loaded an edge's ids turns them into the BYTE
+// OFFSETS of the two operand rows once, the lane groups receive offsets through ds_bpermute and address
+// `base (SGPR pair) + offset (one VGPR)` -- no 64-bit multiply per gather -- the output row of edge j of a chunk is
+// `chunk base (SGPR pair) + j * rowbytes`, and the gathers of step k+1 are issued before step k is combined and stored.
+// OPS: 0 = both operands, 1 = lhs only (copy_lhs), 2 = rhs only (copy_rhs).
+template <int VEC, int G, int OPS>
+__global__ __launch_bounds__(kBlock) void sddmm_coo32_kernel(const SddmmArgs<int32_t> a) {
+  typedef typename VecT<VEC>::type V;
+  constexpr int NB = kWave / G;
+  constexpr int U = 2;
+  constexpr int STEP = NB * U;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int sub = lane / G, l = lane % G;
+  const int kc = (blockIdx.y * G + l) * VEC;
+  const bool kactive = kc < a.out_len;
+  const uint32_t kc4 = kactive ? (uint32_t)kc * 4u : 0u;  // idle feature lanes re-read column 0 and store nothing
+  const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int chunk = a.coo_chunk, nchunks = a.coo_chunks;
+  const int64_t e0 = wave_id * ((int64_t)chunk * nchunks);
+  if (e0 >= a.nnz) return;
+  const uint32_t rowbytes = (uint32_t)a.out_len * 4u;
+  const bool lu = a.lhs_target == MGX_TARGET_U, ru = a.rhs_target == MGX_TARGET_U;
+  const bool need_u = (OPS != 2 && lu) || (OPS != 1 && ru);
+  const bool need_v = (OPS != 2 && !lu) || (OPS != 1 && !ru);
+  const char* __restrict__ Lb = reinterpret_cast<const char*>(a.L);
+  const char* __restrict__ Rb = reinterpret_cast<const char*>(a.R);
+  const int op = a.op;
+  auto load_ids = [&](int64_t base, uint32_t& lo, uint32_t& ro) {
+    const int64_t q = base + lane;
+    const bool in = lane < chunk && q < a.nnz;
+    const int32_t mu = (need_u && in) ? __builtin_nontemporal_load(&a.src[q]) : 0;  // id streams: read once
+    const int32_t mv = (need_v && in) ? __builtin_nontemporal_load(&a.dst[q]) : 0;
+    lo = (uint32_t)(lu ? mu : mv) * rowbytes;
+    ro = (uint32_t)(ru ? mu : mv) * rowbytes;
+  };
+  uint32_t lo, ro;
+  load_ids(e0, lo, ro);
+  for (int c = 0; c < nchunks; ++c) {
+    const int64_t base = e0 + (int64_t)c * chunk;
+    if (base >= a.nnz) break;  // wave-uniform
+    uint32_t nlo = 0, nro = 0;
+    if (c + 1 < nchunks) load_ids(base + chunk, nlo, nro);
+    const int cnt = (int)((a.nnz - base) < chunk ? (a.nnz - base) : chunk);
+    char* __restrict__ ob = reinterpret_cast<char*>(a.out + base * a.out_len);
+    auto issue = [&](int k, V (&lv)[U], V (&rv)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = k + u * NB + sub;
+        const int bi = (j < cnt ? j : 0) * 4;  // lanes past the end re-read edge 0 of the chunk (valid memory) and store nothing
+        if (OPS != 2) lv[u] = *reinterpret_cast<const V*>(Lb + ((uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)lo) + kc4));
+        if (OPS != 1) rv[u] = *reinterpret_cast<const V*>(Rb + ((uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)ro) + kc4));
+      }
+    };
+    auto finish = [&](int k, const V (&lv)[U], const V (&rv)[U]) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = k + u * NB + sub;
+        if (j < cnt && kactive) {
+          const V val = OPS == 1 ? lv[u] : (OPS == 2 ? rv[u] : sddmm_op<V>(op, lv[u], rv[u]));
+          V* o = reinterpret_cast<V*>(ob + ((uint32_t)j * rowbytes + kc4));
+          // rows of >= 32 bytes: the E x D output is written once and not re-read here -- stream it past L2
+          if (VEC * G >= 8) __builtin_nontemporal_store(val, o);
+          else *o = val;
+        }
+      }
+    };
+    V la[U], ra[U], lb[U], rb[U];
+    issue(0, la, ra);
+    int k = STEP;
+    for (;;) {
+      if (k >= cnt) { finish(k - STEP, la, ra); break; }
+      issue(k, lb, rb);
+      finish(k - STEP, la, ra);
+      k += STEP;
+      if (k >= cnt) { finish(k - STEP, lb, rb); break; }
+      issue(k, la, ra);
+      finish(k - STEP, lb, rb);
+      k += STEP;
+    }
+    lo = nlo;
+    ro = nro;
+  }
+}
+
 template <typename Idx, int VEC, int G, bool DIRECT, bool DOT>
 __global__ __launch_bounds__(kBlock) void sddmm_csr_kernel(const SddmmArgs<Idx> a) {
   constexpr int NB = kWave / G;
@@ -381,6 +466,23 @@ template <> bool try_headdot_any<int32_t>(const SddmmArgs<int32_t>& a, hipStream
   return getenv("MGX_SDDMM_GENERIC_DOT") == nullptr && try_headdot(a, s);
 }
 
+// int32 COO graphs with element-wise DIRECT operands on node targets, each addressable with 32-bit byte offsets
+template <int VEC, int G, bool ELIGIBLE>
+static bool launch_coo32(const SddmmArgs<int32_t>& a, dim3 grid, hipStream_t s) {
+  if (!ELIGIBLE || getenv("MGX_SDDMM_V1") != nullptr) return false;  // A/B switch
+  auto rows_of = [&](int t) -> int64_t { return t == MGX_TARGET_U ? a.n_cols : (t == MGX_TARGET_V ? a.n_rows : -1); };
+  const int64_t lim = int64_t(1) << 32;
+  if (a.L && (rows_of(a.lhs_target) <= 0 || rows_of(a.lhs_target) * a.out_len * 4 >= lim)) return false;
+  if (a.R && (rows_of(a.rhs_target) <= 0 || rows_of(a.rhs_target) * a.out_len * 4 >= lim)) return false;
+  if (a.nnz >= (int64_t(1) << 31)) return false;
+  if (a.L && a.R) hipLaunchKernelGGL((sddmm_coo32_kernel<VEC, G, 0>), grid, dim3(kBlock), 0, s, a);
+  else if (a.L) hipLaunchKernelGGL((sddmm_coo32_kernel<VEC, G, 1>), grid, dim3(kBlock), 0, s, a);
+  else hipLaunchKernelGGL((sddmm_coo32_kernel<VEC, G, 2>), grid, dim3(kBlock), 0, s, a);
+  return true;
+}
+template <int VEC, int G, bool ELIGIBLE>
+static bool launch_coo32(const SddmmArgs<int64_t>&, dim3, hipStream_t) { return false; }
+
 template <typename Idx, int VEC, int G, bool CSR, bool DIRECT, bool DOT>
 static void launch_one(const SddmmArgs<Idx>& a, hipStream_t s) {
   const unsigned gy = DOT ? 1u : (unsigned)((a.out_len + G * VEC - 1) / (G * VEC));
@@ -398,6 +500,7 @@ static void launch_one(const SddmmArgs<Idx>& a, hipStream_t s) {
     b.coo_chunks = share < kWave ? 1 : (int)(share / kWave);
     const int64_t per_block = (int64_t)kWavesPerBlock * share;
     const int64_t nb = (a.nnz + per_block - 1) / per_block;
+    if (launch_coo32<VEC, G, DIRECT && !DOT>(b, dim3((unsigned)nb, gy), s)) return;
     hipLaunchKernelGGL((sddmm_coo_kernel<Idx, VEC, G, DIRECT, DOT>), dim3((unsigned)nb, gy), dim3(kBlock), 0, s, b);
   }
 }
@@ -473,11 +576,12 @@ static int32_t check_common(int32_t op, const float* lhs, const float* rhs, int3
 }
 
 template <typename Idx>
-static int32_t run_coo(int64_t nnz, const void* src, const void* dst, int32_t op, const float* lhs, const float* rhs,
+static int32_t run_coo(int64_t num_src, int64_t num_dst, int64_t nnz, const void* src, const void* dst, int32_t op, const float* lhs, const float* rhs,
                        int32_t lt, int32_t rt, int64_t l_len, int64_t r_len, int64_t out_len, int64_t reduce_size,
                        const int64_t* l_off, const int64_t* r_off, float* out, hipStream_t s) {
   SddmmArgs<Idx> a{};
   a.src = (const Idx*)src; a.dst = (const Idx*)dst; a.nnz = nnz; a.L = lhs; a.R = rhs;
+  a.n_cols = num_src; a.n_rows = num_dst;  // rows of a U- / V-target operand (the lean kernel's 32-bit offsets)
   a.l_off = l_off; a.r_off = r_off; a.out = out; a.l_len = l_len; a.r_len = r_len; a.out_len = out_len;
   a.reduce_size = reduce_size; a.op = op; a.lhs_target = lt; a.rhs_target = rt;
   return sddmm_impl<Idx, false>(a, s);
@@ -509,7 +613,6 @@ extern "C" int32_t mgx_sddmm_coo(int64_t num_src, int64_t num_dst, int64_t nnz, 
                                  float* out, void* stream) {
   using namespace mgx;
   MGX_ENTER();
-  (void)num_src; (void)num_dst;
   MGX_CHECK_ARG(idx_bits == 32 || idx_bits == 64, "mgx_sddmm_coo: idx_bits must be 32 or 64, got %d", idx_bits);
   MGX_CHECK_ARG(nnz >= 0, "mgx_sddmm_coo: negative nnz");
   MGX_CHECK_ARG(nnz == 0 || (src && dst), "mgx_sddmm_coo: src/dst is NULL");
@@ -517,9 +620,9 @@ extern "C" int32_t mgx_sddmm_coo(int64_t num_src, int64_t num_dst, int64_t nnz, 
   if (st != MGX_OK) return st;
   MGX_CHECK_ARG(nnz / (kWavesPerBlock * 4) < (int64_t(1) << 31) - 2, "mgx_sddmm_coo: nnz too large");
   if (idx_bits == 32)
-    return run_coo<int32_t>(nnz, src, dst, op, lhs, rhs, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size,
+    return run_coo<int32_t>(num_src, num_dst, nnz, src, dst, op, lhs, rhs, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size,
                             l_off, r_off, out, (hipStream_t)stream);
-  return run_coo<int64_t>(nnz, src, dst, op, lhs, rhs, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size,
+  return run_coo<int64_t>(num_src, num_dst, nnz, src, dst, op, lhs, rhs, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size,
                           l_off, r_off, out, (hipStream_t)stream);
 }
 

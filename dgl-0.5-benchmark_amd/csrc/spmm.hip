@@ -348,8 +348,9 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
   const uint32_t rowbytes = (uint32_t)a.D * 4u;
   const int nvalid = RAGGED ? (a.D - f < VEC ? a.D - f : VEC) : VEC;  // columns this lane owns (RAGGED: the last lane < 4)
   const bool tail = RAGGED && factive && nvalid < VEC;
-  // idle feature lanes re-read the row start (never stored); the tail lane reads the row's last four floats
-  const uint32_t f4 = !factive ? 0u : (tail ? (uint32_t)(a.D - VEC) * 4u : (uint32_t)f * 4u);
+  // idle feature lanes re-read the first column of this pass (lane 0's cache line; never stored); the tail lane reads the
+  // row's last four floats
+  const uint32_t f4 = !factive ? (uint32_t)(blockIdx.y * G * VEC) * 4u : (tail ? (uint32_t)(a.D - VEC) * 4u : (uint32_t)f * 4u);
   const char* __restrict__ srcb = reinterpret_cast<const char*>(a.src);
   const int bidx0 = sub * 4;  // byte index of this lane group's first edge for ds_bpermute
 
@@ -691,11 +692,20 @@ static void launch_fast_v(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s
   const int lanes = (a.D + VEC - 1) / VEC;
   int G = 1;
   while (G < lanes && G < kWave) G <<= 1;
-  // experiment: column tiling -- fewer lanes per row, the remaining columns in further passes (grid.y)
+  // Rows wider than 32 lanes are aggregated in column passes of 32 lanes (grid.y): a wave whose 64 lanes all follow ONE edge
+  // issues one gather per edge, two lane groups of 32 issue one per two edges -- measured at D = 256 / 512 / 608, G = 64 -> 32:
+  // reddit-shaped (492 in-edges per node) 7.24 -> 6.12, 14.45 -> 12.17, 18.19 -> 15.13 ms; proteins-shaped 5.12 -> 4.19 ms at
+  // D = 256; products-shaped 10.37 -> 9.91 ms at D = 256 (experiments/exp_wide_ragged.py).  The index stream is re-read per
+  // pass (4 bytes per edge against 512 gathered).  A second pass that owns only a few columns costs most of a full one
+  // (reddit-shaped, D = 132 / 144 / 160 / 192: one 64-lane pass 4.24 / 4.07 / 4.12 / 5.08 ms, 32 + remainder 5.64 / 5.26 / 4.88 /
+  // 4.96 ms), so rows of 33..44 lanes keep the single 64-lane pass.  MGX_SPMM_G=<lanes> overrides (A/B runs; 64 = old rule).
   static const int env_g = getenv("MGX_SPMM_G") ? atoi(getenv("MGX_SPMM_G")) : 0;
-  if (env_g > 0 && env_g < G && !a.ragged && MODE == MODE_COPY_LHS) G = env_g;
-  const int NB = kWave / G;
   const double avg_deg = a.n_rows > 0 ? (double)nnz / (double)a.n_rows : 0.0;
+  if (MODE == MODE_COPY_LHS) {
+    if (env_g > 0) { if (env_g < G && !a.ragged) G = env_g; }
+    else if (G > 32 && lanes > 44 && avg_deg >= 24.0) G = 32;  // short rows: the per-row cost of a second pass outweighs it
+  }                                                            // (arxiv-shaped, 6.9 in-edges per node, D = 256: 0.202 -> 0.221 ms)
+  const int NB = kWave / G;
   // One row per wave (lane groups share the row's edges) or one row per lane group.  The lean int32 kernel is faster
   // than the row-per-group kernel at every degree measured (arxiv-shaped, avg in-degree 6.9: D = 64 187 -> 108 us, D = 8
   // 148 -> 82 us; cora / pubmed 40-54 -> 22-26 us), so it is always taken when eligible; the 64-bit kernels keep the old
@@ -723,7 +733,7 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
   const int vec_ok = (MODE == MODE_MUL_EDGE) ? a.F : a.D;
   // odd widths (41 classes): 16-byte gathers with a ragged last lane, lean int32 kernel only, one head
   const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.D * 4 < (int64_t(1) << 32) && getenv("MGX_SPMM_V1") == nullptr;
-  if (lean && MODE != MODE_COPY_RHS && a.D % 4 != 0 && a.D > 4 && a.D <= 256 && a.H == 1 && getenv("MGX_SPMM_NO_RAGGED") == nullptr &&
+  if (lean && MODE != MODE_COPY_RHS && a.D % 4 != 0 && a.D > 4 && (a.D <= 256 || MODE == MODE_COPY_LHS) && a.H == 1 && getenv("MGX_SPMM_NO_RAGGED") == nullptr &&
       (uintptr_t)a.src % 4 == 0) {
     SpmmFastArgs<Idx> b = a;
     b.ragged = 1;

@@ -162,8 +162,10 @@ SAGE_CONFIGS = {
                  bidirect=False, neigh_bias=True),       # main_dgl_citation_sage.py:100-101,139
     "pubmed": dict(dataset="pubmed", num_layers=2, hidden=16, dropout=0.5, lr=0.01, batch_norm=False,
                    bidirect=False, neigh_bias=True),
-    "reddit": dict(dataset="reddit-small", num_layers=2, hidden=16, dropout=0.5, lr=0.01, batch_norm=False,
-                   bidirect=False, neigh_bias=True),
+    "reddit": dict(dataset="reddit", num_layers=2, hidden=16, dropout=0.5, lr=0.01, batch_norm=False,
+                   bidirect=False, neigh_bias=True),    # main_dgl_reddit_sage.py:100-101,139 (E = 114.6 M, D = 602 then 16)
+    "reddit-small": dict(dataset="reddit-small", num_layers=2, hidden=16, dropout=0.5, lr=0.01, batch_norm=False,
+                         bidirect=False, neigh_bias=True),
 }
 
 

@@ -79,6 +79,7 @@ def gspmm(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int
     csr = _view(indptr, indices, eids, num_cols)
     want_arg = reduce in ("max", "min")
     out, arg_u, arg_e = sparse.gspmm_raw(csr, op, reduce, ufeat, efeat, want_arg=want_arg)
+    out = out.contiguous()  # the wide-row path returns a column slice of a padded result; the fake impl promises dense strides
     return out, (arg_u if arg_u is not None else indptr.new_empty(0)), (arg_e if arg_e is not None else indptr.new_empty(0))
 
 

@@ -96,6 +96,9 @@ SPMM_SHAPES = [
     (500, 500, 6000, 16), (2000, 2000, 60000, 32), (2000, 2000, 100000, 64), (2000, 2000, 30000, 100),
     (2000, 2000, 30000, 128), (1500, 700, 20000, 256), (300, 300, 2000, 602), (200, 200, 1500, 1433),
     (400, 400, 3000, 7), (400, 400, 3000, 6), (50, 5000, 4000, 64), (3000, 40, 150000, 64),
+    # column passes of 32 lanes (132 = 32 + 1 lanes, 320 = 32 + 32 + 16), wide odd widths on ragged 16-byte lanes
+    (600, 600, 20000, 132), (600, 600, 20000, 320), (500, 500, 9000, 300), (500, 500, 9000, 150), (400, 400, 6000, 514),
+    (300, 300, 5000, 1023), (3000, 40, 90000, 602),
 ]
 
 
@@ -773,3 +776,26 @@ def test_row_sparse_gradient_aggregation(oracle, D, density, monkeypatch):
     monkeypatch.setenv("MGX_SPARSE_GRAD", "0")
     (ops.gspmm(g, "copy_lhs", "mean", h2, None)[sel] * w).sum().backward()
     assert float((h.grad - h2.grad).abs().max()) <= 1e-5 * max(float(h2.grad.abs().max()), 1e-6)
+
+
+def test_wide_rows_are_aggregated_on_a_line_padded_copy(oracle):
+    """sparse.gspmm_raw: D = 602 (reddit's input width) on a dense graph goes through the copy padded to 608 columns and
+    comes back as its [:, :602] view -- same numbers as the oracle, gradients flow through the autograd wrapper."""
+    n, D = 1200, 602
+    nnz = (1 << 20) + 4096
+    src, dst = random_graph(n, n, nnz, seed=5)
+    rng = np.random.default_rng(5)
+    X = rng.random((n, D), dtype=np.float32)
+    g = mk(n, n, src, dst, torch.int32)
+    ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+    x = T(X).requires_grad_(True)
+    out = ops.gspmm(g, "copy_lhs", "mean", x, None)
+    assert out.shape == (n, D) and not out.is_contiguous()  # the padded path was taken
+    assert rel(out.detach().cpu(), oracle.spmm(ip, ix, ei, "copy_lhs", "mean", X, None)) < RTOL
+    w = T(rng.random((n, D), dtype=np.float32))
+    (out * w).sum().backward()
+    # d/dX of sum(w * mean-aggregate) = aggregate over the reversed graph of w / deg
+    deg = np.maximum(np.bincount(dst, minlength=n), 1).astype(np.float32)
+    rp, rx, re = oracle.coo_to_csr(n, src, dst)
+    ref = oracle.spmm(rp, rx, re, "copy_lhs", "sum", (w.cpu().numpy() / deg[:, None]).astype(np.float32), None)
+    assert rel(x.grad.cpu(), ref) < RTOL
