@@ -55,9 +55,10 @@ import torch.nn.functional as F  # noqa: E402
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
-def spmm_algorithmic_bytes(n_dst, n_src, nnz, D):
-    """indptr + indices + every source row once + every output row once."""
-    return 4 * (n_dst + 1) + 4 * nnz + 4 * n_src * D + 4 * n_dst * D
+def spmm_algorithmic_bytes(n_dst, n_src, nnz, D, accumulate=False):
+    """indptr + indices + every source row once + every output row once (an accumulating launch -- out += A x,
+    the backward aggregation inside ops.SageMeanLayerFn -- also reads every output row once)."""
+    return 4 * (n_dst + 1) + 4 * nnz + 4 * n_src * D + 4 * n_dst * D * (2 if accumulate else 1)
 
 
 def host_cores():
@@ -231,7 +232,7 @@ def main():
 
     import dgl
     import full_graph
-    from mi355x_graph import dist as mdist, sparse
+    from mi355x_graph import dist as mdist, ops, sparse
     from mi355x_graph.datasets import SHAPES, synthetic_edges
 
     cfg = full_graph.SAGE_CONFIGS[args.dataset]
@@ -313,7 +314,11 @@ def main():
     del src, dst
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
 
+    y_train = y[train_idx]  # labels are constant: gathered once, outside the timed steps
+
     def make_step(model, opt, bucket):
+        model.rows_are_distinct = True  # train_idx = nonzero() of a mask
+
         def step():
             # main_dgl_product_sage.py:101-110; for P > 1 the mean loss is taken over the GLOBAL train set
             model.train()
@@ -321,8 +326,11 @@ def main():
                 bucket.zero()  # gradients are views into one flat buffer (zero_grad would drop them)
             else:
                 opt.zero_grad()
-            out = model(g, x)[train_idx]
-            loss = F.nll_loss(out, y[train_idx], reduction="sum") / total_train
+            # default model: log_softmax on the train rows only (row-wise, so the same numbers); plain: the reference's line
+            if model.plain:
+                loss = F.nll_loss(model(g, x)[train_idx], y_train, reduction="sum") / total_train
+            else:
+                loss = ops.nll_sum(model(g, x, rows=train_idx), y_train) / total_train
             loss.backward()
             if bucket is not None:
                 bucket.all_reduce()
@@ -373,7 +381,7 @@ def main():
         durs = [r["start"].elapsed_time(r["end"]) * 1e-3 for r in sel]
         r0 = sel[0]
         avg = sum(durs) / len(durs)
-        algo = sum(spmm_algorithmic_bytes(r["n_rows"], r["n_cols"], r["nnz"], width) for r in sel) / len(sel)
+        algo = sum(spmm_algorithmic_bytes(r["n_rows"], r["n_cols"], r["nnz"], width, r.get("accumulate", False)) for r in sel) / len(sel)
         achieved = algo / avg / 1e9
         kernels.append({"bound": "hbm", "kernel": "g-SpMM copy_u/sum|mean, D=%d (mgx_spmm_csr)" % width, "D": width,
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -381,7 +389,9 @@ def main():
                         "algorithmic_bytes_per_launch": int(algo),
                         "no_reuse_gather_bytes_per_launch": int(algo - 4 * r0["n_cols"] * width + 4 * r0["nnz"] * width),
                         "avg_launch_ms": round(avg * 1e3, 4), "launches_timed": len(durs),
-                        "launches_per_epoch": len(durs) // max(args.steps, 1), "rows": r0["n_rows"], "nnz": r0["nnz"]})
+                        "launches_per_epoch": len(durs) // max(args.steps, 1),
+                        "accumulating_launches_per_epoch": sum(1 for r in sel if r.get("accumulate")) // max(args.steps, 1),
+                        "rows": r0["n_rows"], "nnz": r0["nnz"]})
 
     # backward aggregations of a GRADIENT go through the row-sparse kernel (zero rows skipped): listed apart, never mixed into
     # the dense launches' average -- the compulsory-bytes formula assumes every source row is read

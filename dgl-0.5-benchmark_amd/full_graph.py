@@ -57,6 +57,12 @@ class SAGEConv(nn.Module):
         nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
 
     def forward(self, graph, feat):
+        if not self.plain and not isinstance(feat, tuple) and self.fc_self.bias is None:
+            # the whole layer as one autograd node (ops.SageMeanLayerFn): same kernels, the two gradients of `feat` meet inside
+            # the reversed aggregation instead of in a separate add pass
+            y = ops.sage_mean_layer(graph, feat, self.fc_self.weight, self.fc_neigh.weight, self.fc_neigh.bias)
+            if y is not None:
+                return y
         graph = graph.local_var()
         feat_src, feat_dst = feat if isinstance(feat, tuple) else (feat, feat)
         graph.srcdata["h"] = feat_src
@@ -75,6 +81,7 @@ class GraphSAGE(nn.Module):
     def __init__(self, in_feats, hidden_feats, out_feats, num_layers, dropout, batch_norm=False, neigh_bias=True, plain=False):
         super(GraphSAGE, self).__init__()
         self.plain = plain
+        self.rows_are_distinct = False  # set by a caller whose `rows` is an index without duplicates (nonzero of a mask)
         self.layers = nn.ModuleList()
         self.bns = nn.ModuleList()
         dims = [in_feats] + [hidden_feats] * (num_layers - 1) + [out_feats]
@@ -91,7 +98,10 @@ class GraphSAGE(nn.Module):
         for bn in self.bns:
             bn.reset_parameters()
 
-    def forward(self, g, x):
+    def forward(self, g, x, rows=None):
+        """`rows`: return the log-probabilities of these nodes only.  log_softmax is row-wise, so model(g, x, rows) ==
+        model(g, x)[rows] (main_dgl_product_sage.py:105: `model(g, feats)[train_idx]`) without normalising -- forward and
+        backward -- the 92 % of the rows the loss never reads."""
         for i, layer in enumerate(self.layers[:-1]):
             x = layer(g, x)
             if len(self.bns):
@@ -101,6 +111,8 @@ class GraphSAGE(nn.Module):
             else:
                 x = ops.relu_dropout(x, self.dropout.p, self.training)  # F.relu + dropout, one pass each way on the device
         x = self.layers[-1](g, x)
+        if rows is not None:
+            x = ops.select_distinct_rows(x, rows) if self.rows_are_distinct else x[rows]
         return x.log_softmax(dim=-1)
 
 
@@ -134,8 +146,10 @@ def sage_train_step(model, g, feats, labels, train_idx, optimizer):
     """main_dgl_product_sage.py:101-110."""
     model.train()
     optimizer.zero_grad()
-    out = model(g, feats)[train_idx]
-    loss = F.nll_loss(out, labels[train_idx])
+    if model.plain:
+        loss = F.nll_loss(model(g, feats)[train_idx], labels[train_idx])
+    else:  # same numbers: log_softmax on the loss rows only, the mean NLL as a gather + sum
+        loss = ops.nll_sum(model(g, feats, rows=train_idx), labels[train_idx]) / train_idx.shape[0]
     loss.backward()
     optimizer.step()
     return loss.item()
@@ -182,6 +196,7 @@ def build_sage(name, device, scale=1.0):
     model = GraphSAGE(data.features.shape[1], cfg["hidden"], data.num_classes, cfg["num_layers"], cfg["dropout"],
                       cfg["batch_norm"], cfg["neigh_bias"]).to(device)
     train_idx = torch.nonzero(data.train_mask).flatten()
+    model.rows_are_distinct = True  # nonzero() of a mask
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
     return cfg, data, g, model, train_idx, opt
 

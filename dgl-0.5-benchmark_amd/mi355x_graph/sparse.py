@@ -257,7 +257,7 @@ class HipBackend(object):
             rec = None
             if PROFILE is not None:  # bench.py: HIP events on the launch stream around this launch
                 rec = {"op": op, "reduce": reduce, "out_len": out_len, "n_rows": csr.num_rows, "n_cols": csr.num_cols,
-                       "nnz": csr.nnz, "start": torch.cuda.Event(enable_timing=True),
+                       "nnz": csr.nnz, "accumulate": accumulate_into is not None, "start": torch.cuda.Event(enable_timing=True),
                        "end": torch.cuda.Event(enable_timing=True)}
                 rec["start"].record(torch.cuda.current_stream(dev))
             _lib.check(_lib.lib().mgx_spmm_csr(

@@ -212,10 +212,52 @@ def test_plain_reference_modules_match_the_default_model(batch_norm):
     losses = []
     for m in models:
         m.train()
-        loss = F.nll_loss(m(g, x)[idx], y[idx])
+        # default: the layer as one autograd node (ops.SageMeanLayerFn) and log_softmax on the loss rows only; plain: the
+        # reference's composition and its `model(g, feats)[train_idx]`
+        loss = F.nll_loss(m(g, x)[idx] if m.plain else m(g, x, rows=idx), y[idx])
         loss.backward()
         losses.append(float(loss))
     assert abs(losses[0] - losses[1]) < 1e-5 * abs(losses[1])
     for (name, p1), (_, p2) in zip(models[0].named_parameters(), models[1].named_parameters()):
         err, ref = float((p1.grad - p2.grad).abs().max()), float(p2.grad.abs().max())
         assert err < 1e-3 * ref + 1e-7, (name, err, ref)  # two fp32 summation orders over 70 k rows (GEMM vs mgx_xty)
+
+
+def test_fused_sage_layer_node_matches_the_composition(monkeypatch):
+    """ops.sage_mean_layer (one autograd node; the reversed aggregation accumulates into the self GEMM's gradient) against
+    update_all(copy_src, mean) + linear_sum: same output, same gradients for the features and all three parameters."""
+    sys.path.insert(0, PKG)
+    import full_graph
+    n = 5000
+    src, dst = random_graph(n, n, 20 * n, seed=9, skew=True)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().formats(["csr", "csc"]).to(DEV)
+    torch.manual_seed(3)
+    conv = full_graph.SAGEConv(48, 32).to(DEV)
+    x0 = torch.randn(n, 48, device=DEV)
+    w = torch.randn(n, 32, device=DEV)
+    res = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MGX_SAGE_FUSED_LAYER", fused)
+        x = x0.clone().requires_grad_(True)
+        conv.zero_grad()
+        y = conv(g, x)
+        (y * w).sum().backward()
+        res.append([y.detach(), x.grad] + [p.grad.clone() for p in conv.parameters()])
+        assert (type(y.grad_fn).__name__ == "SageMeanLayerFnBackward") == (fused == "1")
+    for a, b in zip(*res):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6
+    assert ops.sage_mean_layer(g, x0.double(), conv.fc_self.weight, conv.fc_neigh.weight) is None  # fp64: not this path
+
+
+def test_log_softmax_on_selected_rows_is_the_same_model_output():
+    sys.path.insert(0, PKG)
+    import full_graph
+    n = 3000
+    src, dst = random_graph(n, n, 10 * n, seed=4)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().to(DEV)
+    torch.manual_seed(0)
+    m = full_graph.GraphSAGE(20, 16, 7, 2, 0.0).to(DEV).eval()
+    x = torch.randn(n, 20, device=DEV)
+    rows = torch.arange(0, n, 7, device=DEV)
+    with torch.no_grad():
+        assert torch.equal(m(g, x)[rows], m(g, x, rows=rows))

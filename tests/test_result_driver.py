@@ -27,3 +27,20 @@ def test_parse_results_takes_mean_of_last_ten_and_final_accuracies():
     assert md.splitlines()[0].startswith("| run | epoch_time") and len(md.splitlines()) == 4
     names = [r[0] for r in gr.RUNS]
     assert len(set(names)) == len(names) and all(os.path.exists(os.path.join(PKG, r[1])) for r in gr.RUNS)
+
+
+def test_loss_helpers_match_torch():
+    """ops.select_distinct_rows / ops.nll_sum (the default model's loss tail) == x[rows] / F.nll_loss(reduction='sum'),
+    values and gradients; host tensors, no kernels involved."""
+    import torch
+    import torch.nn.functional as F
+    from mi355x_graph import ops
+    torch.manual_seed(0)
+    x = torch.randn(50, 7, requires_grad=True)
+    rows = torch.randperm(50)[:20]
+    t = torch.randint(0, 7, (20,))
+    l1 = F.nll_loss(x[rows].log_softmax(-1), t, reduction="sum")
+    (g1,) = torch.autograd.grad(l1, x)
+    l2 = ops.nll_sum(ops.select_distinct_rows(x, rows).log_softmax(-1), t)
+    (g2,) = torch.autograd.grad(l2, x)
+    assert abs(float(l1.detach() - l2.detach())) < 1e-4 and torch.allclose(g1, g2, atol=1e-6)
