@@ -17,11 +17,14 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
   return z ^ (z >> 31);
 }
 
+// Rows of c4 float4s; x rows are ldx4 float4s apart, y rows ldy4 (dense: c4 = n4, one row).  The mask and the random stream
+// are indexed by the DENSE element number, so a strided call draws the same mask as the dense one.
 __global__ __launch_bounds__(kBlock) void relu_dropout_fwd_kernel(int64_t n4, const v4f* __restrict__ x, v4f* __restrict__ y,
                                                                   uint8_t* __restrict__ mask, uint32_t drop_below, float scale,
-                                                                  uint64_t seed, uint64_t offset) {
+                                                                  uint64_t seed, uint64_t offset, int64_t c4, int64_t ldx4, int64_t ldy4) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
-    const v4f v = __builtin_nontemporal_load(&x[i]);
+    const int64_t r = i / c4, c = i - r * c4;
+    const v4f v = __builtin_nontemporal_load(&x[r * ldx4 + c]);
     const uint64_t r0 = splitmix64(seed ^ ((offset + (uint64_t)i) * 2));
     const uint64_t r1 = splitmix64(seed ^ ((offset + (uint64_t)i) * 2 + 1));
     const bool k0 = (uint32_t)r0 >= drop_below && v.x > 0.f, k1 = (uint32_t)(r0 >> 32) >= drop_below && v.y > 0.f;
@@ -31,22 +34,24 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_fwd_kernel(int64_t n4, co
     o.y = k1 ? v.y * scale : 0.f;
     o.z = k2 ? v.z * scale : 0.f;
     o.w = k3 ? v.w * scale : 0.f;
-    y[i] = o;
+    y[r * ldy4 + c] = o;
     mask[i] = (uint8_t)((k0 ? 1 : 0) | (k1 ? 2 : 0) | (k2 ? 4 : 0) | (k3 ? 8 : 0));
   }
 }
 
 __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(int64_t n4, const v4f* __restrict__ dy, const uint8_t* __restrict__ mask,
-                                                                  v4f* __restrict__ dx, float scale) {
+                                                                  v4f* __restrict__ dx, float scale, int64_t c4, int64_t lddy4,
+                                                                  int64_t lddx4) {
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
-    const v4f g = __builtin_nontemporal_load(&dy[i]);
+    const int64_t r = i / c4, c = i - r * c4;
+    const v4f g = __builtin_nontemporal_load(&dy[r * lddy4 + c]);
     const uint8_t m = mask[i];
     v4f o;
     o.x = (m & 1) ? g.x * scale : 0.f;
     o.y = (m & 2) ? g.y * scale : 0.f;
     o.z = (m & 4) ? g.z * scale : 0.f;
     o.w = (m & 8) ? g.w * scale : 0.f;
-    dx[i] = o;
+    dx[r * lddx4 + c] = o;
   }
 }
 
@@ -69,7 +74,7 @@ extern "C" int32_t mgx_relu_dropout_fwd(int64_t n, const float* x, float p, uint
   const double thr = (double)p * 4294967296.0;
   const uint32_t drop_below = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
   hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)x, (v4f*)y,
-                     mask, drop_below, 1.f / (1.f - p), seed, offset);
+                     mask, drop_below, 1.f / (1.f - p), seed, offset, n / 4, n / 4, n / 4);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
@@ -82,7 +87,44 @@ extern "C" int32_t mgx_relu_dropout_bwd(int64_t n, const float* dy, const uint8_
   if (n == 0) return MGX_OK;
   MGX_CHECK_ARG(dy && dx && mask && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0, "mgx_relu_dropout_bwd: NULL or unaligned pointer");
   hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)dy, mask,
-                     (v4f*)dx, 1.f / (1.f - p));
+                     (v4f*)dx, 1.f / (1.f - p), n / 4, n / 4, n / 4);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+// Row-strided forms: x / y (dy / dx) are [rows, cols] views whose rows are *_stride floats apart -- column blocks of wider
+// matrices (the activation written straight into the left half of the next layer's [h | neigh] GEMM operand).  cols and the
+// strides multiples of 4, 16-byte aligned pointers; the mask is dense, [rows * cols / 4].
+extern "C" int32_t mgx_relu_dropout_fwd_strided(int64_t rows, int64_t cols, const float* x, int64_t x_stride, float p, uint64_t seed,
+                                                uint64_t offset, float* y, int64_t y_stride, uint8_t* mask, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(rows >= 0 && cols >= 0 && cols % 4 == 0 && x_stride % 4 == 0 && y_stride % 4 == 0 && x_stride >= cols && y_stride >= cols,
+                "mgx_relu_dropout_fwd_strided: cols and strides must be multiples of 4, strides >= cols");
+  MGX_CHECK_ARG(p >= 0.f && p < 1.f, "mgx_relu_dropout_fwd_strided: p must be in [0, 1)");
+  const int64_t n = rows * cols;
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(x && y && mask && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "mgx_relu_dropout_fwd_strided: NULL or unaligned pointer");
+  const double thr = (double)p * 4294967296.0;
+  const uint32_t drop_below = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+  hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)x, (v4f*)y,
+                     mask, drop_below, 1.f / (1.f - p), seed, offset, cols / 4, x_stride / 4, y_stride / 4);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_relu_dropout_bwd_strided(int64_t rows, int64_t cols, const float* dy, int64_t dy_stride, const uint8_t* mask,
+                                                float p, float* dx, int64_t dx_stride, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(rows >= 0 && cols >= 0 && cols % 4 == 0 && dy_stride % 4 == 0 && dx_stride % 4 == 0 && dy_stride >= cols && dx_stride >= cols,
+                "mgx_relu_dropout_bwd_strided: cols and strides must be multiples of 4, strides >= cols");
+  MGX_CHECK_ARG(p >= 0.f && p < 1.f, "mgx_relu_dropout_bwd_strided: p must be in [0, 1)");
+  const int64_t n = rows * cols;
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(dy && dx && mask && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0, "mgx_relu_dropout_bwd_strided: NULL or unaligned pointer");
+  hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)dy, mask,
+                     (v4f*)dx, 1.f / (1.f - p), cols / 4, dy_stride / 4, dx_stride / 4);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

@@ -54,6 +54,8 @@ struct SpmmFastArgs {
   int mean;
   int accum;  // out += result (MGX_SPMM_ACCUMULATE)
   int ragged; // D % 4 != 0 handled with 16-byte gathers (RAGGED kernel)
+  int lds;    // row stride of `src` in floats (>= D; == D unless mgx_spmm_copy_u_strided)
+  int ldo;    // row stride of `out` in floats
 };
 
 // Work items per workgroup.  Workgroups are dispatched in blockIdx order, so a SMALL value makes
@@ -345,7 +347,7 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
   int64_t item_base, item_stop;
   xcd_stretch(a.xcd, item_base, item_stop);
   item_base += (int64_t)(blockIdx.x / kXcds) * a.rpb;
-  const uint32_t rowbytes = (uint32_t)a.D * 4u;
+  const uint32_t rowbytes = (uint32_t)a.lds * 4u;
   const int nvalid = RAGGED ? (a.D - f < VEC ? a.D - f : VEC) : VEC;  // columns this lane owns (RAGGED: the last lane < 4)
   const bool tail = RAGGED && factive && nvalid < VEC;
   // idle feature lanes re-read the first column of this pass (lane 0's cache line; never stored); the tail lane reads the
@@ -508,14 +510,14 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
       }
       if (!tail) {
         if (row >= 0) {  // separate pointers: the output store keeps its non-temporal hint
-          float* op = a.out + row * (int64_t)a.D + f;
+          float* op = a.out + row * (int64_t)a.ldo + f;
           if (a.accum) acc += *reinterpret_cast<const V*>(op);
           __builtin_nontemporal_store((VA)acc, reinterpret_cast<V*>(op));
         } else {
           *reinterpret_cast<V*>(a.partial + (-(row + 1)) * (int64_t)a.D + f) = acc;
         }
       } else {  // own columns f .. f+nvalid-1 are components VEC-nvalid .. VEC-1 of the window
-        float* op = (row >= 0 ? a.out + row * (int64_t)a.D : a.partial + (-(row + 1)) * (int64_t)a.D) + f;
+        float* op = (row >= 0 ? a.out + row * (int64_t)a.ldo : a.partial + (-(row + 1)) * (int64_t)a.D) + f;
         const float* av = reinterpret_cast<const float*>(&acc);
         for (int j = 0; j < nvalid; ++j) {
           float v = av[VEC - nvalid + j];
@@ -539,7 +541,7 @@ template <typename Idx>
 __global__ __launch_bounds__(kBlock) void spmm_hub_fixup_kernel(const Idx* indptr, const int32_t* hub_row,
                                                                 const int32_t* hub_slot_ptr, int64_t num_hubs,
                                                                 const float* partial, const float* dst_scale,
-                                                                float* out, int D, int mean, int accum) {
+                                                                float* out, int D, int mean, int accum, int ldo) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t h = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
   if (h >= num_hubs) return;
@@ -554,8 +556,8 @@ __global__ __launch_bounds__(kBlock) void spmm_hub_fixup_kernel(const Idx* indpt
       acc = acc / (float)(deg > 1 ? deg : 1);
     }
     if (dst_scale) acc *= dst_scale[row];
-    if (accum) acc += out[row * D + k];
-    out[row * D + k] = acc * scale;
+    if (accum) acc += out[row * ldo + k];
+    out[row * ldo + k] = acc * scale;
   }
 }
 
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void spmm_generic_kernel(const SpmmGenericA
 template <int VEC, int G, int MODE>
 static bool launch_rowwave32(const SpmmFastArgs<int32_t>& a, int64_t src_rows, dim3 grid, hipStream_t s) {
   if (getenv("MGX_SPMM_V1") != nullptr) return false;  // A/B switch
-  if (src_rows * (int64_t)a.D * 4 >= (int64_t(1) << 32)) return false;
+  if (src_rows * (int64_t)a.lds * 4 >= (int64_t(1) << 32)) return false;
   if (a.ragged) {  // VEC == 4, D % 4 != 0, one weight per edge at most (launch_fast checked eligibility)
     if (VEC == 4 && MODE != MODE_COPY_RHS) {
       if (MODE == MODE_MUL_EDGE || a.src_scale) hipLaunchKernelGGL((spmm_rowwave32_kernel<VEC, G, MODE, 1, true, true>), grid, dim3(kBlock), 0, s, a);
@@ -710,7 +712,7 @@ static void launch_fast_v(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s
   // than the row-per-group kernel at every degree measured (arxiv-shaped, avg in-degree 6.9: D = 64 187 -> 108 us, D = 8
   // 148 -> 82 us; cora / pubmed 40-54 -> 22-26 us), so it is always taken when eligible; the 64-bit kernels keep the old
   // rule (rows long enough to feed all NB lane groups).  MGX_SPLIT_FACTOR overrides the factor for A/B runs.
-  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.D * 4 < (int64_t(1) << 32) && getenv("MGX_SPMM_V1") == nullptr;
+  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) && getenv("MGX_SPMM_V1") == nullptr;
   static const double env_factor = getenv("MGX_SPLIT_FACTOR") ? atof(getenv("MGX_SPLIT_FACTOR")) : -1.0;
   const double split_factor = env_factor >= 0.0 ? env_factor : (lean ? 0.0 : 2.0);
   const bool split = (NB == 1) || (avg_deg >= split_factor * NB);
@@ -732,7 +734,7 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
   // MODE_MUL_EDGE needs every lane's VEC features inside one head: F % VEC == 0.
   const int vec_ok = (MODE == MODE_MUL_EDGE) ? a.F : a.D;
   // odd widths (41 classes): 16-byte gathers with a ragged last lane, lean int32 kernel only, one head
-  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.D * 4 < (int64_t(1) << 32) && getenv("MGX_SPMM_V1") == nullptr;
+  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) && getenv("MGX_SPMM_V1") == nullptr;
   if (lean && MODE != MODE_COPY_RHS && a.D % 4 != 0 && a.D > 4 && (a.D <= 256 || MODE == MODE_COPY_LHS) && a.H == 1 && getenv("MGX_SPMM_NO_RAGGED") == nullptr &&
       (uintptr_t)a.src % 4 == 0) {
     SpmmFastArgs<Idx> b = a;
@@ -749,7 +751,8 @@ template <typename Idx>
 static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* partial_ws, int accumulate, int32_t op, int32_t reduce, const float* U, const float* E,
                          int64_t u_len, int64_t e_len, int64_t out_len, const int64_t* u_off,
                          const int64_t* e_off, const float* src_scale, const float* dst_scale, float* out,
-                         void* arg_u, void* arg_e, hipStream_t s, const uint32_t* src_bits = nullptr) {
+                         void* arg_u, void* arg_e, hipStream_t s, const uint32_t* src_bits = nullptr, int64_t u_stride = 0,
+                         int64_t out_stride = 0) {
   const int64_t n_rows = csr->num_rows;
   if (n_rows == 0 || out_len == 0) return MGX_OK;
   const int64_t nblocks = round_up((n_rows + kRowsPerBlock - 1) / kRowsPerBlock, kXcds);
@@ -774,6 +777,8 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     a.mean = reduce == MGX_REDUCE_MEAN;
     a.accum = accumulate;
     a.ragged = 0;
+    a.lds = u_stride ? (int)u_stride : (int)out_len;
+    a.ldo = out_stride ? (int)out_stride : (int)out_len;
     a.item_row = nullptr; a.item_beg = nullptr; a.item_end = nullptr; a.partial = nullptr; a.n_items = n_rows;
     a.plan = plan;
     if (plan) {
@@ -785,13 +790,20 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
       if (plan && plan->num_hubs > 0) {
         hipLaunchKernelGGL((spmm_hub_fixup_kernel<Idx>), dim3((unsigned)((plan->num_hubs + kWavesPerBlock - 1) / kWavesPerBlock)),
                            dim3(kBlock), 0, s, a.indptr, plan->hub_row, plan->hub_slot_ptr, plan->num_hubs,
-                           (const float*)partial_ws, dst_scale, out, a.D, a.mean, a.accum);
+                           (const float*)partial_ws, dst_scale, out, a.D, a.mean, a.accum, a.ldo);
         MGX_CHECK_LAUNCH();
       }
       return MGX_OK;
     };
     if (op == MGX_OP_COPY_LHS && no_bcast && u_len == out_len) {
       a.src = U; a.src_rows = csr->num_cols;
+      if (a.lds != a.D || a.ldo != a.D) {  // strided rows: the lean row-per-wave kernel with 16-byte lanes only
+        const bool ok = sizeof(Idx) == 4 && a.D % 4 == 0 && a.lds % 4 == 0 && a.ldo % 4 == 0 && a.lds >= a.D && a.ldo >= a.D &&
+                        (uintptr_t)U % 16 == 0 && (uintptr_t)out % 16 == 0 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) &&
+                        getenv("MGX_SPMM_V1") == nullptr && !src_bits;
+        if (!ok) MGX_UNSUPPORTED("mgx_spmm_copy_u_strided: needs int32 ids, D and both strides multiples of 4, 16-byte aligned "
+                                 "pointers and a gathered matrix under 4 GiB");
+      }
       launch_fast<Idx, MODE_COPY_LHS>(a, csr->nnz, s);
       MGX_CHECK_LAUNCH();
       return fixup();
@@ -818,7 +830,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
       if (plan && plan->num_hubs > 0) {
         hipLaunchKernelGGL((spmm_hub_fixup_kernel<Idx>), dim3((unsigned)((plan->num_hubs + kWavesPerBlock - 1) / kWavesPerBlock)),
                            dim3(kBlock), 0, s, a.indptr, plan->hub_row, plan->hub_slot_ptr, plan->num_hubs,
-                           (const float*)partial_ws, dst_scale, out, a.D, a.mean, 1);
+                           (const float*)partial_ws, dst_scale, out, a.D, a.mean, 1, a.ldo);
         MGX_CHECK_LAUNCH();
       }
       return MGX_OK;
@@ -918,6 +930,25 @@ extern "C" int32_t mgx_spmm_copy_u_masked(const mgx_csr* csr, const mgx_spmm_pla
   MGX_CHECK_ARG(out != nullptr || csr->num_rows == 0 || D == 0, "mgx_spmm_copy_u_masked: out is NULL");
   return spmm_impl<int32_t>(csr, plan, partial_ws, (flags & MGX_SPMM_ACCUMULATE) ? 1 : 0, MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0, D,
                             nullptr, nullptr, nullptr, dst_scale, out, nullptr, nullptr, (hipStream_t)stream, src_bits);
+}
+
+extern "C" int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t reduce, const float* ufeat,
+                                           int64_t D, int64_t u_stride, const float* dst_scale, float* out, int64_t out_stride,
+                                           float* partial_ws, int32_t flags, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(csr != nullptr, "mgx_spmm_copy_u_strided: csr is NULL");
+  MGX_CHECK_ARG(csr->num_rows >= 0 && csr->nnz >= 0, "mgx_spmm_copy_u_strided: negative sizes");
+  MGX_CHECK_ARG(csr->num_rows == 0 || csr->indptr != nullptr, "mgx_spmm_copy_u_strided: indptr is NULL");
+  MGX_CHECK_ARG(csr->nnz == 0 || csr->indices != nullptr, "mgx_spmm_copy_u_strided: indices is NULL");
+  MGX_CHECK_ARG(reduce == MGX_REDUCE_SUM || reduce == MGX_REDUCE_MEAN, "mgx_spmm_copy_u_strided: SUM or MEAN only, got %d", reduce);
+  MGX_CHECK_ARG(D >= 0 && u_stride >= D && out_stride >= D, "mgx_spmm_copy_u_strided: strides must be >= D");
+  MGX_CHECK_ARG((ufeat != nullptr || csr->num_cols == 0) && (out != nullptr || csr->num_rows == 0 || D == 0),
+                "mgx_spmm_copy_u_strided: ufeat / out is NULL");
+  if (csr->idx_bits != 32) MGX_UNSUPPORTED("mgx_spmm_copy_u_strided: int32 graphs only");
+  return spmm_impl<int32_t>(csr, plan, partial_ws, (flags & MGX_SPMM_ACCUMULATE) ? 1 : 0, MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0,
+                            D, nullptr, nullptr, nullptr, dst_scale, out, nullptr, nullptr, (hipStream_t)stream, nullptr, u_stride,
+                            out_stride);
 }
 
 extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t op, int32_t reduce,

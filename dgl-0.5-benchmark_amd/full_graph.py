@@ -56,11 +56,12 @@ class SAGEConv(nn.Module):
         nn.init.xavier_uniform_(self.fc_self.weight, gain=gain)
         nn.init.xavier_uniform_(self.fc_neigh.weight, gain=gain)
 
-    def forward(self, graph, feat):
+    def forward(self, graph, feat, cat=None):
+        """`cat`: an ops.CatBuffer whose left half is (or will receive) `feat`; the layer then runs as ONE GEMM on [feat | neigh]."""
         if not self.plain and not isinstance(feat, tuple) and self.fc_self.bias is None:
-            # the whole layer as one autograd node (ops.SageMeanLayerFn): same kernels, the two gradients of `feat` meet inside
-            # the reversed aggregation instead of in a separate add pass
-            y = ops.sage_mean_layer(graph, feat, self.fc_self.weight, self.fc_neigh.weight, self.fc_neigh.bias)
+            # the whole layer as one autograd node (ops.SageMeanLayerFn / SageMeanCatFn): same aggregation kernel, the two
+            # gradients of `feat` meet inside the reversed aggregation instead of in a separate add pass
+            y = ops.sage_mean_layer(graph, feat, self.fc_self.weight, self.fc_neigh.weight, self.fc_neigh.bias, cat=cat)
             if y is not None:
                 return y
         graph = graph.local_var()
@@ -82,6 +83,7 @@ class GraphSAGE(nn.Module):
         super(GraphSAGE, self).__init__()
         self.plain = plain
         self.rows_are_distinct = False  # set by a caller whose `rows` is an index without duplicates (nonzero of a mask)
+        self._input_cat = None          # (key, ops.CatBuffer) of the first layer: [input features | their aggregation]
         self.layers = nn.ModuleList()
         self.bns = nn.ModuleList()
         dims = [in_feats] + [hidden_feats] * (num_layers - 1) + [out_feats]
@@ -102,15 +104,29 @@ class GraphSAGE(nn.Module):
         """`rows`: return the log-probabilities of these nodes only.  log_softmax is row-wise, so model(g, x, rows) ==
         model(g, x)[rows] (main_dgl_product_sage.py:105: `model(g, feats)[train_idx]`) without normalising -- forward and
         backward -- the 92 % of the rows the loss never reads."""
+        # default model: every layer's input lives in the left half of an [N, 2K] buffer whose right half receives the
+        # aggregation, so a layer is ONE GEMM (ops.CatBuffer).  The input features are copied there once (same tensor,
+        # unmodified -> kept); hidden activations are written there by relu_dropout directly.
+        cat = None
+        if not self.plain:
+            key = (id(g), x.shape[0], x.shape[1])
+            if self._input_cat is None or self._input_cat[0] != key:
+                c = ops.cat_buffer_for(g, x, x.shape[1])
+                self._input_cat = (key, c) if c is not None else None
+            cat = None if self._input_cat is None or not torch.is_grad_enabled() else self._input_cat[1]
         for i, layer in enumerate(self.layers[:-1]):
-            x = layer(g, x)
+            x = layer(g, x, cat=cat) if not self.plain else layer(g, x)
             if len(self.bns):
                 x = self.bns[i](x)
             if self.plain:
                 x = self.dropout(F.relu(x))
             else:
-                x = ops.relu_dropout(x, self.dropout.p, self.training)  # F.relu + dropout, one pass each way on the device
-        x = self.layers[-1](g, x)
+                cat = ops.cat_buffer_for(g, x, x.shape[1]) if self.training else None
+                # F.relu + dropout, one pass each way on the device, written into the next layer's left half
+                x = ops.relu_dropout(x, self.dropout.p, self.training, out=None if cat is None else cat.left)
+                if cat is not None and not cat.holds(x):
+                    cat = None
+        x = self.layers[-1](g, x, cat=cat) if not self.plain else self.layers[-1](g, x)
         if rows is not None:
             x = ops.select_distinct_rows(x, rows) if self.rows_are_distinct else x[rows]
         return x.log_softmax(dim=-1)

@@ -48,6 +48,7 @@ SIGNATURES = {
                             _fp, _i32, _vp]),
     "mgx_row_nonzero_bits": (_i32, [_i64, _i64, _fp, _vp, _vp]),
     "mgx_spmm_copy_u_masked": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _vp, _fp, _fp, _fp, _i32, _vp]),
+    "mgx_spmm_copy_u_strided": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _i64, _fp, _fp, _i64, _fp, _i32, _vp]),
     "mgx_sddmm_coo": (_i32, [_i64, _i64, _i64, _vp, _vp, _i32, _i32, _fp, _fp, _i32, _i32, _i64, _i64, _i64, _i64,
                              _vp, _vp, _fp, _vp]),
     "mgx_sddmm_csr": (_i32, [_csr_p, _vp, _i32, _fp, _fp, _i32, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _fp, _vp]),
@@ -66,6 +67,8 @@ SIGNATURES = {
     "mgx_segment_reduce": (_i32, [_i64, _vp, _i64, _i32, _fp, _fp, _vp, _vp]),
     "mgx_relu_dropout_fwd": (_i32, [_i64, _fp, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _fp, _vp, _vp]),
     "mgx_relu_dropout_bwd": (_i32, [_i64, _fp, _vp, ctypes.c_float, _fp, _vp]),
+    "mgx_relu_dropout_fwd_strided": (_i32, [_i64, _i64, _fp, _i64, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _fp, _i64, _vp, _vp]),
+    "mgx_relu_dropout_bwd_strided": (_i32, [_i64, _i64, _fp, _i64, _vp, ctypes.c_float, _fp, _i64, _vp]),
     "mgx_column_pair_sums": (_i32, [_i64, _i64, _i32, _fp, _fp, _fp, _fp, _vp, _vp]),
     "mgx_column_affine": (_i32, [_i64, _i64, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     "mgx_xty_workspace": (_i64, [_i64, _i64]),

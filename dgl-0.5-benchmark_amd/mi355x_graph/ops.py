@@ -429,12 +429,17 @@ class ReluDropout(torch.autograd.Function):
     _calls = 0  # advances the counter-based generator: a new mask per call, reproducible after torch.manual_seed
 
     @staticmethod
-    def forward(ctx, x, p):
-        x = x.contiguous()
+    def forward(ctx, x, p, into=None):
+        # `into` wraps the destination view in a plain object: handed over as a Tensor argument it would be an autograd INPUT
+        # modified in place; created here it is simply this node's output (a view of a buffer autograd does not track)
+        out = None if into is None else into.t
+        be = sparse.backend_for(x)
+        if out is None or not be._row_strided(x):
+            x = x.contiguous()
         seed = torch.initial_seed() & (2 ** 64 - 1)
         offset = (ReluDropout._calls * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
         ReluDropout._calls += 1
-        y, mask = sparse.backend_for(x).relu_dropout_fwd(x, float(p), seed, offset)
+        y, mask = be.relu_dropout_fwd(x, float(p), seed, offset, out=out)
         ctx.save_for_backward(mask)
         ctx.p = float(p)
         return y
@@ -443,16 +448,30 @@ class ReluDropout(torch.autograd.Function):
     @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy):
         (mask,) = ctx.saved_tensors
-        return sparse.backend_for(dy).relu_dropout_bwd(dy.contiguous(), mask, ctx.p), None
+        be = sparse.backend_for(dy)
+        if not dy.is_contiguous() and not be._row_strided(dy):
+            dy = dy.contiguous()
+        return be.relu_dropout_bwd(dy, mask, ctx.p), None, None
 
 
-def relu_dropout(x, p=0.5, training=True):
+def relu_dropout(x, p=0.5, training=True, out=None):
     """dropout(relu(x), p) in one pass each way (float32 HIP tensors with numel % 4 == 0; anything else, evaluation mode
-    and HIP-graph capture -- whose replays must draw new masks -- take the two PyTorch ops)."""
+    and HIP-graph capture -- whose replays must draw new masks -- take the two PyTorch ops).  `out`: a [rows, cols] view with
+    unit column stride to write the result into (a column block of a wider matrix); ignored on the PyTorch path."""
     if (not training or p <= 0.0 or p >= 1.0 or x.dtype != torch.float32 or x.device.type != "cuda" or x.numel() % 4
             or x.device.type not in sparse._BACKENDS or torch.cuda.is_current_stream_capturing()):
         return torch.nn.functional.dropout(torch.relu(x), p, training)
-    return ReluDropout.apply(x, p)
+    if out is not None and (x.dim() != 2 or x.shape[1] % 4 or out.shape != x.shape or out.stride(1) != 1 or out.stride(0) % 4
+                            or out.requires_grad):
+        out = None
+    return ReluDropout.apply(x, p, None if out is None else _Into(out))
+
+
+class _Into(object):
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
 
 
 class BatchNormFn(torch.autograd.Function):
@@ -604,7 +623,80 @@ class SageMeanLayerFn(torch.autograd.Function):
         return None, dh, dws, dwn, db
 
 
-def sage_mean_layer(g, h, w_self, w_neigh, bias=None):
+class CatBuffer(object):
+    """An [N, 2 K] matrix whose left half holds a layer's input h and whose right half receives mean_{u->v} h[u]: the operand of
+    the ONE GEMM `[h | neigh] [W_self | W_neigh]^T` that replaces SAGEConv's two.  `generation` counts the forward passes
+    that wrote the right half; a backward pass checks that no later forward overwrote what it saved."""
+    __slots__ = ("buf", "K", "generation", "static_key")
+
+    def __init__(self, n, K, device):
+        self.buf = torch.empty((n, 2 * K), dtype=torch.float32, device=device)
+        self.K = K
+        self.generation = 0
+        self.static_key = None
+
+    @property
+    def left(self):
+        return self.buf[:, :self.K]
+
+    @property
+    def right(self):
+        return self.buf[:, self.K:]
+
+    def holds(self, h):
+        return (h.dim() == 2 and h.shape == (self.buf.shape[0], self.K) and h.data_ptr() == self.buf.data_ptr()
+                and h.stride(0) == self.buf.stride(0) and h.stride(1) == 1)
+
+
+class SageMeanCatFn(torch.autograd.Function):
+    """SageMeanLayerFn over a CatBuffer: the aggregation reads the left half and writes the right half in place
+    (mgx_spmm_copy_u_strided), forward and weight gradients are ONE GEMM / ONE mgx_xty against the stacked weights, and the
+    backward aggregation reads the right half of d[h | neigh] and accumulates into its left half."""
+
+    @staticmethod
+    def forward(ctx, gidx, cat, h, w_self, w_neigh, bias):
+        csc = gidx.csc()
+        be = sparse.backend_for(h)
+        if not cat.holds(h):
+            # a layer input that lives elsewhere -- the model's input features -- is copied into the left half; when it is the
+            # same tensor, unmodified (data pointer + version counter), as in the previous pass the copy is skipped
+            key = (h.data_ptr(), h._version, tuple(h.shape), tuple(h.stride()))
+            if cat.static_key != key or h.requires_grad or os.environ.get("MGX_SAGE_STATIC_CAT", "1") != "1":
+                cat.left.copy_(h)
+                cat.static_key = None if h.requires_grad else key
+        cat.generation += 1
+        be.spmm_copy_u_strided(csc, "mean", cat.left, cat.right)
+        ctx.gidx, ctx.cat, ctx.generation = gidx, cat, cat.generation
+        ctx.save_for_backward(w_self, w_neigh)
+        return torch.nn.functional.linear(cat.buf, torch.cat([w_self, w_neigh], dim=1), bias)
+
+    @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
+    def backward(ctx, dy):
+        w_self, w_neigh = ctx.saved_tensors
+        cat = ctx.cat
+        if cat.generation != ctx.generation:
+            raise DGLError("SAGEConv: a later forward pass overwrote the [h | neigh] buffer this backward pass needs "
+                           "(two forwards before one backward); set MGX_SAGE_CAT=0")
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        be = sparse.backend_for(dy)
+        K = cat.K
+        dh = None
+        if need[2]:
+            dcat = dy @ torch.cat([w_self, w_neigh], dim=1)       # [N, 2K] = d[h | neigh]
+            dcat[:, K:].mul_(ctx.gidx.csc().inv_degrees().view(-1, 1))  # d(sum / deg): one streaming pass, not a per-edge factor
+            be.spmm_copy_u_strided(ctx.gidx.csr(), "sum", dcat[:, K:], dcat[:, :K], accumulate=True)
+            dh = dcat[:, :K]
+        dws = dwn = None
+        if need[3] or need[4]:
+            dw = _weight_grad(dy, cat.buf)                        # [out, 2K]
+            dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
+        db = be.column_sum(dy) if need[5] else None
+        return None, None, dh, dws, dwn, db
+
+
+def sage_mean_layer(g, h, w_self, w_neigh, bias=None, cat=None):
     """Fused form of SAGEConv on a homogeneous square DGLGraph with 2-D float32 HIP features; None when the fused node does
     not apply (the caller then composes update_all + linear_sum)."""
     if (type(g) is not DGLGraph or g.is_block or h.dim() != 2 or h.dtype != torch.float32
@@ -613,7 +705,26 @@ def sage_mean_layer(g, h, w_self, w_neigh, bias=None):
             or (bias is not None and w_self.shape[0] > sparse.backend_for(h).COLUMN_SUM_MAX)
             or _torch_ops() is not None or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):
         return None
+    if cat is not None and _cat_eligible(g, h, cat):
+        return SageMeanCatFn.apply(g._index, cat, h, w_self, w_neigh, bias)
     return SageMeanLayerFn.apply(g._index, h, w_self, w_neigh, bias)
+
+
+def _cat_eligible(g, h, cat):
+    K = h.shape[1]
+    idx = g._index
+    return (os.environ.get("MGX_SAGE_CAT", "1") == "1" and cat.K == K and K % 4 == 0 and cat.buf.shape[0] == h.shape[0]
+            and idx.csc().indptr.dtype == torch.int32 and h.shape[0] * 2 * K * 4 < (1 << 32))
+
+
+def cat_buffer_for(g, x, K):
+    """A CatBuffer for a layer whose input has K columns, or None when the one-GEMM form does not apply to this graph / width."""
+    if (type(g) is not DGLGraph or g.is_block or x.dtype != torch.float32 or x.device.type not in sparse._BACKENDS
+            or not torch.is_grad_enabled() or K % 4 or g.number_of_src_nodes() != g.number_of_dst_nodes()
+            or g.number_of_src_nodes() * 2 * K * 4 >= (1 << 32) or g.idtype != torch.int32
+            or os.environ.get("MGX_SAGE_CAT", "1") != "1" or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):
+        return None
+    return CatBuffer(g.number_of_src_nodes(), K, x.device)
 
 
 def linear(x, weight, bias=None):

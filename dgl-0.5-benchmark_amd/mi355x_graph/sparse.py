@@ -302,6 +302,32 @@ class HipBackend(object):
                 PROFILE.append(rec)
         return out
 
+    def spmm_copy_u_strided(self, csr, reduce, U2d, out2d, accumulate=False, dst_scale=None):
+        """copy_u / sum|mean reading rows of U2d [num_cols, D] and writing rows of out2d [num_rows, D] IN PLACE, both row-strided
+        views (stride(1) == 1) -- column blocks of wider matrices (mgx_spmm_copy_u_strided)."""
+        dev = self._check_dev(csr.indptr, U2d, out2d, dst_scale)
+        D = int(U2d.shape[1])
+        if (U2d.dim() != 2 or out2d.dim() != 2 or U2d.stride(1) != 1 or out2d.stride(1) != 1 or out2d.shape[1] != D
+                or U2d.shape[0] != csr.num_cols or out2d.shape[0] != csr.num_rows):
+            raise DGLError("spmm_copy_u_strided: expected row-strided [num_cols, D] -> [num_rows, D] views")
+        plan = csr.plan()
+        partial = torch.empty((plan.num_slots, D), dtype=torch.float32, device=dev) if plan is not None and plan.num_slots else None
+        with torch.cuda.device(dev):
+            rec = None
+            if PROFILE is not None:
+                rec = {"op": "copy_lhs", "reduce": reduce, "out_len": D, "n_rows": csr.num_rows, "n_cols": csr.num_cols,
+                       "nnz": csr.nnz, "accumulate": bool(accumulate), "strides": (int(U2d.stride(0)), int(out2d.stride(0))),
+                       "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
+                rec["start"].record(torch.cuda.current_stream(dev))
+            _lib.check(_lib.lib().mgx_spmm_copy_u_strided(
+                ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,
+                int(U2d.stride(0)), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial), 1 if accumulate else 0,
+                _stream(dev)))
+            if rec is not None:
+                rec["end"].record(torch.cuda.current_stream(dev))
+                PROFILE.append(rec)
+        return out2d
+
     def sddmm(self, graph_index, op, L, R, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size, l_off, r_off):
         """graph_index supplies either COO (edge-id order) or the in-CSR."""
         nnz = graph_index.num_edges()
@@ -460,20 +486,41 @@ class HipBackend(object):
             _lib.check(_lib.lib().mgx_segment_reduce(n, _ptr(offsets), x2d.shape[1], REDUCE[reduce], _ptr(x2d), _ptr(out), _ptr(arg), _stream(dev)))
         return out, arg
 
-    def relu_dropout_fwd(self, x, p, seed, offset):
-        dev = self._check_dev(x)
-        y = torch.empty_like(x)
+    @staticmethod
+    def _row_strided(t):
+        return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.stride(0) % 4 == 0 and t.shape[1] % 4 == 0
+
+    def relu_dropout_fwd(self, x, p, seed, offset, out=None):
+        """`out`: a row-strided [rows, cols] view to write into (x then 2-D, possibly row-strided itself)."""
+        dev = self._check_dev(x, out)
         mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=dev)
+        if out is None and x.is_contiguous():
+            y = torch.empty_like(x)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().mgx_relu_dropout_fwd(x.numel(), _ptr(x), ctypes.c_float(p), ctypes.c_uint64(seed),
+                                                           ctypes.c_uint64(offset), _ptr(y), _ptr(mask), _stream(dev)))
+            return y, mask
+        y = out if out is not None else torch.empty(x.shape, dtype=torch.float32, device=dev)
+        if not (self._row_strided(x) and self._row_strided(y) and x.shape == y.shape):
+            raise DGLError("relu_dropout_fwd: strided operands must be [rows, cols] views with unit column stride, cols % 4 == 0")
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_relu_dropout_fwd(x.numel(), _ptr(x), ctypes.c_float(p), ctypes.c_uint64(seed),
-                                                       ctypes.c_uint64(offset), _ptr(y), _ptr(mask), _stream(dev)))
+            _lib.check(_lib.lib().mgx_relu_dropout_fwd_strided(x.shape[0], x.shape[1], _ptr(x), x.stride(0), ctypes.c_float(p),
+                                                                ctypes.c_uint64(seed), ctypes.c_uint64(offset), _ptr(y), y.stride(0),
+                                                                _ptr(mask), _stream(dev)))
         return y, mask
 
     def relu_dropout_bwd(self, dy, mask, p):
+        """dy: contiguous, or a row-strided [rows, cols] view (the gradient's column block); dx is dense."""
         dev = self._check_dev(dy, mask)
-        dx = torch.empty_like(dy)
+        dx = torch.empty(dy.shape, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_relu_dropout_bwd(dy.numel(), _ptr(dy), _ptr(mask), ctypes.c_float(p), _ptr(dx), _stream(dev)))
+            if dy.is_contiguous():
+                _lib.check(_lib.lib().mgx_relu_dropout_bwd(dy.numel(), _ptr(dy), _ptr(mask), ctypes.c_float(p), _ptr(dx), _stream(dev)))
+            else:
+                if not self._row_strided(dy):
+                    raise DGLError("relu_dropout_bwd: a non-contiguous gradient must be a [rows, cols] view with unit column stride")
+                _lib.check(_lib.lib().mgx_relu_dropout_bwd_strided(dy.shape[0], dy.shape[1], _ptr(dy), dy.stride(0), _ptr(mask),
+                                                                    ctypes.c_float(p), _ptr(dx), dx.stride(0), _stream(dev)))
         return dx
 
     def column_pair_sums(self, a2d, b2d=None, shifted=False):

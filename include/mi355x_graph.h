@@ -164,6 +164,17 @@ int32_t mgx_spmm_copy_u_masked(const mgx_csr* csr, const mgx_spmm_plan* plan /* 
                                const float* ufeat, int64_t D, const uint32_t* src_bits, const float* dst_scale /* may be NULL */,
                                float* out, float* partial_ws, int32_t flags, void* stream);
 
+/* copy_u / sum | mean with STRIDED rows (round 2): ufeat rows are u_stride floats apart, out rows out_stride floats apart
+ * (both >= D).  Lets the aggregation read and write column blocks of wider matrices in place -- SAGEConv
+ * (main_dgl_product_sage.py:61-64) feeds `fc_self(h) + fc_neigh(neigh)`; with h and neigh as the two halves of one [N, 2 D]
+ * matrix that is ONE GEMM against the stacked weights instead of two, and the backward aggregation accumulates straight
+ * into the h-half of the gradient.  32-bit indices, D and both strides multiples of 4, 16-byte aligned pointers, gathered
+ * matrix below 4 GiB; otherwise MGX_ERR_UNSUPPORTED (make the operands dense and call mgx_spmm_csr).  plan / partial_ws / flags
+ * as for mgx_spmm_csr. */
+int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int32_t reduce,
+                                const float* ufeat, int64_t D, int64_t u_stride, const float* dst_scale /* may be NULL */,
+                                float* out, int64_t out_stride, float* partial_ws, int32_t flags, void* stream);
+
 /* ------------------------------------------------------------------ g-SDDMM
  * Replaces _CAPI_DGLKernelSDDMM as reached by dgl.ops.gsddmm (kernel/dgl-new.py:39),
  * apply_edges(fn.u_add_v) inside GATConv (main_dgl_reddit_gat.py:10) and fn.u_dot_v
@@ -293,6 +304,12 @@ int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int64_t lda, co
 int32_t mgx_relu_dropout_fwd(int64_t n, const float* x, float p, uint64_t seed, uint64_t offset, float* y, uint8_t* mask,
                              void* stream);
 int32_t mgx_relu_dropout_bwd(int64_t n, const float* dy, const uint8_t* mask, float p, float* dx, void* stream);
+/* Row-strided forms (round 2): [rows, cols] views whose rows are *_stride floats apart (cols, strides % 4 == 0); the mask
+ * stays dense and equals the dense call's for the same (seed, offset). */
+int32_t mgx_relu_dropout_fwd_strided(int64_t rows, int64_t cols, const float* x, int64_t x_stride, float p, uint64_t seed,
+                                     uint64_t offset, float* y, int64_t y_stride, uint8_t* mask, void* stream);
+int32_t mgx_relu_dropout_bwd_strided(int64_t rows, int64_t cols, const float* dy, int64_t dy_stride, const uint8_t* mask, float p,
+                                     float* dx, int64_t dx_stride, void* stream);
 
 /* ------------------------------------------------------------------ formats (integer, bit-exact)
  * Replace the lazy COO->CSR/CSC construction behind g.formats(...)/first kernel call

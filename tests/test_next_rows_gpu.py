@@ -261,3 +261,66 @@ def test_log_softmax_on_selected_rows_is_the_same_model_output():
     rows = torch.arange(0, n, 7, device=DEV)
     with torch.no_grad():
         assert torch.equal(m(g, x)[rows], m(g, x, rows=rows))
+
+
+def test_one_gemm_layers_over_cat_buffers_match_the_two_gemm_form(monkeypatch):
+    """Default GraphSAGE with dropout: layers as ONE GEMM on [h | neigh] (ops.CatBuffer: strided aggregation in place,
+    relu_dropout writing the next layer's left half, strided backward) against MGX_SAGE_CAT=0 (two GEMMs per layer) with
+    the same dropout masks: same loss, same parameter gradients, over two training steps (the input-feature copy is reused)."""
+    sys.path.insert(0, PKG)
+    import full_graph
+    n = 70000
+    src, dst = random_graph(n, n, 14 * n, seed=11, skew=True)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().formats(["csr", "csc"]).to(DEV)
+    torch.manual_seed(0)
+    x = torch.randn(n, 100, device=DEV)
+    y = torch.randint(0, 47, (n,), device=DEV)
+    idx = torch.arange(0, n, 9, device=DEV)
+    runs = []
+    for cat in ("1", "0"):
+        monkeypatch.setenv("MGX_SAGE_CAT", cat)
+        torch.manual_seed(77)
+        ops.ReluDropout._calls = 0
+        m = full_graph.GraphSAGE(100, 64, 47, 3, 0.5).to(DEV)
+        m.rows_are_distinct = True
+        m.train()
+        out = []
+        for step in range(2):
+            m.zero_grad()
+            loss = ops.nll_sum(m(g, x, rows=idx), y[idx]) / idx.shape[0]
+            loss.backward()
+            out.append((float(loss), [p.grad.clone() for p in m.parameters()]))
+        runs.append(out)
+        assert (m._input_cat is not None) == (cat == "1")
+    for (l1, g1), (l2, g2) in zip(*runs):
+        assert abs(l1 - l2) < 1e-5 * abs(l2)
+        for a, b in zip(g1, g2):
+            assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-7
+
+
+def test_strided_copy_u_and_relu_dropout_match_the_dense_calls(oracle):
+    n, D = 3000, 64
+    src, dst = random_graph(n, n, 40000, seed=2, skew=True)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().formats(["csr", "csc"]).to(DEV)
+    from mi355x_graph import sparse
+    csc = g._index.csc()
+    be = sparse.backend_for(csc.indptr)
+    torch.manual_seed(5)
+    wide = torch.randn(n, 2 * D + 8, device=DEV)
+    ref, _, _ = sparse.gspmm_raw(csc, "copy_lhs", "mean", wide[:, :D].contiguous(), None)
+    be.spmm_copy_u_strided(csc, "mean", wide[:, :D], wide[:, D:2 * D])
+    assert torch.equal(wide[:, D:2 * D], ref)                      # same kernel, same order of summation
+    acc0 = wide[:, D:2 * D].clone()
+    be.spmm_copy_u_strided(csc, "sum", wide[:, :D], wide[:, D:2 * D], accumulate=True)
+    ref2, _, _ = sparse.gspmm_raw(csc, "copy_lhs", "sum", wide[:, :D].contiguous(), None, accumulate_into=acc0.clone())
+    assert torch.equal(wide[:, D:2 * D], ref2)
+    with pytest.raises(mg.DGLError):                                # 6 columns: not a multiple of 4
+        be.spmm_copy_u_strided(csc, "sum", wide[:, :6], wide[:, 8:14])
+    # relu_dropout into / out of column blocks: same mask and values as the dense call
+    xs = torch.randn(n, 2 * D, device=DEV)
+    y_dense, m_dense = be.relu_dropout_fwd(xs[:, :D].contiguous(), 0.5, 123, 7)
+    buf = torch.zeros(n, 3 * D, device=DEV)
+    y_str, m_str = be.relu_dropout_fwd(xs[:, :D], 0.5, 123, 7, out=buf[:, D:2 * D])
+    assert torch.equal(m_dense, m_str) and torch.equal(y_dense, buf[:, D:2 * D]) and float(buf[:, :D].abs().max()) == 0.0
+    dy = torch.randn(n, 2 * D, device=DEV)
+    assert torch.equal(be.relu_dropout_bwd(dy[:, D:], m_dense, 0.5), be.relu_dropout_bwd(dy[:, D:].contiguous(), m_dense, 0.5))
