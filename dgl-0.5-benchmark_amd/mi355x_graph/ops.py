@@ -523,7 +523,9 @@ def _weight_grad(dy2, x2):
     be = sparse.backend_for(dy2)
     if (x2.shape[0] >= be.XTY_MIN_ROWS and dy2.shape[1] <= be.XTY_MAX[0] and x2.shape[1] <= be.XTY_MAX[1]
             and os.environ.get("MGX_LINEAR_XTY", "1") == "1"):
-        return be.xty(dy2.contiguous(), x2.contiguous())  # millions of rows, <= 64 x 128 outputs: streamed once
+        # millions of rows, <= 64 x 128 outputs: streamed once; mgx_xty takes row strides, so a column slice (the [:, :D] view of
+        # a line-padded aggregation) is read in place
+        return be.xty(dy2 if dy2.stride(1) == 1 else dy2.contiguous(), x2 if x2.stride(1) == 1 else x2.contiguous())
     return dy2.t() @ x2
 
 

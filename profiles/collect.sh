@@ -22,7 +22,8 @@ python3 $R/profiles/summarize.py $TAG $O/${TAG}_bench_trace $O/${TAG}_bench_fetc
 python3 $R/profiles/summarize.py ${TAG}_gat_reddit $O/${TAG}_gat_trace >> $O/${TAG}_summarize.log 2>&1
 python3 $R/profiles/summarize.py ${TAG}_gat8_redditsmall $O/${TAG}_gat8_trace >> $O/${TAG}_summarize.log 2>&1
 python3 $R/profiles/summarize.py ${TAG}_molhiv $O/${TAG}_molhiv_trace >> $O/${TAG}_summarize.log 2>&1
-cp $R/profiles/${TAG}_*.txt $O/ 2>/dev/null
+# only what summarize.py wrote into profiles/ on this box (a blanket copy would overwrite the files generated straight into $O)
+cp $R/profiles/${TAG}_*kernel_stats.txt $R/profiles/${TAG}_pmc_summary.txt $O/ 2>/dev/null
 (python3 $R/profiles/gat_roofline.py $O/${TAG}_gat8_trace 232965 11839883 8 16; python3 $R/profiles/gat_roofline.py $O/${TAG}_gat8_trace 232965 11839883 1 41) > $O/${TAG}_gat8_roofline.txt 2>&1
 python3 $R/dgl-0.5-benchmark_amd/generate_result.py --out $O/${TAG}_generate_result.csv > $O/${TAG}_generate_result.txt 2>&1
 python3 $R/bench.py --steps 10 --warmup 3 > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench_line.err
