@@ -702,7 +702,7 @@ def sage_mean_layer(g, h, w_self, w_neigh, bias=None, cat=None):
     """Fused form of SAGEConv on a homogeneous square DGLGraph with 2-D float32 HIP features; None when the fused node does
     not apply (the caller then composes update_all + linear_sum)."""
     if (type(g) is not DGLGraph or g.is_block or h.dim() != 2 or h.dtype != torch.float32
-            or h.device.type not in sparse._BACKENDS or not torch.is_grad_enabled()
+            or not h.is_cuda or h.device.type not in sparse._BACKENDS or not torch.is_grad_enabled()
             or g.number_of_src_nodes() != g.number_of_dst_nodes() or h.shape[0] != g.number_of_src_nodes()
             or (bias is not None and w_self.shape[0] > sparse.backend_for(h).COLUMN_SUM_MAX)
             or _torch_ops() is not None or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):
@@ -721,7 +721,7 @@ def _cat_eligible(g, h, cat):
 
 def cat_buffer_for(g, x, K):
     """A CatBuffer for a layer whose input has K columns, or None when the one-GEMM form does not apply to this graph / width."""
-    if (type(g) is not DGLGraph or g.is_block or x.dtype != torch.float32 or x.device.type not in sparse._BACKENDS
+    if (type(g) is not DGLGraph or g.is_block or x.dtype != torch.float32 or not x.is_cuda or x.device.type not in sparse._BACKENDS
             or not torch.is_grad_enabled() or K % 4 or g.number_of_src_nodes() != g.number_of_dst_nodes()
             or g.number_of_src_nodes() * 2 * K * 4 >= (1 << 32) or g.idtype != torch.int32
             or os.environ.get("MGX_SAGE_CAT", "1") != "1" or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):
