@@ -66,6 +66,8 @@ struct GatArgs {
   float* out_h;         // BWD_DST: d er; BWD_SRC: d el   [rows, H]
   float* partial;       // [slots, D]
   float* partial_h;     // [slots, H] (stats: [slots, 2H])
+  int gat_ld;           // floats between consecutive rows of `gat` (D unless packed)
+  int small_ld;         // floats between consecutive nodes of the small gathered array (el: H, nstat: 4H unless packed)
 };
 
 // ---------------------------------------------------------------------------------------------- hub rows of the forward
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
   const int f = l * 4;
   const bool fact = f < D;
   const int head = fact ? l / LPH : 0;
-  const uint32_t rowbytes = (uint32_t)D * 4u;
+  const uint32_t rowbytes = (uint32_t)a.gat_ld * 4u;
   const int nvalid = RAGGED ? (D - f < 4 ? D - f : 4) : 4;   // columns this lane owns (RAGGED: the last active lane < 4)
   const bool tail = RAGGED && fact && nvalid < 4;
   const int fw = tail ? D - 4 : f;                            // first column of this lane's 16-byte window
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
     }
     return v;
   };
-  const uint32_t hbytes = (uint32_t)H * (MODE == GAT_BWD_SRC ? 16u : 4u);  // per-node stride of the small per-head array
+  const uint32_t hbytes = (uint32_t)a.small_ld * 4u;  // per-node stride of the small per-head array (el: H floats, nstat: 4H; packed: the row stride)
   const uint32_t h4 = (uint32_t)head * (MODE == GAT_BWD_SRC ? 16u : 4u);
   const char* __restrict__ gatb = reinterpret_cast<const char*>(a.gat);
   const char* __restrict__ smallb = reinterpret_cast<const char*>(MODE == GAT_BWD_SRC ? a.nstat : a.el);
@@ -428,10 +430,41 @@ static void gat_fill(GatArgs& a, const mgx_csr* csr, const mgx_spmm_plan* plan, 
   a.rpb = gat_rows_per_block();
   a.nblocks = xcd_ranges(plan, a.n_items, a.rpb, a.xcd);
   a.H = (int)H; a.F = (int)F; a.D = (int)(H * F);
+  a.gat_ld = a.D; a.small_ld = 0;  // small_ld: set by the caller (H for el, 4H for nstat, the packed stride otherwise)
   a.slope = slope; a.seed = seed;
   a.keep_scale = 1.f / (1.f - p);
   double thr = (double)p * 4294967296.0;
   a.drop_below = thr >= 4294967295.0 ? 4294967295u : (uint32_t)thr;
+}
+
+// Packed gather operand: row r = [rows[r, 0..D) | pad to a multiple of 4 | small[r, 0..S) | pad to whole 128-byte lines].
+// A narrow layer (reddit GAT: D = 16, one head) gathers a 64-byte feature row AND a 4-byte attention term per edge -- two L2
+// requests of one line each, and the kernels are bound by requests; packed, both arrive in ONE line.
+// Returns the packed row stride in floats, or 0 when packing would not save a line per edge or costs too much footprint.
+static int gat_pack_ld(int64_t D, int64_t S) {
+  const int64_t off = round_up(D, 4);
+  const int64_t ld = round_up(off + S, 32);
+  // not when the padding would more than double the bytes a node occupies in L2 (8 features + 1 term in a 128-byte row)
+  return (ld <= round_up(D, 32) && ld <= 2 * (D + S)) ? (int)ld : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void gat_pack_kernel(int64_t n, int D, int S, int ld, int off, const float* __restrict__ rows,
+                                                          const float* __restrict__ small, float* __restrict__ out) {
+  const int64_t total = n * (int64_t)ld;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t r = i / ld;
+    const int c = (int)(i - r * ld);
+    float v = 0.f;
+    if (c < D) v = rows[r * D + c];
+    else if (c >= off && c < off + S) v = small[r * S + (c - off)];
+    out[i] = v;
+  }
+}
+
+static void gat_pack(int64_t n, int D, int S, int ld, const float* rows, const float* small, float* out, hipStream_t s) {
+  int64_t b = (n * (int64_t)ld + kBlock - 1) / kBlock;
+  if (b > 256 * 64) b = 256 * 64;
+  hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)(b < 1 ? 1 : b)), dim3(kBlock), 0, s, n, D, S, ld, (int)round_up(D, 4), rows, small, out);
 }
 
 static void gat_fixup(const mgx_spmm_plan* plan, int L, const float* partial, float* out, hipStream_t s) {
@@ -447,9 +480,19 @@ extern "C" int64_t mgx_gat_fused_workspace(const mgx_spmm_plan* plan, int64_t H,
   return slots * per * (int64_t)sizeof(float);
 }
 
+extern "C" int64_t mgx_gat_fused_pack_workspace(int64_t num_src, int64_t num_dst, int64_t H, int64_t F) {
+  using namespace mgx;
+  if (getenv("MGX_GAT_NO_PACK") != nullptr) return 0;  // A/B switch
+  const int la = gat_pack_ld(H * F, H), lb = gat_pack_ld(H * F, 4 * H);
+  const int64_t rows = num_src > num_dst ? num_src : num_dst;
+  const int64_t ld = la > lb ? la : lb;
+  if (ld == 0 || rows * ld * 4 >= (int64_t(1) << 32)) return 0;
+  return rows * ld * (int64_t)sizeof(float);
+}
+
 extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, int64_t F, const float* feat,
                                      const float* el, const float* er, float negative_slope, float drop_p, uint64_t seed,
-                                     float* out, float* nstat, void* workspace, void* stream) {
+                                     float* out, float* nstat, void* workspace, void* pack_ws, void* stream) {
   using namespace mgx;
   MGX_ENTER();
   int32_t st = gat_check(csr, plan, H, F, csr ? csr->num_cols : 0, drop_p, "mgx_gat_fused_fwd");
@@ -464,6 +507,14 @@ extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* pl
   gat_fill(a, csr, plan, H, F, negative_slope, drop_p, seed);
   a.el = el; a.er = er; a.nstat_w = nstat;
   a.gat = feat; a.nstat = nstat; a.out = out;
+  a.small_ld = (int)H;
+  const int pld = pack_ws ? gat_pack_ld(H * F, H) : 0;
+  if (pld && csr->num_cols * (int64_t)pld * 4 < (int64_t(1) << 32)) {  // [feat | el] rows: one line per gathered source
+    gat_pack(csr->num_cols, a.D, (int)H, pld, feat, el, (float*)pack_ws, s);
+    MGX_CHECK_LAUNCH();
+    a.gat = (const float*)pack_ws; a.el = (const float*)pack_ws + round_up(a.D, 4);
+    a.gat_ld = pld; a.small_ld = pld;
+  }
   float* ws = (float*)workspace;  // [slots, D] partial rows, then [slots, 2H] chunk statistics
   a.partial = ws;
   a.partial_h = hubs ? ws + plan->num_slots * (int64_t)a.D : nullptr;
@@ -481,7 +532,7 @@ extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* pl
 extern "C" int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan, const mgx_csr* csr, const mgx_spmm_plan* csr_plan,
                                      int64_t H, int64_t F, const float* feat, const float* el, float negative_slope, float drop_p,
                                      uint64_t seed, const float* out, const float* d_out, float* nstat, float* d_feat, float* d_el,
-                                     float* d_er, void* workspace, void* stream) {
+                                     float* d_er, void* workspace, void* pack_ws, void* stream) {
   using namespace mgx;
   MGX_ENTER();
   int32_t st = gat_check(csc, csc_plan, H, F, csc ? csc->num_cols : 0, drop_p, "mgx_gat_fused_bwd");
@@ -502,6 +553,14 @@ extern "C" int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* cs
     GatArgs a;
     gat_fill(a, csc, csc_plan, H, F, negative_slope, drop_p, seed);
     a.gat = feat; a.el = el; a.nstat = nstat; a.nstat_w = nstat; a.rowa = d_out; a.rowb = out; a.out_h = d_er;
+    a.small_ld = (int)H;
+    const int pld = pack_ws ? gat_pack_ld(H * F, H) : 0;
+    if (pld && csc->num_cols * (int64_t)pld * 4 < (int64_t(1) << 32)) {  // [feat | el] rows, as in the forward
+      gat_pack(csc->num_cols, D, (int)H, pld, feat, el, (float*)pack_ws, s);
+      MGX_CHECK_LAUNCH();
+      a.gat = (const float*)pack_ws; a.el = (const float*)pack_ws + round_up(D, 4);
+      a.gat_ld = pld; a.small_ld = pld;
+    }
     a.partial_h = (float*)workspace;
     if (!gat_launch<GAT_BWD_DST>(a, drop_p > 0.f, s)) MGX_UNSUPPORTED("mgx_gat_fused_bwd: unsupported head layout");
     MGX_CHECK_LAUNCH();
@@ -515,6 +574,14 @@ extern "C" int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* cs
     GatArgs a;
     gat_fill(a, csr, csr_plan, H, F, negative_slope, drop_p, seed);
     a.gat = d_out; a.el = el; a.nstat = nstat; a.rowa = feat; a.out = d_feat; a.out_h = d_el;
+    a.small_ld = 4 * (int)H;
+    const int pld = pack_ws ? gat_pack_ld(H * F, 4 * H) : 0;
+    if (pld && csr->num_cols * (int64_t)pld * 4 < (int64_t(1) << 32)) {  // [d out | (er, m, 1/s, t)] rows: t was written just above
+      gat_pack(csr->num_cols, D, 4 * (int)H, pld, d_out, nstat, (float*)pack_ws, s);
+      MGX_CHECK_LAUNCH();
+      a.gat = (const float*)pack_ws; a.nstat = (const float*)pack_ws + round_up(D, 4);
+      a.gat_ld = pld; a.small_ld = pld;
+    }
     float* ws = (float*)workspace;
     a.partial = ws;
     a.partial_h = ws ? ws + (csr_plan ? csr_plan->num_slots : 0) * (int64_t)D : nullptr;

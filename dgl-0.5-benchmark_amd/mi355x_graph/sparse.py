@@ -409,11 +409,17 @@ class HipBackend(object):
         nstat = torch.empty((csc.num_rows, H, 4), dtype=torch.float32, device=dev)
         plan = csc.plan()
         ws = self._gat_ws([plan], H, F, dev)
+        pack = self._gat_pack_ws(csc, H, F, dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mgx_gat_fused_fwd(ctypes.byref(csc.c_struct()), self._plan_ptr(plan), H, F, _ptr(feat3d), _ptr(el2d),
                                                     _ptr(er2d), ctypes.c_float(slope), ctypes.c_float(p), ctypes.c_uint64(seed),
-                                                    _ptr(out), _ptr(nstat), _ptr(ws), _stream(dev)))
+                                                    _ptr(out), _ptr(nstat), _ptr(ws), _ptr(pack), _stream(dev)))
         return out, nstat
+
+    @staticmethod
+    def _gat_pack_ws(csc, H, F, dev):
+        need = _lib.lib().mgx_gat_fused_pack_workspace(csc.num_cols, csc.num_rows, H, F)
+        return torch.empty(need // 4, dtype=torch.float32, device=dev) if need else None
 
     def gat_fused_bwd(self, csc, csr, feat3d, el2d, slope, p, seed, out3d, d_out3d, nstat, need_src):
         """-> (d_feat | None, d_el | None, d_er); nstat[..., 3] is overwritten with <out, d_out> per head."""
@@ -424,11 +430,12 @@ class HipBackend(object):
         d_el = torch.empty((csc.num_cols, H), dtype=torch.float32, device=dev) if need_src else None
         p_dst, p_src = csc.plan(), csr.plan()
         ws = self._gat_ws([p_dst, p_src], H, F, dev)
+        pack = self._gat_pack_ws(csc, H, F, dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mgx_gat_fused_bwd(ctypes.byref(csc.c_struct()), self._plan_ptr(p_dst), ctypes.byref(csr.c_struct()),
                                                     self._plan_ptr(p_src), H, F, _ptr(feat3d), _ptr(el2d), ctypes.c_float(slope),
                                                     ctypes.c_float(p), ctypes.c_uint64(seed), _ptr(out3d), _ptr(d_out3d), _ptr(nstat),
-                                                    _ptr(d_feat), _ptr(d_el), _ptr(d_er), _ptr(ws), _stream(dev)))
+                                                    _ptr(d_feat), _ptr(d_el), _ptr(d_er), _ptr(ws), _ptr(pack), _stream(dev)))
         return d_feat, d_el, d_er
 
     @staticmethod

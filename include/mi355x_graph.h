@@ -239,16 +239,22 @@ int32_t mgx_gat_attention_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* m
  * in dword-aligned 16-byte windows); 32-bit indices (else MGX_ERR_UNSUPPORTED: callers fall back to mgx_gat_attention_* +
  * mgx_spmm_csr).  keep(e,h) = hash(seed, e*H + h) >= p * 2^32 (counter based; drop_p = 0: no mask).
  * workspace: max over the plans passed of mgx_gat_fused_workspace(plan, H, F) bytes (NULL when no plan splits rows).
+ * pack_ws (may be NULL): mgx_gat_fused_pack_workspace(num_src, num_dst, H, F) bytes of scratch; when given and the layer is
+ *   narrow enough that a node's feature row and its per-head attention terms fit the row's 128-byte lines (one head of
+ *   16 or 41 features: yes; 8 x 16: no, the function returns 0), the gathered operands are first packed into rows
+ *   [feat | el] (forward, backward destination walk) and [d_out | er, m, 1/s, t] (backward source walk), so that an edge
+ *   costs one L2 request instead of two -- these walks are bound by requests, not bytes.  Same results bit for bit.
  * Deterministic: no atomics, hub partial sums combined in slot order. */
 int64_t mgx_gat_fused_workspace(const mgx_spmm_plan* plan /* may be NULL */, int64_t H, int64_t F);
+int64_t mgx_gat_fused_pack_workspace(int64_t num_src, int64_t num_dst, int64_t H, int64_t F);
 int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int64_t H, int64_t F,
                           const float* feat, const float* el, const float* er, float negative_slope, float drop_p,
-                          uint64_t seed, float* out, float* nstat, void* workspace, void* stream);
+                          uint64_t seed, float* out, float* nstat, void* workspace, void* pack_ws, void* stream);
 int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan /* may be NULL */, const mgx_csr* csr,
                           const mgx_spmm_plan* csr_plan /* may be NULL */, int64_t H, int64_t F, const float* feat,
                           const float* el, float negative_slope, float drop_p, uint64_t seed, const float* out,
                           const float* d_out, float* nstat, float* d_feat /* may be NULL with d_el */, float* d_el,
-                          float* d_er, void* workspace, void* stream);
+                          float* d_er, void* workspace, void* pack_ws, void* stream);
 
 /* ------------------------------------------------------------------ GAT attention terms
  * el[n,h] = sum_f feat[n,h,f] * attn[h,f] -- GATConv's `(feat * attn_l).sum(-1)` (main_dgl_reddit_gat.py:10, UPSTREAM

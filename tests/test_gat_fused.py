@@ -195,3 +195,30 @@ def test_fused_rejects_mismatched_rows():
     assert ops.gat_fused_supported(g, torch.randn(n, 1, 41, device=DEV))       # one head of any width: ragged windows
     assert not ops.gat_fused_supported(g, torch.randn(n, 2, 41, device=DEV))   # several ragged heads: the unfused path
     assert not ops.gat_fused_supported(g, torch.randn(n, 1, 3, device=DEV))
+
+
+@pytest.mark.parametrize("H,F", [(1, 16), (1, 41), (2, 8), (1, 24), (4, 4)])
+def test_packed_gather_operands_change_nothing(H, F, monkeypatch):
+    """Narrow layers gather [feat | el] and [d_out | er, m, 1/s, t] rows packed into whole lines (one L2 request per edge
+    instead of two, mgx_gat_fused_pack_workspace); MGX_GAT_NO_PACK=1 gathers the separate arrays: same bits."""
+    from mi355x_graph import _lib
+    n = 4000
+    src, dst = random_graph(n, n, 60000, seed=H * 100 + F, skew=True)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().formats(["csr", "csc"]).to(DEV)
+    assert _lib.lib().mgx_gat_fused_pack_workspace(n, n, H, F) > 0
+    assert _lib.lib().mgx_gat_fused_pack_workspace(n, n, 8, 16) == 0  # 8 x 16: the terms do not fit the row's lines
+    assert _lib.lib().mgx_gat_fused_pack_workspace(n, n, 1, 8) == 0   # 8 + 1 floats in a 128-byte row: too much padding
+    torch.manual_seed(1)
+    feat0 = torch.randn(n, H, F, device=DEV)
+    el0, er0 = torch.randn(n, H, device=DEV), torch.randn(n, H, device=DEV)
+    w = torch.randn(n, H, F, device=DEV)
+    res = []
+    for nopack in (False, True):
+        if nopack:
+            monkeypatch.setenv("MGX_GAT_NO_PACK", "1")
+        feat, el, er = (t.clone().requires_grad_(True) for t in (feat0, el0, er0))
+        out = ops.gat_fused(g, feat, el, er, 0.2)
+        (out * w).sum().backward()
+        res.append((out.detach(), feat.grad, el.grad, er.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
