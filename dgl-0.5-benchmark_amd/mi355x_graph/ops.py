@@ -704,6 +704,7 @@ def sage_mean_layer(g, h, w_self, w_neigh, bias=None, cat=None):
     if (type(g) is not DGLGraph or g.is_block or h.dim() != 2 or h.dtype != torch.float32
             or not h.is_cuda or h.device.type not in sparse._BACKENDS or not torch.is_grad_enabled()
             or g.number_of_src_nodes() != g.number_of_dst_nodes() or h.shape[0] != g.number_of_src_nodes()
+            or g.idtype != torch.int32  # the accumulating aggregation is exercised on the int32 kernels only
             or (bias is not None and w_self.shape[0] > sparse.backend_for(h).COLUMN_SUM_MAX)
             or _torch_ops() is not None or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):
         return None
