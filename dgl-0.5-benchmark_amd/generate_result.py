@@ -29,6 +29,8 @@ RUNS = [  # name, launcher, arguments (reference script each one stands for)
     ("sage_products", "full_graph.py", ["--model", "sage", "--dataset", "products", "--epochs", "20"]),  # main_dgl_product_sage.py
     ("gat8_reddit_small", "full_graph.py", ["--model", "gat", "--dataset", "reddit-small", "--heads", "8", "--num-layers", "2",
                                             "--epochs", "20"]),                                          # BASELINE config 3 (ns-gat shape)
+    ("gat8_reddit_small_hipgraph", "full_graph.py", ["--model", "gat", "--dataset", "reddit-small", "--heads", "8", "--num-layers", "2",
+                                                     "--epochs", "20", "--hipgraph"]),                   # same step, one captured HIP graph
     ("gcn_molhiv", "graph_classification.py", ["--epochs", "3"]),                                         # main_dgl_molhiv_gcn.py
     ("gcn_molhiv_hipgraph", "graph_classification.py", ["--epochs", "4", "--hipgraph"]),                  # same loop, one captured HIP graph
     ("gin_molhiv", "graph_classification.py", ["--model", "gin", "--epochs", "3"]),                       # BASELINE config 5 wording
