@@ -15,13 +15,17 @@ strong scaling.
 
 The JSON line also carries
   roofline      the dominant hot-path kernel (copy_u/sum g-SpMM at D = 64, 4 launches per epoch): algorithmic bytes
-                (4(N+1) + 4E + 4ND + 4ND) / its mean launch duration, measured live with HIP events on the
-                launch stream, against the 8 TB/s HBM peak; `kernels` lists every g-SpMM shape of the epoch (D = 100 too);
+                (4(N+1) + 4E + 4ND + 4ND; the two backward launches accumulate into the self gradient and so
+                read the output rows as well: + 4ND for them) / its mean launch duration, measured live with HIP events on
+                the launch stream, against the 8 TB/s HBM peak; `kernels` lists every g-SpMM shape of the epoch (D = 100 too);
                 `traffic` = FETCH_SIZE*2 + WRITE_SIZE per launch from rocprofv3 --pmc child passes of the same kernel on
                 the same graph, run after the timed region (N = 1; --no-pmc skips them -> null);
                 `controls` = the same kernel on control graphs of the same size (dgl-0.5-benchmark_amd/kernel_controls.py);
   epoch_ms_plain_model   the same epoch with the reference's exact module graph (torch.nn.Linear, F.relu, nn.Dropout,
-                separate add) -- only update_all() is this package's -- timed right after the headline loop;
+                separate add, log_softmax over all nodes then [train_idx], F.nll_loss) -- only update_all() is this
+                package's -- timed right after the headline loop.  The headline (default) model computes the same function
+                with this package's dense-side forms: a SAGE layer as one autograd node and one GEMM on [h | neigh], fused
+                relu+dropout, the loss tail on the training rows only (DESIGN 6);
   cpu_baseline  the CPU oracle (OpenMP port of DGL's CPU algorithm) timed on the host cores on the g-SpMMs of one epoch
                 (rank 0, N = 1 only, bounded to ~30 s).
 """
