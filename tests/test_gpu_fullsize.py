@@ -162,3 +162,50 @@ def test_reddit_shape_fused_attention_head_dot_and_transpose_properties():
     x = torch.rand(spec["n"] * 10, 47, device=DEV)                    # products-sized column sum (2.3 M x 47)
     got = sparse.backend_for(x).column_sum(x)
     assert rel(got.double(), x.double().sum(0)) < 1e-6
+
+
+@pytest.fixture(scope="module")
+def reddit_full():
+    spec = SHAPES["reddit"]
+    src, dst = synthetic_edges(spec["n"], spec["m"], spec["max_deg"], spec["seed"], DEV, symmetric=True)
+    g = mg.graph((src, dst), num_nodes=spec["n"]).int()
+    return g, src, dst, spec["n"]
+
+
+@pytest.mark.parametrize("D", [602, 256])
+def test_reddit_full_size_wide_rows_properties(reddit_full, D):
+    """reddit at the dataset's own size (E = 114.6 M, 492 in-edges per node), the input width of main_dgl_reddit_sage.py
+    (602: line-padded copy + 128-column passes) and a hidden width that takes two column passes: fp64 column checksum,
+    adjointness with the reversed-graph kernel, mean * deg = sum, determinism."""
+    g, src, dst, n = reddit_full
+    assert src.shape[0] == 114615892
+    gen = torch.Generator(device=DEV).manual_seed(D)
+    x = torch.rand(n, D, device=DEV, generator=gen)
+    ax = ops.gspmm(g, "copy_lhs", "sum", x, None)
+    outdeg = torch.bincount(src, minlength=n).double()
+    ref_cols = (outdeg.view(-1, 1) * x.double()).sum(0)          # sum_v out[v] = sum_u outdeg(u) X[u]
+    assert rel(ax.double().sum(0), ref_cols) < 1e-6
+    y = torch.rand(n, 8, device=DEV, generator=gen)
+    aty = ops.gspmm(g.reverse(), "copy_lhs", "sum", y, None)     # A^T y, D = 8
+    lhs = (ax[:, :8].double() * y.double()).sum()
+    rhs = (x[:, :8].double() * aty.double()).sum()
+    assert abs(float(lhs - rhs)) < 1e-6 * abs(float(rhs))
+    mean = ops.gspmm(g, "copy_lhs", "mean", x, None)
+    indeg = g.in_degrees().clamp(min=1).float().view(-1, 1)
+    assert rel(mean * indeg, ax) < 1e-5
+    assert torch.equal(ax, ops.gspmm(g, "copy_lhs", "sum", x, None))
+
+
+def test_reddit_full_size_u_add_v_checksum(reddit_full):
+    """The lean COO g-SDDMM at the kernel sweep's own size: sum_e (U[src e] + V[dst e]) per column in fp64."""
+    g, src, dst, n = reddit_full
+    D = 32
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    u, v = torch.rand(n, D, device=DEV, generator=gen), torch.rand(n, D, device=DEV, generator=gen)
+    out = ops.gsddmm(g, "add", u, v)
+    assert out.shape == (src.shape[0], D)
+    outdeg, indeg = torch.bincount(src, minlength=n).double(), torch.bincount(dst, minlength=n).double()
+    ref = (outdeg.view(-1, 1) * u.double()).sum(0) + (indeg.view(-1, 1) * v.double()).sum(0)
+    assert rel(out.double().sum(0), ref) < 1e-6
+    e = torch.randint(0, src.shape[0], (4096,), device=DEV, generator=gen)
+    assert torch.equal(out[e], u[src[e]] + v[dst[e]])            # bit-exact on sampled edges
