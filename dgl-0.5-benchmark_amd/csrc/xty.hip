@@ -1,4 +1,5 @@
-// xty.hip -- C[M, K] = A^T B for A [n, M], B [n, K] row-major with n in the millions and M, K <= 64 / 128: the weight
+// xty.hip -- C[M, K] = A^T B for A [n, M], B [n, K] row-major with n in the millions and M, K <= 64 / 128 (one tile; up to
+// 256 x 1024 as a grid of such tiles in one launch): the weight
 // gradient dW = dY^T X of the dense layer that follows every aggregation (SAGEConv's fc_self / fc_neigh,
 // main_dgl_product_sage.py:31-33,64).  rocBLAS / hipBLASLt run these tall-skinny reductions (K-dim = 2.45 M) at 0.5-1.0 ms;
 // the operands only need to be streamed once (1.6 GB at 64 x 100), so the bound is HBM.
@@ -95,6 +96,96 @@ __global__ __launch_bounds__(kBlock) void xty_finish_kernel(int M, int K, int ld
   }
 }
 
+// Outputs wider than one 64 x 128 tile (arxiv's 256 x 512, GAT's 128 x 602, the stacked 64 x 200 of the one-GEMM SAGE layer):
+// ONE launch, blockIdx.y = output tile.  The waves of different tiles walk the same data rows at the same time, so an operand
+// row is read from HBM once and from L2 by the other tiles, and 4 waves per SIMD are resident -- against one launch per tile,
+// each streaming both operands again with less than one wave per SIMD.  About kXtyGridTotal waves in all (4 per SIMD at 128
+// VGPRs) shared evenly by the tiles; partials per (tile, wave).
+constexpr int kXtyGridTotal = 4096;
+constexpr int kXtyTileM = 64, kXtyTileK = 128;
+
+__global__ __launch_bounds__(kBlock) void xty_partial_grid_kernel(int64_t n, int M, int K, int tiles_k, const float* __restrict__ A,
+                                                                  int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                                  float* __restrict__ part) {
+  constexpr int MT = 4, KT = 8;
+  const int tile = blockIdx.y;
+  const int m0 = (tile / tiles_k) * kXtyTileM, k0 = (tile % tiles_k) * kXtyTileK;
+  const int Mt = M - m0 < kXtyTileM ? M - m0 : kXtyTileM, Kt = K - k0 < kXtyTileK ? K - k0 : kXtyTileK;
+  A += m0;
+  B += k0;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t gw = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int c = lane % 16, q = lane / 16;
+  v4f acc[MT][KT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < KT; ++j) acc[i][j] = (v4f)(0.f);
+  bool am[MT], bm[KT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) am[i] = i * 16 + c < Mt;
+#pragma unroll
+  for (int j = 0; j < KT; ++j) bm[j] = j * 16 + c < Kt;
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * 16;
+  for (int64_t r0 = gw * 16; r0 < n; r0 += stride) {
+    float a[4][MT], b[4][KT];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int64_t row = r0 + s * 4 + q;
+      const bool ok = row < n;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[s][i] = (ok && am[i]) ? A[row * lda + i * 16 + c] : 0.f;
+#pragma unroll
+      for (int j = 0; j < KT; ++j) b[s][j] = (ok && bm[j]) ? B[row * ldb + j * 16 + c] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+  }
+  const int64_t wpt = (int64_t)gridDim.x * kWavesPerBlock;  // waves per tile
+  float* p = part + ((int64_t)tile * wpt + gw) * (int64_t)(kXtyTileM * kXtyTileK);
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < KT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[(i * 16 + 4 * q + r) * kXtyTileK + j * 16 + c] = acc[i][j][r];
+}
+
+// blockIdx.y = tile; blockIdx.x over the 64 x 128 elements of a tile, 16 per workgroup; slices combined in slice order
+__global__ __launch_bounds__(kBlock) void xty_finish_grid_kernel(int M, int K, int tiles_k, int wpt, const float* __restrict__ part,
+                                                                 float* __restrict__ out, int64_t ldc) {
+  __shared__ float red[16][17];
+  const int tile = blockIdx.y;
+  const int m0 = (tile / tiles_k) * kXtyTileM, k0 = (tile % tiles_k) * kXtyTileK;
+  const int e = threadIdx.x % 16, sl = threadIdx.x / 16;
+  const int idx = blockIdx.x * 16 + e;  // over the tile's 64 x 128 elements
+  const int m = idx / kXtyTileK, k = idx % kXtyTileK;
+  const bool live = m0 + m < M && k0 + k < K;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (live) {
+    const int tsz = kXtyTileM * kXtyTileK;
+    const float* p = part + (int64_t)tile * wpt * tsz + idx;
+    const int per = wpt / 16;
+    for (int w = sl * per; w < (sl + 1) * per; w += 4) {
+      s0 += p[(int64_t)w * tsz];
+      s1 += p[(int64_t)(w + 1) * tsz];
+      s2 += p[(int64_t)(w + 2) * tsz];
+      s3 += p[(int64_t)(w + 3) * tsz];
+    }
+  }
+  red[sl][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && live) {
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += red[i][e];
+    out[(int64_t)(m0 + m) * ldc + k0 + k] = s;
+  }
+}
+
 template <int MT>
 static bool launch_xty_kt(int kt, int waves, int64_t n, int M, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                           float* part, hipStream_t s) {
@@ -110,7 +201,11 @@ static bool launch_xty_kt(int kt, int waves, int64_t n, int M, int K, const floa
 
 extern "C" int64_t mgx_xty_workspace(int64_t M, int64_t K) {
   const int64_t mt = (M + 15) / 16, kt = (K + 15) / 16;
-  if (M < 1 || K < 1 || mt > 4 || kt > 8) return -1;
+  if (M < 1 || K < 1) return -1;
+  if (mt > 4 || kt > 8) {  // several 64 x 128 tiles in one launch
+    if (M > 256 || K > 1024) return -1;
+    return (int64_t)mgx::kXtyGridTotal * mgx::kXtyTileM * mgx::kXtyTileK * (int64_t)sizeof(float);  // tiles x waves-per-tile <= this many
+  }
   return (int64_t)mgx::kXtyWaves * mt * 16 * kt * 16 * (int64_t)sizeof(float);
 }
 
@@ -120,7 +215,7 @@ extern "C" int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int6
   MGX_ENTER();
   MGX_CHECK_ARG(n >= 0 && M >= 1 && K >= 1, "mgx_xty: bad sizes");
   const int mt = (int)((M + 15) / 16), kt = (int)((K + 15) / 16);
-  if (mt > 4 || kt > 8) MGX_UNSUPPORTED("mgx_xty: needs M <= 64 and K <= 128 (got %lld x %lld)", (long long)M, (long long)K);
+  if (M > 256 || K > 1024) MGX_UNSUPPORTED("mgx_xty: needs M <= 256 and K <= 1024 (got %lld x %lld)", (long long)M, (long long)K);
   MGX_CHECK_ARG(out != nullptr, "mgx_xty: out is NULL");
   MGX_CHECK_ARG(lda >= M && ldb >= K && ldc >= K, "mgx_xty: leading dimensions smaller than the tile (lda %lld, ldb %lld, ldc %lld)",
                 (long long)lda, (long long)ldb, (long long)ldc);
@@ -131,6 +226,21 @@ extern "C" int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int6
   }
   MGX_CHECK_ARG(a && b && workspace, "mgx_xty: NULL pointer");
   float* part = (float*)workspace;
+  if (mt > 4 || kt > 8) {
+    const int tiles_m = (int)((M + kXtyTileM - 1) / kXtyTileM), tiles_k = (int)((K + kXtyTileK - 1) / kXtyTileK);
+    // waves per tile: an even share of kXtyGridTotal, a multiple of 64 (the finish kernel's 16 slices x 4), at least 64 and at
+    // most what gives every wave 256 rows
+    int wpt = kXtyGridTotal / (tiles_m * tiles_k) / 64 * 64;
+    if (wpt > xty_waves(n)) wpt = xty_waves(n);
+    if (wpt < 64) wpt = 64;
+    hipLaunchKernelGGL(xty_partial_grid_kernel, dim3(wpt / kWavesPerBlock, tiles_m * tiles_k), dim3(kBlock), 0, s, n, (int)M,
+                       (int)K, tiles_k, a, lda, b, ldb, part);
+    MGX_CHECK_LAUNCH();
+    hipLaunchKernelGGL(xty_finish_grid_kernel, dim3(kXtyTileM * kXtyTileK / 16, tiles_m * tiles_k), dim3(kBlock), 0, s, (int)M, (int)K,
+                       tiles_k, wpt, (const float*)part, out, ldc);
+    MGX_CHECK_LAUNCH();
+    return MGX_OK;
+  }
   const int waves = xty_waves(n);
   bool ok = false;
   switch (mt) {

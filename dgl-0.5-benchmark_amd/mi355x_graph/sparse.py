@@ -552,8 +552,8 @@ class HipBackend(object):
         return out
 
     COLUMN_SUM_MAX = 256
-    XTY_TILE = (64, 128)      # one mgx_xty call: a^T b with a [n, <= 64], b [n, <= 128]
-    XTY_MAX = (256, 1024)     # wider products are tiled through the leading dimensions (every operand re-read per tile)
+    XTY_TILE = (64, 128)      # one tile of mgx_xty
+    XTY_MAX = (256, 1024)     # the grid of tiles in one launch goes up to this output shape
     XTY_MIN_ROWS = 1 << 16    # shorter reductions stay with the GEMM library
 
     def xty(self, a2d, b2d):
@@ -563,16 +563,26 @@ class HipBackend(object):
         K = b2d.shape[1]
         if M > self.XTY_MAX[0] or K > self.XTY_MAX[1]:
             raise DGLError("mgx_xty: at most %d x %d outputs, got %d x %d" % (self.XTY_MAX + (M, K)))
-        tm, tk = self.XTY_TILE
         out = torch.empty((M, K), dtype=torch.float32, device=dev)
         L = _lib.lib()
-        ws = torch.empty(max(L.mgx_xty_workspace(min(M, tm), min(K, tk)), 4) // 4, dtype=torch.float32, device=dev)
+        tm, tk = self.XTY_TILE
+        ntiles = ((M + tm - 1) // tm) * ((K + tk - 1) // tk)
         with torch.cuda.device(dev):
-            for m0 in range(0, max(M, 1), tm):
-                for k0 in range(0, max(K, 1), tk):
-                    a_t, b_t, o_t = a2d[:, m0:m0 + tm], b2d[:, k0:k0 + tk], out[m0:m0 + tm, k0:k0 + tk]
-                    _lib.check(L.mgx_xty(n, a_t.shape[1], b_t.shape[1], _ptr(a_t), max(a2d.stride(0), M), _ptr(b_t), max(b2d.stride(0), K),
-                                         _ptr(o_t), out.stride(0), _ptr(ws), _stream(dev)))
+            if ntiles == 1 or ntiles >= 4:
+                # a single 64 x 128 tile, or the grid of tiles in ONE launch (operand rows shared through L2): measured
+                # 256 x 512 at n = 169 k 1.07 -> 0.56 ms, 128 x 602 at n = 233 k 0.78 -> 0.57 ms (experiments/exp_wgrad_shapes.py)
+                ws = torch.empty(max(L.mgx_xty_workspace(M, K), 4) // 4, dtype=torch.float32, device=dev)
+                _lib.check(L.mgx_xty(n, M, K, _ptr(a2d), max(a2d.stride(0), M), _ptr(b2d), max(b2d.stride(0), K), _ptr(out),
+                                     out.stride(0), _ptr(ws), _stream(dev)))
+            else:
+                # two or three tiles (the stacked 64 x 200 of the products layer): one launch per tile, each with the exact tile
+                # shape, is faster than the grid's padded 64 x 128 tiles (n = 2.45 M: 0.93 against 1.04 ms)
+                ws = torch.empty(max(L.mgx_xty_workspace(min(M, tm), min(K, tk)), 4) // 4, dtype=torch.float32, device=dev)
+                for m0 in range(0, M, tm):
+                    for k0 in range(0, K, tk):
+                        a_t, b_t, o_t = a2d[:, m0:m0 + tm], b2d[:, k0:k0 + tk], out[m0:m0 + tm, k0:k0 + tk]
+                        _lib.check(L.mgx_xty(n, a_t.shape[1], b_t.shape[1], _ptr(a_t), max(a2d.stride(0), M), _ptr(b_t),
+                                             max(b2d.stride(0), K), _ptr(o_t), out.stride(0), _ptr(ws), _stream(dev)))
         return out
 
     def column_sum(self, x2d):

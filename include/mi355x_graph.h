@@ -294,11 +294,12 @@ int32_t mgx_column_pair_sums(int64_t n, int64_t C, int32_t mode, const float* a,
 int32_t mgx_column_affine(int64_t n, int64_t C, const float* a, const float* b, const float* A, const float* B, const float* Cc,
                           float* out, void* stream);
 
-/* out[M, K] = a^T b for a [n, M] (row stride lda floats), b [n, K] (row stride ldb), out row stride ldc; M <= 64, K <= 128 per
- * call (else MGX_ERR_UNSUPPORTED; wider products are tiled by the caller through the leading dimensions), n in the millions:
- * the weight gradient dW = dY^T X of the dense layer after an aggregation (main_dgl_product_sage.py:31-33,64).  fp32 MFMA,
- * operands streamed once, per-wave partial tiles added in fixed order (deterministic); workspace of
- * mgx_xty_workspace(M, K) bytes (-1 if the shape is unsupported). */
+/* out[M, K] = a^T b for a [n, M] (row stride lda floats), b [n, K] (row stride ldb), out row stride ldc, n in the hundreds of
+ * thousands to millions: the weight gradient dW = dY^T X of the dense layer after an aggregation
+ * (main_dgl_product_sage.py:31-33,64).  M <= 64 and K <= 128: one tile, operands streamed once.  Up to M <= 256, K <= 1024
+ * (round 2): the grid of 64 x 128 tiles in ONE launch, the tiles' waves walking the same rows together so that operand rows
+ * are shared through L2 (else MGX_ERR_UNSUPPORTED).  fp32 MFMA, per-wave partial tiles added in fixed order
+ * (deterministic); workspace of mgx_xty_workspace(M, K) bytes (-1 if the shape is unsupported). */
 int64_t mgx_xty_workspace(int64_t M, int64_t K);
 int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldc,
                 void* workspace, void* stream);

@@ -602,7 +602,8 @@ def test_head_dot_sddmm_on_csr_walk(oracle, H, F, canonical):
 
 
 @pytest.mark.parametrize("n,M,K", [(0, 3, 5), (1, 1, 1), (5, 64, 128), (1000, 47, 64), (70001, 64, 100), (300000, 16, 7),
-                                    (123457, 33, 113), (65536, 64, 64), (70000, 256, 128), (66000, 200, 300), (3000, 65, 129)])
+                                    (123457, 33, 113), (65536, 64, 64), (70000, 256, 128), (66000, 200, 300), (3000, 65, 129),
+                                    (80000, 128, 602), (70000, 256, 1024), (50, 256, 1000), (169343, 256, 512), (0, 200, 300)])
 def test_xty_matches_fp64(n, M, K):
     """mgx_xty (dW = dY^T X with fp32 MFMA) against the fp64 product; every tile-count template and ragged edges."""
     rng = np.random.default_rng(n + M + K)
