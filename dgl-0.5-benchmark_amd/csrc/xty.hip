@@ -231,7 +231,8 @@ extern "C" int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int6
     // waves per tile: an even share of kXtyGridTotal, a multiple of 64 (the finish kernel's 16 slices x 4), at least 64 and at
     // most what gives every wave 256 rows
     int wpt = kXtyGridTotal / (tiles_m * tiles_k) / 64 * 64;
-    if (wpt > xty_waves(n)) wpt = xty_waves(n);
+    const int64_t by_rows = n / 128 / 64 * 64;  // >= 128 rows per wave: short inputs (a batch of small graphs) take few waves
+    if (wpt > by_rows) wpt = (int)by_rows;
     if (wpt < 64) wpt = 64;
     hipLaunchKernelGGL(xty_partial_grid_kernel, dim3(wpt / kWavesPerBlock, tiles_m * tiles_k), dim3(kBlock), 0, s, n, (int)M,
                        (int)K, tiles_k, a, lda, b, ldb, part);
