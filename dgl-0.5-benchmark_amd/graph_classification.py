@@ -250,7 +250,8 @@ class GraphedBatchTrainer(object):
         # layers; experiments/dbg_gin_nan2.py).  Same stream -> a linear graph.
         side = self.side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        from mi355x_graph import ops as _ops
+        with torch.cuda.stream(side), _ops.warming_up_for_capture():  # the forms operators take under capture, here too
             for _ in range(2):
                 self.opt.zero_grad(set_to_none=True)
                 self._forward_loss(buf).backward()

@@ -454,12 +454,34 @@ class ReluDropout(torch.autograd.Function):
         return be.relu_dropout_bwd(dy, mask, ctx.p), None, None
 
 
+_WARMING_UP_FOR_CAPTURE = 0
+
+
+def capture_path():
+    """True while the current stream is being captured into a HIP graph AND during the eager warm-up steps that precede a
+    capture (utils.GraphedStep, graph_classification.GraphedBatchTrainer): operators that choose a different form under
+    capture must choose it in the warm-up too, so that everything the captured form needs -- BLAS handles, workspaces,
+    lazily built plans -- exists before the capture starts."""
+    return _WARMING_UP_FOR_CAPTURE > 0 or torch.cuda.is_current_stream_capturing()
+
+
+class warming_up_for_capture(object):
+    def __enter__(self):
+        global _WARMING_UP_FOR_CAPTURE
+        _WARMING_UP_FOR_CAPTURE += 1
+
+    def __exit__(self, *exc):
+        global _WARMING_UP_FOR_CAPTURE
+        _WARMING_UP_FOR_CAPTURE -= 1
+        return False
+
+
 def relu_dropout(x, p=0.5, training=True, out=None):
     """dropout(relu(x), p) in one pass each way (float32 HIP tensors with numel % 4 == 0; anything else, evaluation mode
     and HIP-graph capture -- whose replays must draw new masks -- take the two PyTorch ops).  `out`: a [rows, cols] view with
     unit column stride to write the result into (a column block of a wider matrix); ignored on the PyTorch path."""
     if (not training or p <= 0.0 or p >= 1.0 or x.dtype != torch.float32 or x.device.type != "cuda" or x.numel() % 4
-            or x.device.type not in sparse._BACKENDS or torch.cuda.is_current_stream_capturing()):
+            or x.device.type not in sparse._BACKENDS or capture_path()):
         return torch.nn.functional.dropout(torch.relu(x), p, training)
     if out is not None and (x.dim() != 2 or x.shape[1] % 4 or out.shape != x.shape or out.stride(1) != 1 or out.stride(0) % 4
                             or out.requires_grad):

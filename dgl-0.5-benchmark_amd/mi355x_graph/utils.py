@@ -30,7 +30,10 @@ class GraphedStep(object):
         self.loss_fn, self.optimizer = loss_fn, optimizer
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # lazily built formats / plans / workspaces and autotuned GEMMs settle here
+        from . import ops
+        # lazily built formats / plans / workspaces and autotuned GEMMs settle here; operators that take another form under
+        # capture (relu_dropout) take it in these steps too, so the captured step meets nothing for the first time
+        with torch.cuda.stream(side), ops.warming_up_for_capture():
             for _ in range(warmup):
                 self._eager()
         torch.cuda.current_stream().wait_stream(side)

@@ -244,3 +244,30 @@ def test_ginconv_matches_dense_formulation():
     mx = dense.max(1)[0]
     mx = torch.where(torch.isinf(mx), torch.zeros_like(mx), mx)
     assert nerr(out, x + mx) < 1e-5
+
+
+def test_hip_graph_capture_with_dropout_takes_the_same_forms_in_warm_up():
+    """GraphedStep with dropout > 0: under capture relu_dropout is the two PyTorch ops (a replay must draw a new mask), which
+    also decides which form the next SAGE layer takes (one GEMM over a CatBuffer only behind the fused kernel).  The warm-up
+    steps must take the captured forms (ops.warming_up_for_capture), or the capture meets a BLAS path -- and its handle
+    creation -- for the first time (regression: hipblasCreate inside the capture)."""
+    sys.path.insert(0, PKG)
+    import full_graph
+    from mi355x_graph.utils import GraphedStep
+    from mi355x_graph.datasets import synthetic_edges
+    dev = "cuda:0"
+    n = 4000
+    src, dst = synthetic_edges(n, 30000, 200, seed=6, symmetric=True)
+    g = mg.graph((src, dst), num_nodes=n).int().formats(["csr", "csc"]).to(dev)
+    gen = torch.Generator().manual_seed(1)
+    x = torch.rand(n, 20, generator=gen).to(dev)
+    y = torch.randint(0, 5, (n,), generator=gen).to(dev)
+    idx = torch.nonzero(torch.rand(n, generator=gen) < 0.3).flatten().to(dev)
+    torch.manual_seed(4)
+    model = full_graph.GraphSAGE(20, 16, 5, 3, dropout=0.5).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=0.01, capturable=True)
+    model.train()
+    step = GraphedStep(lambda: F.nll_loss(model(g, x)[idx], y[idx]), opt, warmup=2)
+    losses = [float(step()) for _ in range(12)]
+    assert all(np.isfinite(losses)) and min(losses[6:]) < losses[0]
+    assert len({round(v, 6) for v in losses}) > 6          # replays draw new dropout masks
