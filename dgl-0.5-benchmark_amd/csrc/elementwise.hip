@@ -21,7 +21,11 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 // are indexed by the DENSE element number, so a strided call draws the same mask as the dense one.
 __global__ __launch_bounds__(kBlock) void relu_dropout_fwd_kernel(int64_t n4, const v4f* __restrict__ x, v4f* __restrict__ y,
                                                                   uint8_t* __restrict__ mask, uint32_t drop_below, float scale,
-                                                                  uint64_t seed, uint64_t offset, int64_t c4, int64_t ldx4, int64_t ldy4) {
+                                                                  uint64_t seed, uint64_t offset, int64_t c4, int64_t ldx4, int64_t ldy4,
+                                                                  const uint64_t* __restrict__ counter) {
+  // counter (device memory, may be NULL): the call's position in the random stream is read at RUN time -- a HIP graph that
+  // replays this launch draws a new mask every replay once the graph also increments the counter
+  if (counter) offset = (*counter * 0x9E3779B97F4A7C15ull) & 0x7FFFFFFFFFFFFFFFull;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
     const int64_t r = i / c4, c = i - r * c4;
     const v4f v = __builtin_nontemporal_load(&x[r * ldx4 + c]);
@@ -74,7 +78,7 @@ extern "C" int32_t mgx_relu_dropout_fwd(int64_t n, const float* x, float p, uint
   const double thr = (double)p * 4294967296.0;
   const uint32_t drop_below = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
   hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)x, (v4f*)y,
-                     mask, drop_below, 1.f / (1.f - p), seed, offset, n / 4, n / 4, n / 4);
+                     mask, drop_below, 1.f / (1.f - p), seed, offset, n / 4, n / 4, n / 4, (const uint64_t*)nullptr);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
@@ -108,7 +112,7 @@ extern "C" int32_t mgx_relu_dropout_fwd_strided(int64_t rows, int64_t cols, cons
   const double thr = (double)p * 4294967296.0;
   const uint32_t drop_below = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
   hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)x, (v4f*)y,
-                     mask, drop_below, 1.f / (1.f - p), seed, offset, cols / 4, x_stride / 4, y_stride / 4);
+                     mask, drop_below, 1.f / (1.f - p), seed, offset, cols / 4, x_stride / 4, y_stride / 4, (const uint64_t*)nullptr);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
@@ -125,6 +129,28 @@ extern "C" int32_t mgx_relu_dropout_bwd_strided(int64_t rows, int64_t cols, cons
   MGX_CHECK_ARG(dy && dx && mask && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0, "mgx_relu_dropout_bwd_strided: NULL or unaligned pointer");
   hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)dy, mask,
                      (v4f*)dx, 1.f / (1.f - p), cols / 4, dy_stride / 4, dx_stride / 4);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+// As mgx_relu_dropout_fwd_strided, but the offset into the random stream is `*counter * 0x9E3779B97F4A7C15 mod 2^63`, read on the
+// device when the launch runs: captured in a HIP graph together with an increment of the counter, every replay draws a new mask
+// (the host-side offset of the plain entry points is a launch argument and would be frozen by the capture).
+extern "C" int32_t mgx_relu_dropout_fwd_counter(int64_t rows, int64_t cols, const float* x, int64_t x_stride, float p, uint64_t seed,
+                                                const uint64_t* counter, float* y, int64_t y_stride, uint8_t* mask, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(rows >= 0 && cols >= 0 && cols % 4 == 0 && x_stride % 4 == 0 && y_stride % 4 == 0 && x_stride >= cols && y_stride >= cols,
+                "mgx_relu_dropout_fwd_counter: cols and strides must be multiples of 4, strides >= cols");
+  MGX_CHECK_ARG(p >= 0.f && p < 1.f, "mgx_relu_dropout_fwd_counter: p must be in [0, 1)");
+  MGX_CHECK_ARG(counter != nullptr, "mgx_relu_dropout_fwd_counter: counter is NULL");
+  const int64_t n = rows * cols;
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(x && y && mask && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0, "mgx_relu_dropout_fwd_counter: NULL or unaligned pointer");
+  const double thr = (double)p * 4294967296.0;
+  const uint32_t drop_below = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+  hipLaunchKernelGGL(relu_dropout_fwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)x, (v4f*)y,
+                     mask, drop_below, 1.f / (1.f - p), seed, (uint64_t)0, cols / 4, x_stride / 4, y_stride / 4, counter);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

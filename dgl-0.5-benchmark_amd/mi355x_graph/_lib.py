@@ -70,6 +70,7 @@ SIGNATURES = {
     "mgx_relu_dropout_bwd": (_i32, [_i64, _fp, _vp, ctypes.c_float, _fp, _vp]),
     "mgx_relu_dropout_fwd_strided": (_i32, [_i64, _i64, _fp, _i64, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _fp, _i64, _vp, _vp]),
     "mgx_relu_dropout_bwd_strided": (_i32, [_i64, _i64, _fp, _i64, _vp, ctypes.c_float, _fp, _i64, _vp]),
+    "mgx_relu_dropout_fwd_counter": (_i32, [_i64, _i64, _fp, _i64, ctypes.c_float, ctypes.c_uint64, _vp, _fp, _i64, _vp, _vp]),
     "mgx_column_pair_sums": (_i32, [_i64, _i64, _i32, _fp, _fp, _fp, _fp, _vp, _vp]),
     "mgx_column_affine": (_i32, [_i64, _i64, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     "mgx_xty_workspace": (_i64, [_i64, _i64]),

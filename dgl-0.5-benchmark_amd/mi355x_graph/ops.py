@@ -437,9 +437,16 @@ class ReluDropout(torch.autograd.Function):
         if out is None or not be._row_strided(x):
             x = x.contiguous()
         seed = torch.initial_seed() & (2 ** 64 - 1)
-        offset = (ReluDropout._calls * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
-        ReluDropout._calls += 1
-        y, mask = be.relu_dropout_fwd(x, float(p), seed, offset, out=out)
+        if capture_path():
+            # a HIP graph freezes launch arguments: the position in the random stream comes from a device counter that the
+            # captured step itself advances, so every replay draws a new mask
+            ctr = _capture_counter(x.device)
+            y, mask = be.relu_dropout_fwd(x, float(p), seed, 0, out=out, counter=ctr)
+            ctr.add_(1)
+        else:
+            offset = (ReluDropout._calls * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
+            ReluDropout._calls += 1
+            y, mask = be.relu_dropout_fwd(x, float(p), seed, offset, out=out)
         ctx.save_for_backward(mask)
         ctx.p = float(p)
         return y
@@ -465,6 +472,17 @@ def capture_path():
     return _WARMING_UP_FOR_CAPTURE > 0 or torch.cuda.is_current_stream_capturing()
 
 
+_CAPTURE_COUNTERS = {}
+
+
+def _capture_counter(device):
+    """One int64 counter per device, advanced by every captured relu_dropout call (created outside any capture: warm-up)."""
+    c = _CAPTURE_COUNTERS.get(device)
+    if c is None:
+        c = _CAPTURE_COUNTERS[device] = torch.full((1,), 1 << 20, dtype=torch.int64, device=device)
+    return c
+
+
 class warming_up_for_capture(object):
     def __enter__(self):
         global _WARMING_UP_FOR_CAPTURE
@@ -477,11 +495,13 @@ class warming_up_for_capture(object):
 
 
 def relu_dropout(x, p=0.5, training=True, out=None):
-    """dropout(relu(x), p) in one pass each way (float32 HIP tensors with numel % 4 == 0; anything else, evaluation mode
-    and HIP-graph capture -- whose replays must draw new masks -- take the two PyTorch ops).  `out`: a [rows, cols] view with
+    """dropout(relu(x), p) in one pass each way (float32 HIP tensors with numel % 4 == 0; anything else and evaluation mode
+    take the two PyTorch ops).  Under HIP-graph capture the mask's position in the random stream is read from a device
+    counter that the captured step advances, so replays draw new masks.  `out`: a [rows, cols] view with
     unit column stride to write the result into (a column block of a wider matrix); ignored on the PyTorch path."""
     if (not training or p <= 0.0 or p >= 1.0 or x.dtype != torch.float32 or x.device.type != "cuda" or x.numel() % 4
-            or x.device.type not in sparse._BACKENDS or capture_path()):
+            or x.device.type not in sparse._BACKENDS
+            or (capture_path() and (x.dim() != 2 or x.shape[1] % 4 or x.stride(1) != 1 or x.stride(0) % 4))):
         return torch.nn.functional.dropout(torch.relu(x), p, training)
     if out is not None and (x.dim() != 2 or x.shape[1] % 4 or out.shape != x.shape or out.stride(1) != 1 or out.stride(0) % 4
                             or out.requires_grad):

@@ -497,10 +497,20 @@ class HipBackend(object):
     def _row_strided(t):
         return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1] and t.stride(0) % 4 == 0 and t.shape[1] % 4 == 0
 
-    def relu_dropout_fwd(self, x, p, seed, offset, out=None):
-        """`out`: a row-strided [rows, cols] view to write into (x then 2-D, possibly row-strided itself)."""
-        dev = self._check_dev(x, out)
+    def relu_dropout_fwd(self, x, p, seed, offset, out=None, counter=None):
+        """`out`: a row-strided [rows, cols] view to write into (x then 2-D, possibly row-strided itself).  `counter`: a
+        1-element int64 device tensor read by the launch when it RUNS instead of the host-side `offset` (HIP-graph replays)."""
+        dev = self._check_dev(x, out, counter)
         mask = torch.empty(x.numel() // 4, dtype=torch.uint8, device=dev)
+        if counter is not None:
+            y = out if out is not None else torch.empty(x.shape, dtype=torch.float32, device=dev)
+            if not (self._row_strided(x) and self._row_strided(y) and x.shape == y.shape):
+                raise DGLError("relu_dropout_fwd: counter mode needs [rows, cols] operands with unit column stride, cols % 4 == 0")
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().mgx_relu_dropout_fwd_counter(x.shape[0], x.shape[1], _ptr(x), x.stride(0), ctypes.c_float(p),
+                                                                    ctypes.c_uint64(seed), _ptr(counter), _ptr(y), y.stride(0),
+                                                                    _ptr(mask), _stream(dev)))
+            return y, mask
         if out is None and x.is_contiguous():
             y = torch.empty_like(x)
             with torch.cuda.device(dev):

@@ -317,6 +317,10 @@ int32_t mgx_relu_dropout_fwd_strided(int64_t rows, int64_t cols, const float* x,
                                      uint64_t offset, float* y, int64_t y_stride, uint8_t* mask, void* stream);
 int32_t mgx_relu_dropout_bwd_strided(int64_t rows, int64_t cols, const float* dy, int64_t dy_stride, const uint8_t* mask, float p,
                                      float* dx, int64_t dx_stride, void* stream);
+/* Forward whose offset into the random stream is read from device memory when the launch RUNS (offset = *counter *
+ * 0x9E3779B97F4A7C15 mod 2^63): captured in a HIP graph next to an increment of the counter, every replay draws a new mask. */
+int32_t mgx_relu_dropout_fwd_counter(int64_t rows, int64_t cols, const float* x, int64_t x_stride, float p, uint64_t seed,
+                                     const uint64_t* counter, float* y, int64_t y_stride, uint8_t* mask, void* stream);
 
 /* ------------------------------------------------------------------ formats (integer, bit-exact)
  * Replace the lazy COO->CSR/CSC construction behind g.formats(...)/first kernel call
