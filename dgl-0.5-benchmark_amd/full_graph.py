@@ -244,7 +244,9 @@ def main():
             from dgl.utils import GraphedStep
             opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"], capturable=True)
             model.train()
-            graphed = GraphedStep(lambda: F.nll_loss(model(g, data.features)[train_idx], data.labels[train_idx]), opt)
+            y_train = data.labels[train_idx]
+            # the loss tail of sage_train_step (training rows only, gather + sum): no host synchronisation, capture-safe
+            graphed = GraphedStep(lambda: ops.nll_sum(model(g, data.features, rows=train_idx), y_train) / train_idx.shape[0], opt)
         for epoch in range(1, args.epochs + 1):
             t0 = time.time()
             if args.hipgraph:
