@@ -703,11 +703,12 @@ class SageMeanCatFn(torch.autograd.Function):
         be = sparse.backend_for(h)
         if not cat.holds(h):
             # a layer input that lives elsewhere -- the model's input features -- is copied into the left half; when it is the
-            # same tensor, unmodified (data pointer + version counter), as in the previous pass the copy is skipped
-            key = (h.data_ptr(), h._version, tuple(h.shape), tuple(h.stride()))
-            if cat.static_key != key or h.requires_grad or os.environ.get("MGX_SAGE_STATIC_CAT", "1") != "1":
+            # SAME tensor object, unmodified (version counter), as in the previous pass the copy is skipped.  The buffer keeps
+            # a reference to that tensor: a per-step temporary at a recycled address is a different object and is copied.
+            same = cat.static_key is not None and cat.static_key[0] is h and cat.static_key[1] == h._version
+            if not same or h.requires_grad or os.environ.get("MGX_SAGE_STATIC_CAT", "1") != "1":
                 cat.left.copy_(h)
-                cat.static_key = None if h.requires_grad else key
+                cat.static_key = None if h.requires_grad else (h, h._version)
         cat.generation += 1
         be.spmm_copy_u_strided(csc, "mean", cat.left, cat.right)
         ctx.gidx, ctx.cat, ctx.generation = gidx, cat, cat.generation

@@ -324,3 +324,30 @@ def test_strided_copy_u_and_relu_dropout_match_the_dense_calls(oracle):
     assert torch.equal(m_dense, m_str) and torch.equal(y_dense, buf[:, D:2 * D]) and float(buf[:, :D].abs().max()) == 0.0
     dy = torch.randn(n, 2 * D, device=DEV)
     assert torch.equal(be.relu_dropout_bwd(dy[:, D:], m_dense, 0.5), be.relu_dropout_bwd(dy[:, D:].contiguous(), m_dense, 0.5))
+
+
+def test_input_feature_copy_is_keyed_on_the_tensor_object_not_its_address():
+    """The one-GEMM first layer keeps the copy of the input features only for the SAME tensor object at the same version: a
+    fresh tensor per step (possibly at the address the allocator just recycled) and an in-place update are both copied."""
+    sys.path.insert(0, PKG)
+    import full_graph
+    n = 3000
+    src, dst = random_graph(n, n, 12 * n, seed=13)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().formats(["csr", "csc"]).to(DEV)
+    torch.manual_seed(0)
+    conv = full_graph.SAGEConv(32, 16).to(DEV)
+    cat = ops.cat_buffer_for(g, torch.zeros(n, 32, device=DEV), 32)
+    assert cat is not None
+    outs = []
+    for step in range(3):
+        x = torch.full((n, 32), float(step + 1), device=DEV)   # a new tensor every step; the allocator may reuse the address
+        outs.append(conv(g, x, cat=cat).detach().clone())
+        ref = full_graph.SAGEConv.forward(conv, g, x)            # no buffer: the one-node form
+        assert torch.allclose(outs[-1], ref.detach(), rtol=1e-5, atol=1e-5)
+        del x
+    assert not torch.equal(outs[0], outs[1])
+    x = torch.ones(n, 32, device=DEV)
+    a = conv(g, x, cat=cat).detach().clone()
+    x.mul_(3.0)                                                  # same object, new version
+    b = conv(g, x, cat=cat).detach()
+    assert torch.allclose(b, full_graph.SAGEConv.forward(conv, g, x).detach(), rtol=1e-5, atol=1e-5) and not torch.equal(a, b)
