@@ -22,6 +22,7 @@ RUNS = [  # name, launcher, arguments (reference script each one stands for)
     ("sage_pubmed", "full_graph.py", ["--model", "sage", "--dataset", "pubmed", "--epochs", "50"]),
     ("gat_cora", "full_graph.py", ["--model", "gat", "--dataset", "cora", "--epochs", "50"]),            # main_dgl_citation_gat.py
     ("sage_arxiv", "full_graph.py", ["--model", "sage", "--dataset", "arxiv", "--epochs", "30"]),        # main_dgl_arxiv_sage.py
+    ("sage_arxiv_hipgraph", "full_graph.py", ["--model", "sage", "--dataset", "arxiv", "--epochs", "30", "--hipgraph"]),  # captured step
     ("gat_arxiv", "full_graph.py", ["--model", "gat", "--dataset", "arxiv", "--epochs", "30"]),          # main_dgl_arxiv_gat.py
     ("sage_reddit", "full_graph.py", ["--model", "sage", "--dataset", "reddit", "--epochs", "20"]),      # main_dgl_reddit_sage.py
     ("gat_reddit", "full_graph.py", ["--model", "gat", "--dataset", "reddit", "--heads", "1", "--num-layers", "3",
