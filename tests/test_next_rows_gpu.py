@@ -263,7 +263,8 @@ def test_log_softmax_on_selected_rows_is_the_same_model_output():
         assert torch.equal(m(g, x)[rows], m(g, x, rows=rows))
 
 
-def test_one_gemm_layers_over_cat_buffers_match_the_two_gemm_form(monkeypatch):
+@pytest.mark.parametrize("batch_norm", [False, True])
+def test_one_gemm_layers_over_cat_buffers_match_the_two_gemm_form(monkeypatch, batch_norm):
     """Default GraphSAGE with dropout: layers as ONE GEMM on [h | neigh] (ops.CatBuffer: strided aggregation in place,
     relu_dropout writing the next layer's left half, strided backward) against MGX_SAGE_CAT=0 (two GEMMs per layer) with
     the same dropout masks: same loss, same parameter gradients, over two training steps (the input-feature copy is reused)."""
@@ -281,7 +282,7 @@ def test_one_gemm_layers_over_cat_buffers_match_the_two_gemm_form(monkeypatch):
         monkeypatch.setenv("MGX_SAGE_CAT", cat)
         torch.manual_seed(77)
         ops.ReluDropout._calls = 0
-        m = full_graph.GraphSAGE(100, 64, 47, 3, 0.5).to(DEV)
+        m = full_graph.GraphSAGE(100, 64, 47, 3, 0.5, batch_norm).to(DEV)  # batch_norm: main_dgl_arxiv_sage.py's bn -> relu -> dropout
         m.rows_are_distinct = True
         m.train()
         out = []
