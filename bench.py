@@ -40,6 +40,29 @@ import sys
 import tempfile
 import time
 
+def host_cores():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+# Before torch is imported, for EVERY way this file is started (plain, self-launched children, the driver's
+# `python -m torch.distributed.run ... bench.py`): dmabuf IPC -- RCCL and device-tensor sharing across processes fail with
+# `hipIpcGetMemHandle: invalid argument` on this driver without it -- and a bounded OpenMP team per rank (torch.distributed.run
+# exports OMP_NUM_THREADS=1 itself when it is unset, which this leaves alone).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "dgl-0.5-benchmark_amd")
 for _p in (ROOT, PKG):
@@ -60,25 +83,10 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
 def spmm_algorithmic_bytes(n_dst, n_src, nnz, D, accumulate=False):
-    """indptr + indices + every source row once + every output row once (an accumulating launch -- out += A x,
-    the backward aggregation inside ops.SageMeanLayerFn -- also reads every output row once)."""
+    """indptr + indices + every source row once + every output row once.  `accumulate`: the extended count for an
+    accumulating launch (out += A x, the backward aggregation inside ops.SageMeanLayerFn), which also reads every output row
+    once -- reported beside the contract's figure (`frac_incl_accumulate_read`), never under `frac`."""
     return 4 * (n_dst + 1) + 4 * nnz + 4 * n_src * D + 4 * n_dst * D * (2 if accumulate else 1)
-
-
-def host_cores():
-    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota."""
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            cores = max(1, min(cores, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return cores
 
 
 def cpu_baseline(g, feat_dim, hidden, budget_s=30.0):
@@ -132,6 +140,28 @@ def cpu_baseline(g, feat_dim, hidden, budget_s=30.0):
                          "cores": cores, "seconds": round(dt, 3)}
     except Exception as err:  # a missing CPU sparse kernel must not lose the bench line
         out["second"] = {"value": None, "kind": "torch.sparse_csr @ X", "error": str(err)[:200]}
+    return out
+
+
+def profile_avg_us(tag=None):
+    """Average duration (us) of the g-SpMM kernels in the committed rocprofv3 --kernel-trace --stats summary of this same
+    command (profiles/<tag>_kernel_stats.txt, newest round by default), keyed by feature width, so that the live HIP-event
+    mean and the traced mean sit side by side in the line.  {} when no summary travels with the tree."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_stats.txt")))
+    if tag:
+        files = [f for f in files if os.path.basename(f).startswith(tag + "_")]
+    if not files:
+        return {}
+    out = {}
+    for ln in open(files[-1]):
+        m = re.match(r"void mgx::spmm_(?:rowwave32|tile)\w*_kernel<(\d+), (\d+),.*?\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s*$", ln)
+        if m:
+            vec, g, calls, _total, avg = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4), float(m.group(5))
+            for width in (64, 100):  # lane-group width G covers D = 4 G columns (D = 100: G = 32 with idle lanes)
+                if (vec * g >= width > vec * g // 2) and width not in out:
+                    out[width] = {"avg_us": avg, "calls": calls, "file": os.path.basename(files[-1])}
     return out
 
 
@@ -318,8 +348,6 @@ def main():
     del src, dst
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
 
-    y_train = y[train_idx]  # labels are constant: gathered once, outside the timed steps
-
     def make_step(model, opt, bucket):
         model.rows_are_distinct = True  # train_idx = nonzero() of a mask
 
@@ -330,6 +358,7 @@ def main():
                 bucket.zero()  # gradients are views into one flat buffer (zero_grad would drop them)
             else:
                 opt.zero_grad()
+            y_train = y[train_idx]  # main_dgl_product_sage.py:106 gathers the labels inside train()
             # default model: log_softmax on the train rows only (row-wise, so the same numbers); plain: the reference's line
             if model.plain:
                 loss = F.nll_loss(model(g, x)[train_idx], y_train, reduction="sum") / total_train
@@ -380,19 +409,26 @@ def main():
     kernels = []
     sparse_recs = [r for r in records if r.get("variant") == "row-sparse"]
     records = [r for r in records if r.get("variant") != "row-sparse"]
+    traced = profile_avg_us()
     for width in sorted({r["out_len"] for r in records if r["op"] == "copy_lhs"}):
         sel = [r for r in records if r["op"] == "copy_lhs" and r["out_len"] == width]
         durs = [r["start"].elapsed_time(r["end"]) * 1e-3 for r in sel]
         r0 = sel[0]
         avg = sum(durs) / len(durs)
-        algo = sum(spmm_algorithmic_bytes(r["n_rows"], r["n_cols"], r["nnz"], width, r.get("accumulate", False)) for r in sel) / len(sel)
+        # the contract's figure for EVERY launch; the accumulating launches' extra read of the output rows is
+        # real traffic of the fused layer and is reported beside it, under its own keys
+        algo = spmm_algorithmic_bytes(r0["n_rows"], r0["n_cols"], r0["nnz"], width)
+        algo_rmw = sum(spmm_algorithmic_bytes(r["n_rows"], r["n_cols"], r["nnz"], width, r.get("accumulate", False)) for r in sel) / len(sel)
         achieved = algo / avg / 1e9
         kernels.append({"bound": "hbm", "kernel": "g-SpMM copy_u/sum|mean, D=%d (mgx_spmm_csr)" % width, "D": width,
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                         "algorithmic_bytes_per_launch": int(algo),
+                        "frac_incl_accumulate_read": round(algo_rmw / avg / 1e9 / HBM_PEAK_GBPS, 4),
+                        "bytes_incl_accumulate_read_per_launch": int(algo_rmw),
                         "no_reuse_gather_bytes_per_launch": int(algo - 4 * r0["n_cols"] * width + 4 * r0["nnz"] * width),
                         "avg_launch_ms": round(avg * 1e3, 4), "launches_timed": len(durs),
+                        "profile_avg_us": traced.get(width),
                         "launches_per_epoch": len(durs) // max(args.steps, 1),
                         "accumulating_launches_per_epoch": sum(1 for r in sel if r.get("accumulate")) // max(args.steps, 1),
                         "rows": r0["n_rows"], "nnz": r0["nnz"]})

@@ -561,6 +561,16 @@ __global__ __launch_bounds__(kBlock) void spmm_hub_fixup_kernel(const Idx* indpt
   }
 }
 
+// used by spmm_tile.hip: the same fix-up pass after the tile kernel
+int32_t spmm_hub_fixup_launch(const mgx_csr* csr, const mgx_spmm_plan* plan, const float* partial, const float* dst_scale, float* out,
+                              int D, int mean, int accum, int ldo, hipStream_t s) {
+  hipLaunchKernelGGL((spmm_hub_fixup_kernel<int32_t>), dim3((unsigned)((plan->num_hubs + kWavesPerBlock - 1) / kWavesPerBlock)),
+                     dim3(kBlock), 0, s, (const int32_t*)csr->indptr, plan->hub_row, plan->hub_slot_ptr, plan->num_hubs, partial,
+                     dst_scale, out, D, mean, accum, ldo);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic kernel: any op x any reduce x arbitrary broadcast tables.  One wave per row, lanes over
 // output elements, serial over the row's edges (storage order => same order as the CPU oracle).
@@ -677,6 +687,7 @@ template <typename Idx, int VEC, int G, int MODE>
 static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, hipStream_t s) {
   constexpr int NB = kWave / G;
   if (a.ragged) split = true;  // only the lean row-per-wave kernel implements the ragged 16-byte tail window
+  if (a.lds != a.D || a.ldo != a.D) split = true;  // ... and row strides (spmm_fast_kernel ignores lds / ldo; MGX_SPLIT_FACTOR A/B runs)
   a.rpb = rows_per_block_setting();
   if (!split && a.rpb < kWavesPerBlock * NB) a.rpb = kWavesPerBlock * NB;  // one item per lane group
   a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);

@@ -11,6 +11,7 @@ Epoch timing follows main_dgl_product_sage.py:175-180 (epochs 1-2 discarded) but
 steady-state mean, not the reference's cumulative running mean.
 Datasets are the seeded synthetic stand-ins of mi355x_graph.datasets (no network here).
 """
+import weakref
 import argparse
 import os
 import sys
@@ -100,6 +101,11 @@ class GraphSAGE(nn.Module):
         for bn in self.bns:
             bn.reset_parameters()
 
+    def invalidate_input_cache(self):
+        """Forget the resident copy of the input features (the next forward copies them again)."""
+        if self._input_cat is not None:
+            self._input_cat[2].static_key = None
+
     def forward(self, g, x, rows=None):
         """`rows`: return the log-probabilities of these nodes only.  log_softmax is row-wise, so model(g, x, rows) ==
         model(g, x)[rows] (main_dgl_product_sage.py:105: `model(g, feats)[train_idx]`) without normalising -- forward and
@@ -109,11 +115,15 @@ class GraphSAGE(nn.Module):
         # unmodified -> kept); hidden activations are written there by relu_dropout directly.
         cat = None
         if not self.plain:
-            key = (id(g), x.shape[0], x.shape[1])
-            if self._input_cat is None or self._input_cat[0] != key:
+            # keyed on the graph OBJECT (weak reference: an id() can be reused after garbage collection) and the input shape.
+            # The buffer skips the copy of an input it already holds -- same tensor object, same version counter -- so the
+            # features must not be changed behind autograd's back (`.data` writes, raw kernels): call
+            # invalidate_input_cache() after such a write.  A step captured by utils.GraphedStep never contains the copy.
+            held = self._input_cat
+            if held is None or held[0]() is not g or held[1] != tuple(x.shape):
                 c = ops.cat_buffer_for(g, x, x.shape[1])
-                self._input_cat = (key, c) if c is not None else None
-            cat = None if self._input_cat is None or not torch.is_grad_enabled() else self._input_cat[1]
+                self._input_cat = held = (weakref.ref(g), tuple(x.shape), c) if c is not None else None
+            cat = None if held is None or not torch.is_grad_enabled() else held[2]
         for i, layer in enumerate(self.layers[:-1]):
             x = layer(g, x, cat=cat) if not self.plain else layer(g, x)
             if len(self.bns):

@@ -350,7 +350,9 @@ class DistCopyU(torch.autograd.Function):
             if static_cache is not None:
                 static_cache["version"], static_cache["recv"] = x._version, recv
         scale = plan.inv_deg if reduce == "mean" else None
-        out, _, _ = sparse.gspmm_raw(plan.loc.csc(), "copy_lhs", "sum", x, None, dst_scale=scale)
+        # dense_out: the halo aggregation below accumulates into `out` through the raw kernel (a line-padded view would be
+        # written at the wrong offsets)
+        out, _, _ = sparse.gspmm_raw(plan.loc.csc(), "copy_lhs", "sum", x, None, dst_scale=scale, dense_out=True)
         work.wait()
         if plan.n_halo:
             sparse.gspmm_raw(plan.halo.csc(), "copy_lhs", "sum", recv, None, dst_scale=scale, accumulate_into=out)
@@ -371,7 +373,7 @@ class DistCopyU(torch.autograd.Function):
         else:
             g_halo = torch.empty((0,) + feat, dtype=dZ.dtype, device=dZ.device)
         work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
-        gx = sparse.gspmm_grad_raw(plan.loc.csr(), dZ)
+        gx = sparse.gspmm_grad_raw(plan.loc.csr(), dZ, dense_out=True)  # add_returned_rows accumulates into it
         work.wait()
         plan.add_returned_rows(gx, back)
         return gx, None, None, None, None
@@ -556,16 +558,38 @@ class GradBucket(object):
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        self._attach()
+
+    def _attach(self, keep=False):
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            view = self.flat[off:off + n].view_as(p)
+            if keep and p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)  # a gradient autograd allocated afresh after the views were dropped: keep its value
+            elif keep and p.grad is None:
+                view.zero_()
+            p.grad = view
             off += n
 
+    def attached(self):
+        """True while every p.grad still aliases its slice of the flat buffer (optimizer.zero_grad(set_to_none=True) or
+        model.zero_grad() drop the views; the reduce would then see a stale buffer and the ranks would diverge silently)."""
+        off, base, esz = 0, self.flat.data_ptr(), self.flat.element_size()
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != base + off * esz or not p.grad.is_contiguous():
+                return False
+            off += p.numel()
+        return True
+
     def zero(self):
+        if not self.attached():
+            self._attach()
         self.flat.zero_()
 
     def all_reduce(self):
+        if not self.attached():  # ADVICE r02: re-attach, carrying over the gradients of this step
+            self._attach(keep=True)
         all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
 

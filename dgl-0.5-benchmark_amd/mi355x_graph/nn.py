@@ -140,7 +140,10 @@ class GATConv(nn.Module):
                 el = (feat_src * self.attn_l).sum(dim=-1).unsqueeze(-1)
                 er = (feat_dst * self.attn_r).sum(dim=-1).unsqueeze(-1)
             rst = None
-            if not get_attention and ops.gat_fused_supported(graph, feat_src):
+            # Under HIP-graph capture the fused block's attn_drop seed would be a frozen launch argument -- every replay the
+            # same mask -- so a dropping layer takes the unfused path there (nn.Dropout is capture-safe); ADVICE r02.
+            frozen_mask = self.training and self.attn_drop.p > 0.0 and feat_src.is_cuda and ops.capture_path()
+            if not get_attention and not frozen_mask and ops.gat_fused_supported(graph, feat_src):
                 # the whole block u_add_v -> leaky_relu -> edge_softmax -> attn_drop -> u_mul_e/sum without any E x H tensor
                 rst = ops.gat_fused(graph, feat_src, el, er, self.leaky_relu.negative_slope, self.attn_drop.p, self.training)
             # e and a are internal to the module: keep them in in-CSR (destination-major) edge order so that

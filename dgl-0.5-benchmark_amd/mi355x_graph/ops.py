@@ -326,6 +326,9 @@ def gat_fused(graph, feat, el, er, negative_slope=0.2, attn_drop=0.0, training=T
     p = float(attn_drop) if training else 0.0
     if not 0.0 <= p < 1.0:
         raise DGLError("gat_fused: attn_drop must be in [0, 1), got %g" % p)
+    if p > 0.0 and feat.is_cuda and capture_path():
+        raise DGLError("gat_fused: attn_drop > 0 under HIP-graph capture would replay ONE dropout mask (the seed is a launch "
+                       "argument); use the unfused operators there, as GATConv does")
     return GATFused.apply(_gidx(graph), feat, el, er, negative_slope, p)
 
 

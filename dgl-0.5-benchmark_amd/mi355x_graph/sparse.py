@@ -240,6 +240,11 @@ class HipBackend(object):
              accumulate_into=None):
         dev = self._check_dev(csr.indptr, U, E, src_scale, dst_scale, accumulate_into)
         if accumulate_into is not None:
+            # the C ABI takes a dense [num_rows, out_len] output: a strided view (e.g. gspmm_raw's line-padded wide result)
+            # would be written at the wrong offsets -- refuse it loudly (column blocks go through spmm_copy_u_strided)
+            if not accumulate_into.is_contiguous() or accumulate_into.numel() != csr.num_rows * out_len:
+                raise DGLError("gspmm: accumulate_into must be a contiguous tensor of %d x %d elements (got shape %s, strides %s)"
+                               % (csr.num_rows, out_len, tuple(accumulate_into.shape), tuple(accumulate_into.stride())))
             out = accumulate_into.view(csr.num_rows, out_len)
         else:
             out = torch.empty((csr.num_rows, out_len), dtype=torch.float32, device=dev)
@@ -283,6 +288,8 @@ class HipBackend(object):
         """copy_u / sum|mean that skips source rows whose bit is clear (exact when those rows are zero)."""
         dev = self._check_dev(csr.indptr, U2d, bits, dst_scale, accumulate_into)
         D = int(U2d.shape[1])
+        if accumulate_into is not None and (not accumulate_into.is_contiguous() or accumulate_into.numel() != csr.num_rows * D):
+            raise DGLError("spmm_copy_u_masked: accumulate_into must be a contiguous tensor of %d x %d elements" % (csr.num_rows, D))
         out = accumulate_into.view(csr.num_rows, D) if accumulate_into is not None else \
             torch.empty((csr.num_rows, D), dtype=torch.float32, device=dev)
         plan = csr.plan()
@@ -688,13 +695,15 @@ def _as_f32(t, what):
 
 _WIDE_PAD = os.environ.get("MGX_WIDE_PAD", "1") != "0"
 _WIDE_PAD_MIN = 176  # above this width the g-SpMM runs in column passes of 128 columns (csrc/spmm.hip launch_fast_v)
+_WIDE_PAD_MIN_NNZ = int(os.environ.get("MGX_WIDE_PAD_MIN_NNZ", 1 << 20))  # tests lower it to reach the path on small graphs
 
 
-def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=False, accumulate_into=None):
+def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=False, accumulate_into=None, dense_out=False):
     """out[v] = reduce_{p in row v} op(U[indices[p]], E[eids[p]]).
 
     U: (num_cols, *ushape) or None; E: (nnz, *eshape) or None.  Returns (out, arg_u, arg_e) with out of
-    shape (num_rows, *bcast(ushape, eshape))."""
+    shape (num_rows, *bcast(ushape, eshape)).  `out` may be a row-strided VIEW (the line-padded wide path below) unless
+    `dense_out` is set -- callers that hand the result to a raw kernel (accumulate_into) ask for a dense one."""
     if op not in ("add", "mul", "copy_lhs", "copy_rhs"):
         raise DGLError("gspmm_raw: unsupported op %r (sub/div are rewritten by the caller)" % op)
     U = None if op == "copy_rhs" else _as_f32(U, "gspmm lhs feature")
@@ -708,14 +717,14 @@ def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=Fa
     if E is not None and E.shape[0] != csr.nnz:
         raise DGLError("gspmm: expected %d edge rows, got %d" % (csr.nnz, E.shape[0]))
     if (op == "copy_lhs" and reduce in ("sum", "mean") and U.dim() == 2 and U.is_cuda and accumulate_into is None
-            and U.shape[1] > _WIDE_PAD_MIN and U.shape[1] % 32 and csr.nnz >= max(1 << 20, 64 * csr.num_cols) and _WIDE_PAD):
+            and U.shape[1] > _WIDE_PAD_MIN and U.shape[1] % 32 and csr.nnz >= max(_WIDE_PAD_MIN_NNZ, 64 * csr.num_cols) and _WIDE_PAD):
         # Wide rows that are not whole 128-byte lines (reddit's 602 input features: 2408-byte rows) on a dense graph: every
         # 512-byte column pass of a gathered row straddles one more line and 16-byte lanes are misaligned.  Aggregating a copy
         # padded to whole lines and returning the [:, :D] view is faster by more than the copy costs once a row is gathered
         # ~64 times (reddit-shaped, 492 in-edges per node: D = 602 18.4 ms -> 0.3 + 14.4 ms; D = 300 9.7 -> 0.2 + 8.0 ms).
         D = U.shape[1]
         out, _, _ = gspmm_raw(csr, op, reduce, torch.nn.functional.pad(U, (0, (-D) % 32)), None, src_scale, dst_scale)
-        return out[:, :D], None, None
+        return (out[:, :D].contiguous() if dense_out else out[:, :D]), None, None
     ushape = tuple(U.shape[1:]) if U is not None else ()
     eshape = tuple(E.shape[1:]) if E is not None else ()
     if U is not None and E is not None:
@@ -741,7 +750,7 @@ def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=Fa
 _SPARSE_GRAD_MIN_NNZ = int(os.environ.get("MGX_SPARSE_GRAD_MIN_NNZ", 2_000_000))
 
 
-def gspmm_grad_raw(csr, dZ, dst_scale=None, accumulate_into=None):
+def gspmm_grad_raw(csr, dZ, dst_scale=None, accumulate_into=None, dense_out=False):
     """copy_u / sum over `csr` of a GRADIENT matrix dZ [num_cols, ...]: the backward aggregation of copy_u (dX = A^T dZ).
     Gradients of a loss taken on a subset of the nodes are zero in most rows at the last layer (ogbn-products: 92 %), so the
     rows of dZ are flagged first (one streaming pass) and the aggregation skips the all-zero ones -- same sum, fewer gathers.
@@ -757,7 +766,7 @@ def gspmm_grad_raw(csr, dZ, dst_scale=None, accumulate_into=None):
         bits = be.row_nonzero_bits(flat)
         out = be.spmm_copy_u_masked(csr, "sum", flat, bits, dst_scale, accumulate_into)
         return out.view((csr.num_rows,) + tuple(dZ.shape[1:]))
-    return gspmm_raw(csr, "copy_lhs", "sum", dZ, None, dst_scale=dst_scale, accumulate_into=accumulate_into)[0]
+    return gspmm_raw(csr, "copy_lhs", "sum", dZ, None, dst_scale=dst_scale, accumulate_into=accumulate_into, dense_out=dense_out)[0]
 
 
 def gsddmm_raw(gidx, op, L, R, lhs_target="u", rhs_target="v"):

@@ -1,0 +1,291 @@
+"""Tile plans (mgx_tile_plan) for the LDS-staged g-SpMM of dense neighbourhoods (csrc/spmm_tile.hip).
+
+Why: on graphs with hundreds of in-edges per node (reddit: 492, proteins: 597; kernel/dgl-new.py:61,
+main_dgl_reddit_sage.py:73-80) the row-per-wave kernel delivers every edge's source row from L2 to a CU -- E*D*4 bytes at
+the chip's 17-19 TB/s L2 gather rate, 3-5 % of the HBM roofline -- while destination rows that the locality schedule placed
+next to each other read the SAME source rows 4.6x (reddit-shaped, 256 rows) to 7.7x (1024 rows) over.  A tile plan cuts the
+schedule into TILES of R work items (one 1024-thread workgroup each), and for every tile
+
+  * lists the tile's STAGED sources -- the ones gathered at least `tau` times inside the tile -- in CHUNKS of 127 rows; a
+    chunk is gathered ONCE from L2 into LDS (LDS-DMA, 4-deep ring) and every edge into it is then served from LDS;
+  * turns the edges into per-wave STREAMS the kernel can walk without looking at the graph again: a wave owns NACC rows per
+    16-lane group (4 groups: 4 * NACC rows), one accumulator register set per row, statically indexed; a stream STEP holds one
+    LDS slot (1 byte) per lane group, rows are padded to 4-step SUPERSTEPS with the chunk's all-zero slot, so the inner loop
+    is branch-free: 4 x (slot -> ds_read_b128) then 4 x add;
+  * sends the remaining edges (sources used once in the tile: no reuse to exploit) down a DIRECT stream of source ids that
+    the same waves gather from global memory into the same accumulators afterwards.
+
+Work items are the (row | hub chunk, edge range) items of an mgx_spmm_plan, so hub rows stay split and their partial sums go
+through the same fix-up kernel.  Inside a tile, items are ranked by length; 4 consecutive ranks share a wave-instruction
+(similar lengths: little padding) and the quads are dealt to the waves boustrophedon (similar work per wave: the per-chunk
+barrier waits for the slowest).  Integer preprocessing, once per CSR, like the CSR build itself; torch sorts on the device.
+"""
+import ctypes
+import os
+
+import torch
+
+GROUPS = 4          # 16-lane groups of a wave (one 64-column pass: 16 lanes x float4)
+CHUNK_SLOTS = 128   # LDS rows per chunk: 127 staged sources + the all-zero slot
+ZERO_SLOT = CHUNK_SLOTS - 1
+TILE_WAVES = 16     # 1024-thread workgroups
+NO_ITEM = -(2 ** 31)
+STREAM_TAIL = 64    # padding SUPERSTEPS behind every stream (the kernel prefetches two supersteps ahead, unconditionally)
+
+
+class MgxTilePlan(ctypes.Structure):
+    _fields_ = [
+        ("num_tiles", ctypes.c_int64),
+        ("num_chunks", ctypes.c_int64),
+        ("lds_steps", ctypes.c_int64),
+        ("dir_steps", ctypes.c_int64),
+        ("consumers", ctypes.c_int32),
+        ("nacc", ctypes.c_int32),
+        ("loaders", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("tile_chunk_ptr", ctypes.c_void_p),
+        ("chunk_ids", ctypes.c_void_p),
+        ("lds_off", ctypes.c_void_p),
+        ("lds_cnt", ctypes.c_void_p),
+        ("lds_stream", ctypes.c_void_p),
+        ("dir_off", ctypes.c_void_p),
+        ("dir_cnt", ctypes.c_void_p),
+        ("dir_stream", ctypes.c_void_p),
+        ("tile_item", ctypes.c_void_p),
+        ("zero_row", ctypes.c_void_p),
+    ]
+
+
+class TilePlan(object):
+    """Device tables of one tile plan (see build_tile_plan); `base` is the SpmmPlan whose items it tiles."""
+
+    def __init__(self, base, consumers, nacc, loaders, tables, stats):
+        self.base, self.consumers, self.nacc, self.loaders = base, int(consumers), int(nacc), int(loaders)
+        self.__dict__.update(tables)
+        self.stats = stats
+        self._c = None
+
+    @property
+    def rows_per_tile(self):
+        return self.consumers * self.nacc * GROUPS
+
+    @property
+    def num_tiles(self):
+        return int(self.tile_chunk_ptr.shape[0]) - 1
+
+    @property
+    def num_chunks(self):
+        return int(self.chunk_ids.shape[0]) // CHUNK_SLOTS
+
+    def c_struct(self):
+        if self._c is None:
+            p = lambda t: t.data_ptr() if t.numel() else None
+            self._c = MgxTilePlan(self.num_tiles, self.num_chunks, int(self.lds_stream.shape[0]) // GROUPS - STREAM_TAIL,
+                                  int(self.dir_stream.shape[0]) // (4 * GROUPS) - STREAM_TAIL,
+                                  self.consumers, self.nacc, self.loaders, 0, p(self.tile_chunk_ptr), p(self.chunk_ids), p(self.lds_off),
+                                  p(self.lds_cnt), p(self.lds_stream), p(self.dir_off), p(self.dir_cnt), p(self.dir_stream),
+                                  p(self.tile_item), p(self.zero_row))
+        return self._c
+
+
+def _excl_cumsum(x):
+    out = torch.zeros(x.shape[0] + 1, dtype=torch.int64, device=x.device)
+    torch.cumsum(x, 0, out=out[1:])
+    return out
+
+
+def _streams(seg_key, nseg, payload, pad, dtype):
+    """Edges with segment key (((unit * NC + cw) * NACC + j) * 4 + g) -> (superstep counts per (unit, cw, j), first superstep of
+    each, stream).  A (unit, cw, j) row of the stream has max_g(count) steps rounded up to whole SUPERSTEPS (4 steps); layout
+    [superstep][lane group g][step u]: one payload per entry, `pad` where a group has run out.  Edges keep their storage order
+    inside a group (stable sort)."""
+    dev = seg_key.device
+    cnt4 = torch.bincount(seg_key, minlength=nseg * GROUPS)
+    steps = cnt4.view(nseg, GROUPS).max(dim=1)[0]
+    ssteps = (steps + 3) // 4
+    base = _excl_cumsum(ssteps)  # first superstep of every (unit, cw, j)
+    total = int(base[-1])
+    stream = torch.full(((total + STREAM_TAIL) * GROUPS * 4,), pad, dtype=dtype, device=dev)
+    if seg_key.numel():
+        order = torch.sort(seg_key, stable=True)[1]
+        sk = seg_key[order]
+        seg_start = _excl_cumsum(cnt4)
+        rank = torch.arange(sk.shape[0], device=dev) - seg_start[sk]
+        idx = ((base[sk // GROUPS] + rank // 4) * GROUPS + (sk % GROUPS)) * 4 + rank % 4
+        stream[idx] = payload[order].to(dtype)
+    return ssteps, base, stream
+
+
+def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2):
+    """csr: CsrView (int32, device or host); base: SpmmPlan over it (items in schedule order; None = natural rows)."""
+    dev = csr.indptr.device
+    NC, NACC = int(consumers), int(nacc)
+    if NC + int(loaders) != TILE_WAVES or not 1 <= NACC <= 8 or int(loaders) not in (2, 4):
+        raise ValueError("tile plan: consumers + loaders must be %d, nacc in 1..8, loaders 2 or 4" % TILE_WAVES)
+    R = NC * NACC * GROUPS
+    n_src = csr.num_cols
+    if base is not None:
+        item_row = base.item_row.long()
+        beg, end = base.item_beg.long(), base.item_end.long()
+    else:
+        item_row = torch.arange(csr.num_rows, device=dev)
+        beg, end = csr.indptr[:-1].long(), csr.indptr[1:].long()
+    I = int(item_row.shape[0])
+    T = (I + R - 1) // R
+    lens = end - beg
+    E = int(lens.sum())
+    it_tile = torch.arange(I, device=dev) // R
+    # ---- position of every item inside its tile: rank by length, quads of ranks, quads dealt to the waves back and forth
+    maxlen = int(lens.max()) if I else 0
+    order = torch.sort(it_tile * (maxlen + 1) + (maxlen - lens), stable=True)[1]
+    rank = torch.empty(I, dtype=torch.int64, device=dev)
+    rank[order] = torch.arange(I, device=dev) - it_tile[order] * R
+    quad, g = rank // GROUPS, rank % GROUPS
+    rnd, w = quad // NC, quad % NC
+    cw = torch.where(rnd % 2 == 0, w, NC - 1 - w)
+    pos = (cw * NACC + rnd) * GROUPS + g
+    tile_item = torch.full((T * R,), NO_ITEM, dtype=torch.int64, device=dev)
+    tile_item[it_tile * R + pos] = item_row
+    # ---- edges: (tile, position in tile, source)
+    e_item = torch.repeat_interleave(torch.arange(I, device=dev), lens)
+    first = _excl_cumsum(lens)[:-1]
+    e_src = csr.indices[beg[e_item] + (torch.arange(E, device=dev) - first[e_item])].long()
+    e_tile, e_pos = it_tile[e_item], pos[e_item]
+    del e_item, first
+    # ---- sources gathered >= tau times inside a tile are staged; per tile they are ordered by multiplicity (dense chunks first)
+    skey, perm = torch.sort(e_tile * n_src + e_src)
+    uniq, inv, counts = torch.unique_consecutive(skey, return_inverse=True, return_counts=True)
+    del skey
+    g_tile, g_src = uniq // n_src, uniq % n_src
+    sel = torch.nonzero(counts >= tau).flatten()
+    st, sc = g_tile[sel], counts[sel]
+    maxc = int(sc.max()) if sel.numel() else 0
+    o2 = torch.sort(st * (maxc + 1) + (maxc - sc), stable=True)[1]
+    sel = sel[o2]
+    st = g_tile[sel]
+    per_tile = torch.bincount(st, minlength=T)
+    rank_in_tile = torch.arange(sel.shape[0], device=dev) - _excl_cumsum(per_tile)[st]
+    real = CHUNK_SLOTS - 1
+    tile_chunk_ptr = _excl_cumsum((per_tile + real - 1) // real)
+    NCH = int(tile_chunk_ptr[-1])
+    s_chunk = tile_chunk_ptr[st] + rank_in_tile // real
+    s_slot = rank_in_tile % real
+    chunk_ids = torch.full((NCH * CHUNK_SLOTS,), -1, dtype=torch.int32, device=dev)
+    chunk_ids[s_chunk * CHUNK_SLOTS + s_slot] = g_src[sel].to(torch.int32)
+    grp_chunk = torch.full((uniq.shape[0],), -1, dtype=torch.int64, device=dev)
+    grp_slot = torch.zeros(uniq.shape[0], dtype=torch.int64, device=dev)
+    grp_chunk[sel], grp_slot[sel] = s_chunk, s_slot
+    # back to storage order of the edges (so that the streams keep it inside every lane group)
+    e_chunk = torch.empty(E, dtype=torch.int64, device=dev)
+    e_slot = torch.empty(E, dtype=torch.int64, device=dev)
+    e_chunk[perm], e_slot[perm] = grp_chunk[inv], grp_slot[inv]
+    del perm, inv, grp_chunk, grp_slot, uniq
+    staged = e_chunk >= 0
+    # ---- LDS streams: one per (chunk, consumer wave)
+    per_unit = NC * NACC * GROUPS
+    sk = e_chunk[staged] * per_unit + e_pos[staged]
+    lds_cnt, lds_base, lds_bytes = _streams(sk, NCH * NC * NACC, e_slot[staged], ZERO_SLOT, torch.uint8)
+    lds_off = lds_base.view(-1)[::NACC].clone() if NCH else torch.zeros(1, dtype=torch.int64, device=dev)
+    # ---- direct streams: one per (tile, consumer wave)
+    direct = ~staged
+    dk = e_tile[direct] * per_unit + e_pos[direct]
+    dir_cnt, dir_base, dir_stream = _streams(dk, T * NC * NACC, e_src[direct], -1, torch.int32)
+    dir_off = dir_base.view(-1)[::NACC].clone()
+    if int(lds_cnt.max() if lds_cnt.numel() else 0) > 65535:
+        raise ValueError("tile plan: more than 65535 supersteps in one (chunk, row)")
+
+    def cnt8(c, units, dtype):  # [units * NC, 8] with NACC live columns
+        out = torch.zeros((units * NC, 8), dtype=dtype, device=dev)
+        if units:
+            out[:, :NACC] = c.view(units * NC, NACC).to(dtype)
+        return out.view(-1)
+
+    n_staged = int(staged.sum())
+    stats = {"tiles": T, "rows_per_tile": R, "chunks": NCH, "edges": E, "staged_edges": n_staged, "direct_edges": E - n_staged,
+             "staged_sources": int(sel.shape[0]), "lds_supersteps": int(lds_bytes.shape[0]) // (4 * GROUPS) - STREAM_TAIL,
+             "dir_supersteps": int(dir_stream.shape[0]) // (4 * GROUPS) - STREAM_TAIL,
+             "gathered_rows_per_edge": (int(sel.shape[0]) + E - n_staged) / max(E, 1),
+             "lds_slot_fill": n_staged / max(int(lds_bytes.shape[0]) - STREAM_TAIL * GROUPS * 4, 1),
+             "dir_slot_fill": (E - n_staged) / max(int(dir_stream.shape[0]) - STREAM_TAIL * GROUPS * 4, 1)}
+    tables = {
+        "tile_chunk_ptr": tile_chunk_ptr.to(torch.int32),
+        "chunk_ids": chunk_ids,
+        "lds_off": lds_off.to(torch.int32),            # [NCH * NC + 1] first superstep of (chunk, cw); the last entry closes the table
+        "lds_cnt": cnt8(lds_cnt, NCH, torch.int16),    # supersteps of (chunk, cw, j), 8 uint16 per (chunk, cw)
+        "lds_stream": lds_bytes.view(torch.int32) if lds_bytes.numel() else torch.zeros(0, dtype=torch.int32, device=dev),
+        "dir_off": dir_off.to(torch.int32),            # [T * NC + 1]
+        "dir_cnt": cnt8(dir_cnt, T, torch.int32),      # supersteps of (tile, cw, j), 8 int32 per (tile, cw)
+        "dir_stream": dir_stream,                      # [dir_supersteps * 16] source ids, -1 = padding
+        "tile_item": tile_item.to(torch.int32),        # [T * R] item_row of the item at every position, NO_ITEM = none
+        "zero_row": torch.zeros(64, dtype=torch.float32, device=dev),
+    }
+    if int(lds_base[-1]) * 4 >= 2 ** 31 or int(dir_base[-1]) * 16 >= 2 ** 31:
+        raise ValueError("tile plan: stream offsets exceed 31 bits")
+    return TilePlan(base, NC, NACC, loaders, tables, stats)
+
+
+def emulate(plan, x, out_rows, num_slots=0):
+    """Walks a tile plan on the host exactly as the kernel does (same streams, same padding) and returns
+    (out [out_rows, D], partial [num_slots, D]) in float64 -- the structural check of build_tile_plan used by tests/ (CPU)."""
+    import numpy as np
+    x = x.detach().cpu().double().numpy()
+    D = x.shape[1]
+    NC, NACC, R = plan.consumers, plan.nacc, plan.rows_per_tile
+    tcp = plan.tile_chunk_ptr.cpu().numpy()
+    ids = plan.chunk_ids.cpu().numpy()
+    lds_off, lds_cnt = plan.lds_off.cpu().numpy(), plan.lds_cnt.cpu().numpy().astype(np.uint16).reshape(-1, 8)
+    lds_stream = plan.lds_stream.cpu().numpy().view(np.uint8).reshape(-1, GROUPS, 4)  # [superstep][group][step]
+    dir_off, dir_cnt = plan.dir_off.cpu().numpy(), plan.dir_cnt.cpu().numpy().reshape(-1, 8)
+    dir_stream = plan.dir_stream.cpu().numpy().reshape(-1, GROUPS, 4)
+    tile_item = plan.tile_item.cpu().numpy()
+    out = np.zeros((out_rows, D))
+    partial = np.zeros((max(num_slots, 1), D))
+    for t in range(plan.num_tiles):
+        acc = np.zeros((R, D))
+        for c in range(tcp[t], tcp[t + 1]):
+            lds = np.zeros((CHUNK_SLOTS, D))
+            cid = ids[c * CHUNK_SLOTS:(c + 1) * CHUNK_SLOTS]
+            assert cid[ZERO_SLOT] == -1
+            lds[cid >= 0] = x[cid[cid >= 0]]
+            for cw in range(NC):
+                k = c * NC + cw
+                ss = lds_off[k]
+                for j in range(NACC):
+                    for _ in range(int(lds_cnt[k, j])):
+                        for g in range(GROUPS):
+                            for u in range(4):
+                                acc[(cw * NACC + j) * GROUPS + g] += lds[lds_stream[ss, g, u]]
+                        ss += 1
+                assert ss == lds_off[k + 1]
+        for cw in range(NC):
+            k = t * NC + cw
+            ss = dir_off[k]
+            for j in range(NACC):
+                for _ in range(int(dir_cnt[k, j])):
+                    for g in range(GROUPS):
+                        for u in range(4):
+                            sid = dir_stream[ss, g, u]
+                            if sid >= 0:
+                                acc[(cw * NACC + j) * GROUPS + g] += x[sid]
+                    ss += 1
+            assert ss == dir_off[k + 1]
+        for p in range(R):
+            it = tile_item[t * R + p]
+            if it == NO_ITEM:
+                assert not acc[p].any()
+            elif it >= 0:
+                out[it] += acc[p]
+            else:
+                partial[-(it + 1)] += acc[p]
+    return out, partial
+
+
+def tile_plan_wanted(csr):
+    """Policy: dense neighbourhoods only -- the kernel pays when a staged source is re-used often enough inside a tile.
+    MGX_TILE=0 disables, =1 forces (tests)."""
+    mode = os.environ.get("MGX_TILE", "auto")
+    if mode == "0" or csr.idx_bits != 32 or not csr.indptr.is_cuda or csr.nnz == 0:
+        return False
+    if mode == "1":
+        return True
+    return csr.nnz >= (1 << 22) and csr.nnz >= 128 * csr.num_rows

@@ -35,7 +35,7 @@ pos[perm] = torch.arange(n)
 row_of_edge = torch.repeat_interleave(torch.arange(n), deg)
 E = indices.numel()
 for label, p in (("natural", torch.arange(n)), ("schedule", pos)):
-    for R in (16, 64, 256):
+    for R in (16, 64, 128, 256, 512, 1024):
         tile = (p[row_of_edge] // R).numpy()
         key = tile * np.int64(n) + indices.numpy()
         distinct = np.unique(key).shape[0]

@@ -175,6 +175,43 @@ int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan /*
                                 const float* ufeat, int64_t D, int64_t u_stride, const float* dst_scale /* may be NULL */,
                                 float* out, int64_t out_stride, float* partial_ws, int32_t flags, void* stream);
 
+/* LDS-staged copy_u / sum | mean for DENSE neighbourhoods (round 3; csrc/spmm_tile.hip).  On graphs with hundreds of in-edges
+ * per node (reddit, proteins: kernel/dgl-new.py:61; main_dgl_reddit_sage.py:73-80) destination rows scheduled next to each other
+ * share most of their sources; a TILE of consumers * nacc * 4 work items of the schedule is aggregated by one 1024-thread
+ * workgroup that gathers each of the tile's re-used sources ONCE from L2 into LDS (chunks of 127 rows x 64 columns, LDS-DMA,
+ * 4-deep ring, `loaders` loader waves) and serves every edge into it from LDS; sources used once in the tile are gathered
+ * directly.  The tables below replace the graph arrays inside the kernel (built once per CSR by the host layer,
+ * mi355x_graph/tileplan.py; all device memory, caller-owned):
+ *   tile_chunk_ptr [num_tiles+1]            chunks of tile t are [ptr[t], ptr[t+1])
+ *   chunk_ids      [num_chunks*128]         source row of every LDS slot, -1 = all-zero row (slot 127 always)
+ *   lds_off        [num_chunks*consumers+1] first step of the stream of (chunk, consumer wave)
+ *   lds_cnt        [num_chunks*consumers*8] uint16 supersteps (4 steps) of (chunk, wave, accumulator j < nacc)
+ *   lds_stream     [lds_steps]              one byte per lane group and step: the LDS slot to add (127 = zero row)
+ *   dir_off / dir_cnt (int32) / dir_stream  the same per (tile, wave) for the direct part; dir_stream holds 4 source ids
+ *                                           per step, -1 = padding
+ *   tile_item      [num_tiles*R]            item_row of the work item at every (wave, j, lane group), INT32_MIN = none
+ *   zero_row       [64] floats of zeros
+ * Work items are those of `plan` (hub rows stay split: partial_ws / fix-up as for mgx_spmm_csr; plan may be NULL when the tile
+ * plan was built over natural rows).  32-bit indices, D and both strides multiples of 4, 16-byte aligned operands, gathered
+ * matrix below 4 GiB; otherwise MGX_ERR_UNSUPPORTED (call mgx_spmm_csr).  Deterministic: no atomics. */
+typedef struct mgx_tile_plan {
+  int64_t num_tiles, num_chunks, lds_steps, dir_steps;
+  int32_t consumers, nacc, loaders, reserved;
+  const int32_t* tile_chunk_ptr;
+  const int32_t* chunk_ids;
+  const int32_t* lds_off;
+  const uint16_t* lds_cnt;
+  const uint32_t* lds_stream;
+  const int32_t* dir_off;
+  const int32_t* dir_cnt;
+  const int32_t* dir_stream;
+  const int32_t* tile_item;
+  const float* zero_row;
+} mgx_tile_plan;
+int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, const mgx_tile_plan* tile_plan,
+                             int32_t reduce, const float* ufeat, int64_t D, int64_t u_stride, const float* dst_scale /* may be NULL */,
+                             float* out, int64_t out_stride, float* partial_ws, int32_t flags, void* stream);
+
 /* ------------------------------------------------------------------ g-SDDMM
  * Replaces _CAPI_DGLKernelSDDMM as reached by dgl.ops.gsddmm (kernel/dgl-new.py:39),
  * apply_edges(fn.u_add_v) inside GATConv (main_dgl_reddit_gat.py:10) and fn.u_dot_v
