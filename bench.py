@@ -229,6 +229,7 @@ def main():
     p.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     p.add_argument("--no-controls", action="store_true", help="skip the control graphs (roofline.controls)")
     p.add_argument("--no-plain", action="store_true", help="skip the plain-torch-module epoch (epoch_ms_plain_model)")
+    p.add_argument("--dropout", type=float, default=None, help="override the model's dropout (tests compare N = 1 and N > 1 at 0)")
     args = p.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -269,7 +270,9 @@ def main():
     from mi355x_graph import dist as mdist, ops, sparse
     from mi355x_graph.datasets import SHAPES, synthetic_edges
 
-    cfg = full_graph.SAGE_CONFIGS[args.dataset]
+    cfg = dict(full_graph.SAGE_CONFIGS[args.dataset])
+    if args.dropout is not None:
+        cfg["dropout"] = args.dropout
     spec = SHAPES[cfg["dataset"]]
     n = max(64, int(spec["n"] * args.scale))
     m = max(64, int(spec["m"] * args.scale))
@@ -459,7 +462,9 @@ def main():
                                 "1 GPU" if world == 1 else "edge-cut partition over %d GPUs, RCCL all_to_all halo" % world),
                    "spmm_per_epoch": 2 * cfg["num_layers"] - 1, "final_loss": loss,
                    "schedule": os.environ.get("MGX_SCHEDULE", "auto"), "partition": part_stats,
-                   "module_graph": "full_graph.GraphSAGE: the reference module graph; dense layers with this package's gradient helpers",
+                   "module_graph": "full_graph.GraphSAGE (default form): a SAGE layer as ONE GEMM on [h | mean_agg(h)], the same form on "
+                                   "one GPU and on every rank of a partition (dist.DistSageMeanCatFn: halo exchange inside the layer)",
+                   "dropout": cfg["dropout"],
                    "dense_gemm_selection": tunable.status()},
     }
 

@@ -5,8 +5,9 @@
 // 492, proteins 597), where that kernel is pinned at the L2 -> CU gather rate (every edge re-fetches its source row from L2:
 // 17-19 TB/s, 3-5 % of the HBM roofline) although destination rows scheduled next to each other share most of their sources.
 //
-// One 1024-thread workgroup (16 waves) owns a TILE of R = consumers * NACC * 4 work items of the schedule and walks the
-// tables of an mgx_tile_plan (mi355x_graph/tileplan.py):
+// One workgroup of W waves (16: one per CU with a 4-chunk ring; or 8: TWO per CU with a 2-chunk ring each, so that one tile's
+// barrier waits, direct part and epilogue overlap the other's LDS work) owns a TILE of R = consumers * NACC * 4 work items of
+// the schedule and walks the tables of an mgx_tile_plan (mi355x_graph/tileplan.py):
 //   * LOADER waves (NL of the 16) gather the tile's staged sources chunk by chunk (127 rows + one all-zero row, 64 columns
 //     = 32 KiB) from L2 into a 4-deep LDS ring with LDS-DMA (global_load_lds_dwordx4: per-lane source address = a row
 //     gather, no VGPR round trip); they run up to three chunks ahead of the consumers, paced by ONE workgroup barrier per chunk
@@ -25,14 +26,12 @@
 
 namespace mgx {
 
-constexpr int kTileThreads = 1024;
-constexpr int kTileWaves = kTileThreads / kWave;
 constexpr int kChunkSlots = 128;                        // LDS rows per chunk (127 staged + the zero row)
 constexpr int kPassCols = 64;                           // columns per pass: 16 lanes x float4
 constexpr int kSlotBytes = kPassCols * 4;               // 256
 constexpr int kChunkBytes = kChunkSlots * kSlotBytes;   // 32 KiB
-constexpr int kRing = 4;                                // chunks resident in LDS
 constexpr int kDmaPerChunk = kChunkBytes / 1024;        // LDS-DMA wave-instructions (1 KiB each) per chunk
+constexpr int kStreamRingBytes = 1024;                  // per consumer wave: 4 stream windows of 16 supersteps x 16 bytes
 constexpr int kNoItem = INT32_MIN;
 
 struct TileArgs {
@@ -54,7 +53,15 @@ struct TileArgs {
   int num_tiles, tiles_per_xcd;
   int D, lds, ldo;  // columns, row strides (floats) of x and out
   int mean, accum;
+#ifdef MGX_TILE_STAMPS
+  unsigned long long* stamps;  // diagnostic build only: [num_tiles][16 waves][8] cycles (barrier wait, work, direct, total, ...)
+#endif
 };
+
+#ifdef MGX_TILE_STAMPS
+static unsigned long long* g_tile_stamps = nullptr;
+#define MGX_STAMP() __builtin_amdgcn_s_memtime()
+#endif
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
@@ -75,9 +82,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // ---- loader waves ---------------------------------------------------------------------------------------------------------
-template <int NL>
-__device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, int wave, int lane, int cbeg, int n, int col0) {
+template <int W, int NL, int RING>
+__device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, int wave, int lane, int tile, int cbeg, int n, int col0) {
   constexpr int PER = kDmaPerChunk / NL;  // DMA instructions per loader wave per chunk
+  static_assert((RING - 2) * PER <= 48, "the counted vmcnt wait must stay below the 6-bit counter");
   const int g = lane >> 4, l = lane & 15;
   const int col = col0 + l * 4;
   const bool cvalid = col < a.D;
@@ -88,7 +96,7 @@ __device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, int w
   // load would sit on the same in-order counter as the DMA and every wait for it would drain the chunks in flight.
   auto issue = [&](int k) {  // chunk k of this tile -> ring slot k % kRing; this wave's rows [wave * PER * 4, +PER * 4)
     const auto* ids = as_const(reinterpret_cast<const v4i*>(a.chunk_ids + (int64_t)(cbeg + k) * kChunkSlots + wave * (PER * 4)));
-    char* dst = ring + (k % kRing) * kChunkBytes + wave * (PER * 1024);
+    char* dst = ring + (k % RING) * kChunkBytes + wave * (PER * 1024);
     v4i q[PER];  // rows 4 i .. 4 i + 3 of this wave's share: one per lane group; all requested before the first is used
 #pragma unroll
     for (int i = 0; i < PER; ++i) q[i] = ids[i];
@@ -103,23 +111,46 @@ __device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, int w
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
     }
   };
-  const int pre = n < kRing - 1 ? n : kRing - 1;
+  const int pre = n < RING - 1 ? n : RING - 1;
+#ifdef MGX_TILE_STAMPS
+  unsigned long long t_wait = 0, t_bar = 0, t_issue = 0;
+  const unsigned long long t_begin = MGX_STAMP();
+#endif
   for (int k = 0; k < pre; ++k) issue(k);
   for (int c = 0; c < n; ++c) {
     const int rem = n - 1 - c;  // chunks issued after c that may stay in flight
-    if (rem >= 2) wait_vmcnt<2 * PER>();
-    else if (rem == 1) wait_vmcnt<PER>();
+#ifdef MGX_TILE_STAMPS
+    const unsigned long long t0 = MGX_STAMP();
+#endif
+    if (RING >= 4 && rem >= 2) wait_vmcnt<(RING >= 4 ? 2 : 0) * PER>();  // chunks c + 1, c + 2 may stay in flight
+    else if (RING >= 3 && rem >= 1) wait_vmcnt<(RING >= 3 ? 1 : 0) * PER>();
     else wait_vmcnt<0>();
+#ifdef MGX_TILE_STAMPS
+    const unsigned long long t1 = MGX_STAMP();
+#endif
     __builtin_amdgcn_s_barrier();  // chunk c has landed; every consumer has finished chunk c - 1
     asm volatile("" ::: "memory");
-    if (c + kRing - 1 < n) issue(c + kRing - 1);  // into the slot chunk c - 1 occupied
+#ifdef MGX_TILE_STAMPS
+    const unsigned long long t2 = MGX_STAMP();
+#endif
+    if (c + RING - 1 < n) issue(c + RING - 1);  // into the slot chunk c - 1 occupied
+#ifdef MGX_TILE_STAMPS
+    const unsigned long long t3 = MGX_STAMP();
+    t_wait += t1 - t0; t_bar += t2 - t1; t_issue += t3 - t2;
+#endif
   }
+#ifdef MGX_TILE_STAMPS
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((int64_t)tile * 16 + wave) * 8;
+    o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = MGX_STAMP() - t_begin; o[4] = n;
+  }
+#endif
 }
 
 // ---- consumer waves -------------------------------------------------------------------------------------------------------
-template <int NACC, int NL>
-__device__ __forceinline__ void tile_consumer(const TileArgs& a, const char* ring, int cw, int lane, int tile, int cbeg, int n, int col0) {
-  constexpr int NC = kTileWaves - NL;
+template <int W, int NL, int NACC, int RING>
+__device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int cw, int lane, int tile, int cbeg, int n, int col0) {
+  constexpr int NC = W - NL;
   constexpr int R = NC * NACC * 4;
   const int g = lane >> 4, l = lane & 15;
   const int col = col0 + l * 4;
@@ -127,80 +158,191 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, const char* rin
   v4f acc[NACC];
 #pragma unroll
   for (int j = 0; j < NACC; ++j) acc[j] = (v4f)(0.f);
+#ifdef MGX_TILE_STAMPS
+  unsigned long long t_bar = 0, t_lds = 0, t_dir = 0, n_ss = 0;
+  const unsigned long long t_begin = MGX_STAMP();
+#endif
 
-  // ---- staged part: chunks from LDS.  Stream layout [superstep][lane group][4 steps]: a lane reads ONE dword per superstep (its
-  // group's four slot bytes; 16 lanes share the address, a wave reads 16 contiguous bytes), two supersteps ahead of its use --
-  // the stream is contiguous over the rows (j) and chunks of a wave and padded behind its end, so the prefetch never branches.
+  // The per-wave STREAMS are read once from HBM, 16 bytes (LDS part) or 64 bytes (direct part) per superstep and wave: a
+  // register prefetch two supersteps ahead exposes an HBM miss per cache line (measured: 3.7 us per chunk of 12 supersteps).
+  // Instead every consumer wave DMAs its own stream into a private LDS ring, a WINDOW of 16 supersteps per wave-instruction
+  // (one coalesced 256-byte / 1-KiB read), two windows = 32 supersteps ahead of its use; the words then come from LDS.  The
+  // window test is the only branch of the inner loop and has no register results (a load into registers under that branch
+  // made hipcc wait for it at the loop's back edge).  Window k is complete when at most ONE younger DMA is outstanding.
+  // ---- staged part: chunks from LDS.  Stream layout [superstep][lane group][4 steps]: one dword per lane group and superstep.
   if (n > 0) {
-    const auto* off = as_const(a.lds_off);
-    const auto* cnt = as_const(reinterpret_cast<const v4u*>(a.lds_cnt));
+    const auto* cnt = as_const(reinterpret_cast<const v4u*>(a.lds_cnt));  // 16 uint16 = two quads per (chunk, wave)
     int64_t k = (int64_t)cbeg * NC + cw;
-    const uint32_t* sp = a.lds_stream + (int64_t)off[k] * 4 + g;
-    uint32_t w0 = sp[0], w1 = sp[4];
-    sp += 8;
+    const uint32_t* gs = a.lds_stream + (int64_t)as_const(a.lds_off)[(int64_t)tile * NC + cw] * 4 + lane;
+    char* swin = ring + RING * kChunkBytes + cw * kStreamRingBytes;  // 4 windows x 256 bytes
+    auto dma = [&](int wi) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gs + (int64_t)wi * 64), (lds_ptr_t)(swin + (wi & 3) * 256), 4, 0, 0);
+    };
+    dma(0);
+    dma(1);
+    wait_vmcnt<1>();
+    dma(2);
+    int ss = 0;      // supersteps of this wave's stream consumed so far
+    int ready = 16;  // supersteps [0, ready) are in the LDS ring
+    auto word = [&](int i) -> uint32_t { return *reinterpret_cast<const uint32_t*>(swin + (i & 63) * 16 + g * 4); };
+    auto open_window = [&](int upto) {  // make the stream words up to superstep `upto` readable
+      if (upto >= ready) {
+        wait_vmcnt<1>();
+        dma((ready >> 4) + 2);
+        ready += 16;
+      }
+    };
+    uint32_t w0 = word(0), w1 = word(1);  // the next two supersteps
     for (int c = 0; c < n; ++c) {
-      const v4u cq = cnt[k];
-      const uint32_t cnts[4] = {cq.x, cq.y, cq.z, cq.w};
+      const v4u cq = cnt[2 * k];
+      const v4u cr = NACC > 8 ? cnt[2 * k + 1] : (v4u)(0u);
+      const uint32_t cnts[8] = {cq.x, cq.y, cq.z, cq.w, cr.x, cr.y, cr.z, cr.w};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the previous chunk has returned
+#ifdef MGX_TILE_STAMPS
+      const unsigned long long tb0 = MGX_STAMP();
+#endif
       __builtin_amdgcn_s_barrier();                         // chunk c is in its ring slot
       asm volatile("" ::: "memory");
-      const uint32_t lrow = (uint32_t)(c % kRing) * kChunkBytes + (uint32_t)l * 16u;
+#ifdef MGX_TILE_STAMPS
+      const unsigned long long tb1 = MGX_STAMP();
+      t_bar += tb1 - tb0;
+      const int ss_before = ss;
+#endif
+      const uint32_t lrow = (uint32_t)(c % RING) * kChunkBytes + (uint32_t)l * 16u;
+      auto gather4 = [&](uint32_t w, v4f (&v)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4f*>(ring + ((((w >> (8 * u)) & 0xffu) << 8) + lrow));
+      };
 #pragma unroll
       for (int j = 0; j < NACC; ++j) {
         const int nss = (int)((cnts[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
-        for (int s = 0; s < nss; ++s) {
-          const uint32_t w = w0;
+        int s = 0;
+        for (; s + 2 <= nss; s += 2) {  // two supersteps = 8 LDS rows in flight per lane group
+          open_window(ss + 3);
+          const uint32_t n0 = word(ss + 2), n1 = word(ss + 3);
+          v4f va[4], vb[4];
+          gather4(w0, va);
+          gather4(w1, vb);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += va[u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += vb[u];
+          w0 = n0;
+          w1 = n1;
+          ss += 2;
+        }
+        if (s < nss) {
+          open_window(ss + 2);
+          const uint32_t n1 = word(ss + 2);
+          v4f va[4];
+          gather4(w0, va);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += va[u];
           w0 = w1;
-          w1 = *sp;
-          sp += 4;
-          v4f v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint32_t slot = (w >> (8 * u)) & 0xffu;
-            v[u] = *reinterpret_cast<const v4f*>(ring + ((slot << 8) + lrow));
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc[j] += v[u];
+          w1 = n1;
+          ss += 1;
         }
       }
+#ifdef MGX_TILE_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t_lds += MGX_STAMP() - tb1;
+      n_ss += ss - ss_before;
+#endif
       k += NC;
     }
   }
 
-  // ---- direct part: sources used once in this tile, gathered from global memory.  Stream layout [superstep][lane group][4 ids].
+  // ---- direct part: sources used once in this tile, gathered from global memory.  Stream layout [superstep][lane group][4 ids]
+  // = 64 bytes per superstep; its windows (1 KiB) live where the chunk ring was: every consumer has left the staged part
+  // (barrier; the loader waves have exited and no longer count).
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef MGX_TILE_STAMPS
+  const unsigned long long td0 = MGX_STAMP();
+#endif
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#ifdef MGX_TILE_STAMPS
+  const unsigned long long td1 = MGX_STAMP();
+#endif
   {
     const int64_t k = (int64_t)tile * NC + cw;
     const int so = as_const(a.dir_off)[k], se = as_const(a.dir_off)[k + 1];  // supersteps
     if (se > so) {
-      const v4u c0 = as_const(reinterpret_cast<const v4u*>(a.dir_cnt))[k * 2];
-      const v4u c1 = as_const(reinterpret_cast<const v4u*>(a.dir_cnt))[k * 2 + 1];
-      const uint32_t cnts[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-      const v4i* dp = reinterpret_cast<const v4i*>(a.dir_stream) + (int64_t)so * 4 + g;
-      v4i i0 = dp[0], i1 = dp[4];
-      dp += 8;
+      const auto* dcnt = as_const(reinterpret_cast<const v4u*>(a.dir_cnt)) + k * 4;  // 16 int32 = four quads per (tile, wave)
+      const v4u c0 = dcnt[0];
+      const v4u c1 = NACC > 4 ? dcnt[1] : (v4u)(0u);
+      const v4u c2 = NACC > 8 ? dcnt[2] : (v4u)(0u);
+      const v4u c3 = NACC > 12 ? dcnt[3] : (v4u)(0u);
+      const uint32_t cnts[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
+      const v4i* gd = reinterpret_cast<const v4i*>(a.dir_stream) + (int64_t)so * 4 + lane;
+      char* dwin = ring + cw * 4096;  // 4 windows x 1 KiB
+      auto dma = [&](int wi) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gd + (int64_t)wi * 64), (lds_ptr_t)(dwin + (wi & 3) * 1024), 16, 0, 0);
+      };
+      dma(0);
+      dma(1);
+      wait_vmcnt<1>();
+      dma(2);
+      int ss = 0, ready = 16;
+      auto ids = [&](int i) -> v4i { return *reinterpret_cast<const v4i*>(dwin + (i & 63) * 64 + g * 16); };
+      auto open_window = [&](int upto) {
+        if (upto >= ready) {
+          wait_vmcnt<1>();  // also retires the row gathers of the previous supersteps: they are older than the window
+          dma((ready >> 4) + 2);
+          ready += 16;
+        }
+      };
+      v4i i0 = ids(0), i1 = ids(1);
       const uint32_t rowbytes = (uint32_t)a.lds * 4u;
       const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)(cvalid ? col : 0) * 4u;  // idle lanes re-read column 0 (never stored)
+      auto gather4 = [&](const v4i& id, v4f (&v)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t o = id[u] >= 0 ? (uint32_t)id[u] * rowbytes : 0u;  // padding re-reads row 0 (valid memory)
+          v[u] = *reinterpret_cast<const v4f*>(xb + o);
+        }
+      };
 #pragma unroll
       for (int j = 0; j < NACC; ++j) {
         const int nss = (int)cnts[j];
-        for (int s = 0; s < nss; ++s) {
-          const v4i id = i0;
+        int s = 0;
+        for (; s + 2 <= nss; s += 2) {
+          open_window(ss + 3);
+          const v4i n0 = ids(ss + 2), n1 = ids(ss + 3);
+          v4f va[4], vb[4];
+          gather4(i0, va);
+          gather4(i1, vb);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += i0[u] >= 0 ? va[u] : (v4f)(0.f);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += i1[u] >= 0 ? vb[u] : (v4f)(0.f);
+          i0 = n0;
+          i1 = n1;
+          ss += 2;
+        }
+        if (s < nss) {
+          open_window(ss + 2);
+          const v4i n1 = ids(ss + 2);
+          v4f va[4];
+          gather4(i0, va);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += i0[u] >= 0 ? va[u] : (v4f)(0.f);
           i0 = i1;
-          i1 = *dp;
-          dp += 4;
-          v4f v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint32_t o = id[u] >= 0 ? (uint32_t)id[u] * rowbytes : 0u;  // padding re-reads row 0 (valid memory)
-            v[u] = *reinterpret_cast<const v4f*>(xb + o);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc[j] += id[u] >= 0 ? v[u] : (v4f)(0.f);
+          i1 = n1;
+          ss += 1;
         }
       }
     }
   }
 
+#ifdef MGX_TILE_STAMPS
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  t_dir = MGX_STAMP() - td1;
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((int64_t)tile * 16 + (cw + NL)) * 8;
+    o[0] = t_bar; o[1] = t_lds; o[2] = t_dir; o[3] = MGX_STAMP() - t_begin; o[4] = n_ss; o[5] = td1 - td0; o[6] = t_begin; o[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20) /* XCC_ID */;
+  }
+#endif
   // ---- epilogue: one row per lane group and accumulator
   if (!cvalid) return;
 #pragma unroll
@@ -223,32 +365,49 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, const char* rin
   }
 }
 
-template <int NACC, int NL>
-__global__ __launch_bounds__(kTileThreads) void spmm_tile_kernel(const TileArgs a) {
-  __shared__ __attribute__((aligned(1024))) char ring[kRing * kChunkBytes];
+template <int W, int NL, int NACC, int RING>
+__global__ __launch_bounds__(W * kWave, 4) void spmm_tile_kernel(const TileArgs a) {
+  // W = 16: one workgroup per CU (4 waves per SIMD); W = 8: two per CU -- either way 128 registers per lane
+  __shared__ __attribute__((aligned(1024))) char ring[RING * kChunkBytes + W * kStreamRingBytes];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & (kWave - 1);
   // block b serves XCD b % 8 (observed round-robin placement; speed only): consecutive tiles of the schedule -- which share
   // sources -- stay on one XCD's L2
   const int tile = (int)(blockIdx.x % kXcds) * a.tiles_per_xcd + (int)(blockIdx.x / kXcds);
-  if (tile >= a.num_tiles || (int)(blockIdx.x / kXcds) >= a.tiles_per_xcd) return;
+  if (tile >= a.num_tiles) return;
   const int cbeg = a.tile_chunk_ptr[tile];
   const int n = a.tile_chunk_ptr[tile + 1] - cbeg;
   const int col0 = blockIdx.y * kPassCols;
-  if (wave < NL) tile_loader<NL>(a, ring, wave, lane, cbeg, n, col0);
-  else tile_consumer<NACC, NL>(a, ring, wave - NL, lane, tile, cbeg, n, col0);
+  if (wave < NL) tile_loader<W, NL, RING>(a, ring, wave, lane, tile, cbeg, n, col0);
+  else tile_consumer<W, NL, NACC, RING>(a, ring, wave - NL, lane, tile, cbeg, n, col0);
 }
 
-template <int NL>
-static bool launch_tile(int nacc, const TileArgs& a, dim3 grid, hipStream_t s) {
-  switch (nacc) {
-    case 4: hipLaunchKernelGGL((spmm_tile_kernel<4, NL>), grid, dim3(kTileThreads), 0, s, a); return true;
-    case 5: hipLaunchKernelGGL((spmm_tile_kernel<5, NL>), grid, dim3(kTileThreads), 0, s, a); return true;
-    case 6: hipLaunchKernelGGL((spmm_tile_kernel<6, NL>), grid, dim3(kTileThreads), 0, s, a); return true;
-    case 8: hipLaunchKernelGGL((spmm_tile_kernel<8, NL>), grid, dim3(kTileThreads), 0, s, a); return true;
-    default: return false;
+#define MGX_TILE_LAUNCH(W_, NL_, NACC_, RING_)                                                                      \
+  do {                                                                                                             \
+    hipLaunchKernelGGL((spmm_tile_kernel<W_, NL_, NACC_, RING_>), grid, dim3(W_ * kWave), 0, s, a);                \
+    return true;                                                                                                   \
+  } while (0)
+
+// (waves, loaders, rows per lane group) the library is built for
+static bool launch_tile(int waves, int loaders, int nacc, const TileArgs& a, dim3 grid, hipStream_t s) {
+  if (waves == 16 && loaders == 2) {
+    if (nacc == 4) MGX_TILE_LAUNCH(16, 2, 4, 4);
+    if (nacc == 5) MGX_TILE_LAUNCH(16, 2, 5, 4);
+    if (nacc == 6) MGX_TILE_LAUNCH(16, 2, 6, 4);
+    if (nacc == 8) MGX_TILE_LAUNCH(16, 2, 8, 4);
+  } else if (waves == 16 && loaders == 4) {
+    if (nacc == 4) MGX_TILE_LAUNCH(16, 4, 4, 4);
+    if (nacc == 6) MGX_TILE_LAUNCH(16, 4, 6, 4);
+    if (nacc == 8) MGX_TILE_LAUNCH(16, 4, 8, 4);
+  } else if (waves == 8 && loaders == 1) {
+    if (nacc == 6) MGX_TILE_LAUNCH(8, 1, 6, 2);
+    if (nacc == 8) MGX_TILE_LAUNCH(8, 1, 8, 2);
+    if (nacc == 10) MGX_TILE_LAUNCH(8, 1, 10, 2);
+    if (nacc == 12) MGX_TILE_LAUNCH(8, 1, 12, 2);
   }
+  return false;
 }
+#undef MGX_TILE_LAUNCH
 
 // defined in spmm.hip
 int32_t spmm_hub_fixup_launch(const mgx_csr* csr, const mgx_spmm_plan* plan, const float* partial, const float* dst_scale, float* out,
@@ -268,7 +427,7 @@ extern "C" int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan*
     MGX_UNSUPPORTED("mgx_spmm_tile_copy_u: D and both strides must be multiples of 4 and the operands 16-byte aligned");
   MGX_CHECK_ARG(u_stride >= D && out_stride >= D, "mgx_spmm_tile_copy_u: strides must be >= D");
   if (csr->num_cols * u_stride * 4 >= (int64_t(1) << 32)) MGX_UNSUPPORTED("mgx_spmm_tile_copy_u: gathered matrix must be below 4 GiB");
-  MGX_CHECK_ARG(tp->consumers + tp->loaders == kTileWaves && (tp->loaders == 2 || tp->loaders == 4),
+  MGX_CHECK_ARG(tp->consumers >= 1 && tp->loaders >= 1 && (tp->consumers + tp->loaders == 16 || tp->consumers + tp->loaders == 8),
                 "mgx_spmm_tile_copy_u: tile plan built for %d + %d waves", tp->consumers, tp->loaders);
   MGX_CHECK_ARG(tp->num_tiles >= 0 && tp->num_tiles < (int64_t(1) << 28), "mgx_spmm_tile_copy_u: bad tile count");
   if (tp->num_tiles == 0 || csr->num_rows == 0) return MGX_OK;
@@ -287,11 +446,19 @@ extern "C" int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan*
   a.tiles_per_xcd = (int)((tp->num_tiles + kXcds - 1) / kXcds);
   a.D = (int)D; a.lds = (int)u_stride; a.ldo = (int)out_stride;
   a.mean = reduce == MGX_REDUCE_MEAN; a.accum = (flags & MGX_SPMM_ACCUMULATE) ? 1 : 0;
+#ifdef MGX_TILE_STAMPS
+  a.stamps = g_tile_stamps;
+#endif
   const dim3 grid((unsigned)(a.tiles_per_xcd * kXcds), (unsigned)((D + kPassCols - 1) / kPassCols));
   hipStream_t s = (hipStream_t)stream;
-  const bool ok = tp->loaders == 2 ? launch_tile<2>(tp->nacc, a, grid, s) : launch_tile<4>(tp->nacc, a, grid, s);
-  if (!ok) MGX_UNSUPPORTED("mgx_spmm_tile_copy_u: no kernel for %d rows per lane group", tp->nacc);
+  if (!launch_tile(tp->consumers + tp->loaders, tp->loaders, tp->nacc, a, grid, s))
+    MGX_UNSUPPORTED("mgx_spmm_tile_copy_u: no kernel for %d consumer + %d loader waves with %d rows per lane group", tp->consumers,
+                    tp->loaders, tp->nacc);
   MGX_CHECK_LAUNCH();
   if (hubs) return spmm_hub_fixup_launch(csr, plan, partial_ws, dst_scale, out, a.D, a.mean, a.accum, a.ldo, s);
   return MGX_OK;
 }
+
+#ifdef MGX_TILE_STAMPS
+extern "C" void mgx_debug_set_tile_stamps(void* p) { mgx::g_tile_stamps = (unsigned long long*)p; }
+#endif

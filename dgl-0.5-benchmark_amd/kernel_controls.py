@@ -27,7 +27,7 @@ if HERE not in sys.path:
 import torch  # noqa: E402
 
 N_PRODUCTS, M_PRODUCTS, MAXDEG_PRODUCTS, SEED_PRODUCTS = 2449029, 61859140, 17481, 4
-CONTROLS = ("products", "mixing1", "rmat", "uniform", "banded")
+CONTROLS = ("products", "mixing1", "rmat", "uniform", "banded", "clustered")
 
 
 def spmm_algorithmic_bytes(n_dst, n_src, nnz, D):
@@ -80,6 +80,18 @@ def banded_edges(n, e, seed, device, half_width=2048):
     return (dst + off).clamp_(0, n - 1), dst
 
 
+def clustered_edges(n, m, max_deg, seed, device, family=48):
+    """A control with real NEIGHBOURHOOD OVERLAP (the benchmark generator's communities have none inside -- their
+    edges are random pairs): products' node and edge counts and power-law endpoints, but half of the edges stay inside small
+    FAMILIES of ~`family` nodes (dense groups: a node with 50 edges has ~25 of them among its ~48 family members, so two
+    neighbours of a node are likely neighbours of each other -- co-purchase graphs have clustering ~0.4), a quarter inside
+    the usual communities and a quarter anywhere.  Average local clustering of the result: experiments/exp_clustered_control.py."""
+    from mi355x_graph.datasets import synthetic_edges
+    s1, d1 = synthetic_edges(n, m // 2, max_deg, seed, device, mixing=0.0, avg_comm=family, symmetric=True)
+    s2, d2 = synthetic_edges(n, m - m // 2, max_deg, seed + 1, device, mixing=0.5, symmetric=True)
+    return torch.cat([s1, s2]), torch.cat([d1, d2])
+
+
 def control_edges(kind, device, scale=1.0):
     from mi355x_graph.datasets import synthetic_edges
     n = max(4096, int(N_PRODUCTS * scale))
@@ -94,6 +106,8 @@ def control_edges(kind, device, scale=1.0):
         return n, uniform_edges(n, 2 * m, SEED_PRODUCTS, device)
     if kind == "banded":
         return n, banded_edges(n, 2 * m, SEED_PRODUCTS, device)
+    if kind == "clustered":
+        return n, clustered_edges(n, m, min(MAXDEG_PRODUCTS, n - 1), SEED_PRODUCTS, device)
     raise ValueError("unknown control graph %r (have %s)" % (kind, ", ".join(CONTROLS)))
 
 

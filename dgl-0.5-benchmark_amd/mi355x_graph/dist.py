@@ -379,6 +379,77 @@ class DistCopyU(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+class DistSageMeanCatFn(torch.autograd.Function):
+    """ops.SageMeanCatFn on a partition: one mean-aggregator GraphSAGE layer (main_dgl_product_sage.py:52-64) as ONE GEMM on
+    [h | neigh] with the halo exchange hidden behind the local aggregation -- the layer every rank of `bench.py --gpus N` runs, so
+    that N = 1 and N > 1 time the same module form.
+
+      forward   pack boundary rows of h -> all_to_all (async) || aggregation over owned sources, left half -> right half in place
+                -> wait -> aggregation over the received halo rows accumulating into the right half -> ONE GEMM
+      backward  ONE GEMM gives d[h | neigh]; halo-row gradients first -> all_to_all (async) || reversed aggregation over owned
+                rows accumulating into the left half -> wait -> returned rows added into their owners (fixed order)
+    `static_cache`: DistGraph.set_static_input's declaration for the layer-1 input (its halo rows stay resident)."""
+
+    @staticmethod
+    def forward(ctx, plan, comm, cat, h, w_self, w_neigh, bias, static_cache):
+        be = sparse.backend_for(h)
+        if static_cache is not None and static_cache.get("recv") is not None and static_cache.get("version") == h._version:
+            recv, work = static_cache["recv"], _Done()
+        else:
+            send = torch.index_select(h, 0, plan.send_idx.long()) if plan.send_idx.numel() else h.new_empty((0, h.shape[1]))
+            recv = torch.empty((plan.n_halo, h.shape[1]), dtype=h.dtype, device=h.device)
+            work = comm.all_to_all_async(recv, send, plan.recv_splits, plan.send_splits)
+            if static_cache is not None:
+                static_cache["version"], static_cache["recv"] = h._version, recv
+        if not cat.holds(h):  # the layer-1 input lives elsewhere: copied into the left half unless it is the same unmodified tensor
+            same = cat.static_key is not None and cat.static_key[0] is h and cat.static_key[1] == h._version
+            if not same or h.requires_grad or os.environ.get("MGX_SAGE_STATIC_CAT", "1") != "1":
+                cat.left.copy_(h)
+                cat.static_key = None if h.requires_grad else (h, h._version)
+        cat.generation += 1
+        be.spmm_copy_u_strided(plan.loc.csc(), "sum", cat.left, cat.right, dst_scale=plan.inv_deg)
+        work.wait()
+        if plan.n_halo:
+            be.spmm_copy_u_strided(plan.halo.csc(), "sum", recv, cat.right, accumulate=True, dst_scale=plan.inv_deg)
+        ctx.plan, ctx.comm, ctx.cat, ctx.generation = plan, comm, cat, cat.generation
+        ctx.save_for_backward(w_self, w_neigh)
+        return torch.nn.functional.linear(cat.buf, torch.cat([w_self, w_neigh], dim=1), bias)
+
+    @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
+    def backward(ctx, dy):
+        from . import ops
+        w_self, w_neigh = ctx.saved_tensors
+        plan, comm, cat = ctx.plan, ctx.comm, ctx.cat
+        if cat.generation != ctx.generation:
+            raise DGLError("SAGEConv: a later forward pass overwrote the [h | neigh] buffer this backward pass needs")
+        dy = dy.contiguous()
+        need = ctx.needs_input_grad
+        be = sparse.backend_for(dy)
+        K = cat.K
+        dh = None
+        if need[3]:
+            dcat = dy @ torch.cat([w_self, w_neigh], dim=1)  # [n_own, 2K] = d[h | neigh]
+            dn = dcat[:, K:]
+            dn.mul_(plan.inv_deg.view(-1, 1))  # d(sum / deg)
+            back = torch.empty((plan.send_idx.shape[0], K), dtype=dy.dtype, device=dy.device)
+            g_halo = torch.empty((plan.n_halo, K), dtype=dy.dtype, device=dy.device)
+            if plan.n_halo:
+                be.spmm_copy_u_strided(plan.halo.csr(), "sum", dn, g_halo)
+            work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
+            be.spmm_copy_u_strided(plan.loc.csr(), "sum", dn, dcat[:, :K], accumulate=True)
+            work.wait()
+            if back.shape[0]:  # row v += the returned rows whose owner is v: copy_u over (owned row -> position in `back`)
+                be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dcat[:, :K], accumulate=True)
+            dh = dcat[:, :K]
+        dws = dwn = None
+        if need[4] or need[5]:
+            dw = ops._weight_grad(dy, cat.buf)
+            dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
+        db = be.column_sum(dy) if need[6] else None
+        return None, None, None, dh, dws, dwn, db, None
+
+
 class HaloExchange(torch.autograd.Function):
     """x_own [n_own, ...] -> [n_own + n_halo, ...]; backward adds halo gradients into their owners."""
 
@@ -504,6 +575,19 @@ class DistGraph(DGLGraph):
     def apply_edges(self, func, edges="__ALL__", etype=None):
         blk = self._local(self._u_fields(func))
         core.apply_edges(blk, func)
+
+    def sage_mean_layer(self, h, w_self, w_neigh, bias, cat):
+        """The one-GEMM SAGE layer on this partition (ops.sage_mean_layer dispatches here); None when it does not apply."""
+        plan = self._plan
+        if (cat is None or plan.loc is None or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda or cat.K != h.shape[1]
+                or h.shape[0] != plan.n_own or cat.buf.shape[0] != plan.n_own or h.shape[1] % 4
+                or plan.loc.csc().indptr.dtype != torch.int32 or not torch.is_grad_enabled()
+                or os.environ.get("MGX_SAGE_CAT", "1") != "1" or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):
+            return None
+        if plan.return_csr().num_cols * h.shape[1] * 4 >= (1 << 32) or (plan.n_own + plan.n_halo) * 2 * h.shape[1] * 4 >= (1 << 32):
+            return None
+        static = self._static_halo if self._static_halo.get("tensor") is h else None
+        return DistSageMeanCatFn.apply(plan, self._comm, cat, h, w_self, w_neigh, bias, static)
 
 
 # ----------------------------------------------------------------------------- training helpers

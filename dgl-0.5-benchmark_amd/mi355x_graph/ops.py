@@ -744,9 +744,70 @@ class SageMeanCatFn(torch.autograd.Function):
         return None, None, dh, dws, dwn, db
 
 
+class SageMeanProjectFirstFn(torch.autograd.Function):
+    """y = h W_self^T + mean_{u->v}(h[u] W_neigh^T) + b: the projection BEFORE the aggregation -- mean and the linear map commute,
+    so this is SAGEConv's `fc_self(h) + fc_neigh(mean_agg(h))` (main_dgl_reddit_sage.py:73-80) with the aggregation running at
+    the OUTPUT width (upstream dgl.nn.SAGEConv does the same when in_feats > out_feats: `lin_before_mp`).  reddit's first layer
+    aggregates 16 columns instead of 602.  One GEMM gives [s | z] = h [W_self | W_neigh]^T, the aggregation reads the z half and
+    accumulates into the s half in place; backward: dz = A_mean^T dy (one more aggregation at the output width), then
+    d[W_self | W_neigh] = [dy | dz]^T h and dh = [dy | dz] [W_self ; W_neigh]."""
+
+    @staticmethod
+    def forward(ctx, gidx, h, w_self, w_neigh, bias):
+        K = w_self.shape[0]
+        w = torch.cat([w_self, w_neigh], dim=0)            # [2K, in]
+        sz = torch.nn.functional.linear(h, w)               # [N, 2K] = [s | z]
+        sparse.backend_for(h).spmm_copy_u_strided(gidx.csc(), "mean", sz[:, K:], sz[:, :K], accumulate=True)
+        y = sz[:, :K].contiguous()
+        if bias is not None:
+            y.add_(bias)
+        ctx.gidx = gidx
+        ctx.save_for_backward(h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
+    def backward(ctx, dy):
+        h, w = ctx.saved_tensors
+        K = w.shape[0] // 2
+        need = ctx.needs_input_grad
+        be = sparse.backend_for(dy)
+        dcat = torch.empty((dy.shape[0], 2 * K), dtype=dy.dtype, device=dy.device)
+        dcat[:, :K] = dy
+        dn = dy * ctx.gidx.csc().inv_degrees().view(-1, 1)  # d(sum / deg): one streaming pass, not a per-edge factor
+        be.spmm_copy_u_strided(ctx.gidx.csr(), "sum", dn, dcat[:, K:])
+        dh = dcat @ w if need[1] else None
+        dws = dwn = None
+        if need[2] or need[3]:
+            dw = _weight_grad(dcat, h)                       # [2K, in]
+            dws, dwn = dw[:K], dw[K:]
+        db = be.column_sum(dy.contiguous()) if need[4] else None
+        return None, dh, dws, dwn, db
+
+
+def sage_project_first(g, h, w_self, w_neigh, bias=None):
+    """SAGEConv with the projection before the aggregation, or None when that form does not apply / does not pay: a square int32
+    DGLGraph, 2-D float32 HIP features, out_feats a multiple of 4, and TWO aggregations at the output width (forward and
+    backward) cheaper than ONE at the input width (the input needs no gradient) resp. two (it does)."""
+    K, D = w_self.shape
+    if (type(g) is not DGLGraph or g.is_block or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda
+            or h.device.type not in sparse._BACKENDS or not torch.is_grad_enabled() or g.idtype != torch.int32
+            or g.number_of_src_nodes() != g.number_of_dst_nodes() or h.shape[0] != g.number_of_src_nodes()
+            or K % 4 or K > 128 or _torch_ops() is not None or os.environ.get("MGX_SAGE_PROJECT_FIRST", "1") != "1"
+            or (bias is not None and K > sparse.backend_for(h).COLUMN_SUM_MAX)
+            or g.number_of_src_nodes() * 2 * K * 4 >= (1 << 32)):
+        return None
+    aggs_now = 2 if h.requires_grad else 1
+    if 2 * max(K, 16) * 1.1 > aggs_now * D:  # rows narrower than 64 bytes cost as much as 64-byte rows (request bound)
+        return None
+    return SageMeanProjectFirstFn.apply(g._index, h, w_self, w_neigh, bias)
+
+
 def sage_mean_layer(g, h, w_self, w_neigh, bias=None, cat=None):
     """Fused form of SAGEConv on a homogeneous square DGLGraph with 2-D float32 HIP features; None when the fused node does
     not apply (the caller then composes update_all + linear_sum)."""
+    if hasattr(g, "sage_mean_layer"):  # dist.DistGraph: the same one-GEMM layer with the halo exchange inside
+        return g.sage_mean_layer(h, w_self, w_neigh, bias, cat)
     if (type(g) is not DGLGraph or g.is_block or h.dim() != 2 or h.dtype != torch.float32
             or not h.is_cuda or h.device.type not in sparse._BACKENDS or not torch.is_grad_enabled()
             or g.number_of_src_nodes() != g.number_of_dst_nodes() or h.shape[0] != g.number_of_src_nodes()
@@ -768,7 +829,7 @@ def _cat_eligible(g, h, cat):
 
 def cat_buffer_for(g, x, K):
     """A CatBuffer for a layer whose input has K columns, or None when the one-GEMM form does not apply to this graph / width."""
-    if (type(g) is not DGLGraph or g.is_block or x.dtype != torch.float32 or not x.is_cuda or x.device.type not in sparse._BACKENDS
+    if ((type(g) is not DGLGraph and not hasattr(g, "sage_mean_layer")) or g.is_block or x.dtype != torch.float32 or not x.is_cuda or x.device.type not in sparse._BACKENDS
             or not torch.is_grad_enabled() or K % 4 or g.number_of_src_nodes() != g.number_of_dst_nodes()
             or g.number_of_src_nodes() * 2 * K * 4 >= (1 << 32) or g.idtype != torch.int32
             or os.environ.get("MGX_SAGE_CAT", "1") != "1" or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):

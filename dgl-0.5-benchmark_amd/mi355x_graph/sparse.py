@@ -19,6 +19,7 @@ from ._lib import DGLError, MgxCsr, OP, REDUCE, TARGET
 
 
 PROFILE = None  # set to a list by bench.py to collect per-launch HIP-event timings of mgx_spmm_csr
+TILE_MIN_WIDTH = int(os.environ.get("MGX_TILE_MIN_WIDTH", 48))  # narrower rows stay on the row kernel (a tile pass is 64 columns wide)
 
 
 def _ptr(t):
@@ -40,7 +41,7 @@ class CsrView(object):
     """An immutable CSR over torch tensors (in-CSR: rows = destination nodes)."""
 
     __slots__ = ("__weakref__", "num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan", "_sm_plan",
-                 "_row_order", "dst_is_src_prefix")
+                 "_row_order", "dst_is_src_prefix", "_tile_plan")
 
     def __init__(self, num_rows, num_cols, indptr, indices, eids):
         self.num_rows, self.num_cols = int(num_rows), int(num_cols)
@@ -50,6 +51,7 @@ class CsrView(object):
         self._inv_deg = None
         self._plan = False  # False = not built yet; None = run without a plan
         self._sm_plan = False
+        self._tile_plan = False
         self._row_order = (None, None)  # (row order, kind) computed with the first plan
         self.dst_is_src_prefix = False  # block graphs whose destination nodes are the first source nodes
 
@@ -92,6 +94,20 @@ class CsrView(object):
             from . import schedule
             self._plan = schedule.plan_for(self) if self.indptr.is_cuda else None
         return self._plan
+
+    def tile_plan(self):
+        """Tile plan of the LDS-staged g-SpMM (tileplan.py) on graphs with dense neighbourhoods, else None; built on first use."""
+        if self._tile_plan is False:
+            from . import schedule, tileplan
+            self._tile_plan = None
+            if tileplan.tile_plan_wanted(self):
+                self.plan()  # computes (and caches) the locality row order first
+                nc, nacc, nl, tau = tileplan.config()
+                base = schedule.plan_for(self, split=tileplan.TILE_SPLIT)
+                tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau)
+                tileplan.validate(tp, self)
+                self._tile_plan = tp
+        return self._tile_plan
 
     def softmax_plan(self):
         """Schedule of the edge-softmax / fused attention kernels: the g-SpMM plan unless MGX_SOFTMAX_SPLIT asks for a
@@ -254,6 +270,13 @@ class HipBackend(object):
                 arg_u = torch.empty((csr.num_rows, out_len), dtype=csr.indptr.dtype, device=dev)
             if op != "copy_lhs":
                 arg_e = torch.empty((csr.num_rows, out_len), dtype=csr.indptr.dtype, device=dev)
+        if (op == "copy_lhs" and reduce in ("sum", "mean") and src_scale is None and u_off is None and e_off is None
+                and u_len == out_len and out_len >= TILE_MIN_WIDTH and out_len % 4 == 0 and csr.idx_bits == 32
+                and csr.num_cols * out_len * 4 < 2 ** 32 and U.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and not want_arg):
+            tp = csr.tile_plan()
+            if tp is not None:  # dense neighbourhoods: the LDS-staged tile kernel
+                self.spmm_tile_copy_u(csr, tp, reduce, U.view(csr.num_cols, out_len), out, accumulate_into is not None, dst_scale)
+                return out, None, None
         plan = csr.plan() if reduce in ("sum", "mean") else None
         partial = None
         if plan is not None and plan.num_slots:
@@ -317,6 +340,11 @@ class HipBackend(object):
         if (U2d.dim() != 2 or out2d.dim() != 2 or U2d.stride(1) != 1 or out2d.stride(1) != 1 or out2d.shape[1] != D
                 or U2d.shape[0] != csr.num_cols or out2d.shape[0] != csr.num_rows):
             raise DGLError("spmm_copy_u_strided: expected row-strided [num_cols, D] -> [num_rows, D] views")
+        if (D >= TILE_MIN_WIDTH and D % 4 == 0 and csr.idx_bits == 32 and csr.num_cols * int(U2d.stride(0)) * 4 < 2 ** 32
+                and U2d.stride(0) % 4 == 0 and out2d.stride(0) % 4 == 0 and U2d.data_ptr() % 16 == 0 and out2d.data_ptr() % 16 == 0):
+            tp = csr.tile_plan()
+            if tp is not None:
+                return self.spmm_tile_copy_u(csr, tp, reduce, U2d, out2d, accumulate, dst_scale)
         plan = csr.plan()
         partial = torch.empty((plan.num_slots, D), dtype=torch.float32, device=dev) if plan is not None and plan.num_slots else None
         with torch.cuda.device(dev):
@@ -330,6 +358,33 @@ class HipBackend(object):
                 ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,
                 int(U2d.stride(0)), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial), 1 if accumulate else 0,
                 _stream(dev)))
+            if rec is not None:
+                rec["end"].record(torch.cuda.current_stream(dev))
+                PROFILE.append(rec)
+        return out2d
+
+    def spmm_tile_copy_u(self, csr, tile_plan, reduce, U2d, out2d=None, accumulate=False, dst_scale=None):
+        """copy_u / sum|mean through the LDS-staged tile kernel (mgx_spmm_tile_copy_u); U2d / out2d may be row-strided views."""
+        dev = self._check_dev(csr.indptr, U2d, out2d, dst_scale)
+        D = int(U2d.shape[1])
+        if out2d is None:
+            out2d = torch.empty((csr.num_rows, D), dtype=torch.float32, device=dev)
+        if (U2d.dim() != 2 or out2d.dim() != 2 or U2d.stride(1) != 1 or out2d.stride(1) != 1 or out2d.shape[1] != D
+                or U2d.shape[0] != csr.num_cols or out2d.shape[0] != csr.num_rows):
+            raise DGLError("spmm_tile_copy_u: expected row-strided [num_cols, D] -> [num_rows, D] views")
+        base = tile_plan.base
+        partial = torch.empty((base.num_slots, D), dtype=torch.float32, device=dev) if base is not None and base.num_slots else None
+        with torch.cuda.device(dev):
+            rec = None
+            if PROFILE is not None:
+                rec = {"op": "copy_lhs", "reduce": reduce, "out_len": D, "n_rows": csr.num_rows, "n_cols": csr.num_cols,
+                       "nnz": csr.nnz, "accumulate": bool(accumulate), "variant": "tile",
+                       "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
+                rec["start"].record(torch.cuda.current_stream(dev))
+            _lib.check(_lib.lib().mgx_spmm_tile_copy_u(
+                ctypes.byref(csr.c_struct()), None if base is None else ctypes.byref(base.c_struct()), ctypes.byref(tile_plan.c_struct()),
+                REDUCE[reduce], _ptr(U2d), D, int(U2d.stride(0)), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial),
+                1 if accumulate else 0, _stream(dev)))
             if rec is not None:
                 rec["end"].record(torch.cuda.current_stream(dev))
                 PROFILE.append(rec)

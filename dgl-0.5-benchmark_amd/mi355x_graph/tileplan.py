@@ -28,7 +28,8 @@ import torch
 GROUPS = 4          # 16-lane groups of a wave (one 64-column pass: 16 lanes x float4)
 CHUNK_SLOTS = 128   # LDS rows per chunk: 127 staged sources + the all-zero slot
 ZERO_SLOT = CHUNK_SLOTS - 1
-TILE_WAVES = 16     # 1024-thread workgroups
+TILE_WAVES = (8, 16)  # workgroups of 8 waves (two per CU, 2-chunk ring) or 16 waves (one per CU, 4-chunk ring)
+CNT_STRIDE = 16     # superstep counts per (chunk | tile, wave) in lds_cnt / dir_cnt
 NO_ITEM = -(2 ** 31)
 STREAM_TAIL = 64    # padding SUPERSTEPS behind every stream (the kernel prefetches two supersteps ahead, unconditionally)
 
@@ -94,17 +95,24 @@ def _excl_cumsum(x):
     return out
 
 
-def _streams(seg_key, nseg, payload, pad, dtype):
-    """Edges with segment key (((unit * NC + cw) * NACC + j) * 4 + g) -> (superstep counts per (unit, cw, j), first superstep of
-    each, stream).  A (unit, cw, j) row of the stream has max_g(count) steps rounded up to whole SUPERSTEPS (4 steps); layout
-    [superstep][lane group g][step u]: one payload per entry, `pad` where a group has run out.  Edges keep their storage order
-    inside a group (stable sort)."""
+def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None):
+    """Edges with segment key (seg * 4 + g), seg = a (unit, cw, j) row of the stream -> (superstep counts per seg, first superstep
+    of each seg, stream).  A row has max_g(count) steps rounded up to whole SUPERSTEPS (4 steps); layout
+    [superstep][lane group g][step u]: one payload per entry, `pad` where a group has run out.  `seg_order`: the order in which
+    the rows are laid out in the stream (default: seg order).  Edges keep their storage order inside a group (stable sort)."""
     dev = seg_key.device
     cnt4 = torch.bincount(seg_key, minlength=nseg * GROUPS)
     steps = cnt4.view(nseg, GROUPS).max(dim=1)[0]
     ssteps = (steps + 3) // 4
-    base = _excl_cumsum(ssteps)  # first superstep of every (unit, cw, j)
-    total = int(base[-1])
+    if seg_order is None:
+        base = _excl_cumsum(ssteps)  # first superstep of every row
+        total = int(base[-1])
+        base = base[:-1]
+    else:
+        laid = _excl_cumsum(ssteps[seg_order])
+        total = int(laid[-1])
+        base = torch.empty(nseg, dtype=torch.int64, device=dev)
+        base[seg_order] = laid[:-1]
     stream = torch.full(((total + STREAM_TAIL) * GROUPS * 4,), pad, dtype=dtype, device=dev)
     if seg_key.numel():
         order = torch.sort(seg_key, stable=True)[1]
@@ -113,15 +121,18 @@ def _streams(seg_key, nseg, payload, pad, dtype):
         rank = torch.arange(sk.shape[0], device=dev) - seg_start[sk]
         idx = ((base[sk // GROUPS] + rank // 4) * GROUPS + (sk % GROUPS)) * 4 + rank % 4
         stream[idx] = payload[order].to(dtype)
-    return ssteps, base, stream
+    return ssteps, base, total, stream
 
 
-def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2):
+NUM_CUS = 256
+
+
+def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False):
     """csr: CsrView (int32, device or host); base: SpmmPlan over it (items in schedule order; None = natural rows)."""
     dev = csr.indptr.device
     NC, NACC = int(consumers), int(nacc)
-    if NC + int(loaders) != TILE_WAVES or not 1 <= NACC <= 8 or int(loaders) not in (2, 4):
-        raise ValueError("tile plan: consumers + loaders must be %d, nacc in 1..8, loaders 2 or 4" % TILE_WAVES)
+    if NC + int(loaders) not in TILE_WAVES or not 1 <= NACC <= CNT_STRIDE or int(loaders) not in (1, 2, 4):
+        raise ValueError("tile plan: consumers + loaders must be 8 or 16, nacc in 1..16, loaders 1, 2 or 4")
     R = NC * NACC * GROUPS
     n_src = csr.num_cols
     if base is not None:
@@ -131,15 +142,35 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2):
         item_row = torch.arange(csr.num_rows, device=dev)
         beg, end = csr.indptr[:-1].long(), csr.indptr[1:].long()
     I = int(item_row.shape[0])
-    T = (I + R - 1) // R
     lens = end - beg
     E = int(lens.sum())
-    it_tile = torch.arange(I, device=dev) // R
+    # ---- tiles: consecutive items of the schedule, at most R of them and about the same number of EDGES each.  A launch runs
+    # only a few tiles per CU (one 1024-thread workgroup fills a CU), so tiles of unequal length leave CUs idle at the end;
+    # the edge budget is chosen so that the tile count lands just under a whole number of rounds over the 256 CUs.
+    T0 = max((I + R - 1) // R, 1)
+    if balance and T0 >= NUM_CUS + NUM_CUS // 2:
+        rounds = (T0 + NUM_CUS - 1) // NUM_CUS
+        budget = max(E // max(rounds * NUM_CUS - NUM_CUS // 32, 1), 1)
+        te = (torch.cumsum(lens, 0) - lens) // budget              # tile by edge count ...
+        first = torch.ones(I, dtype=torch.bool, device=dev)
+        first[1:] = te[1:] != te[:-1]
+        start = torch.cummax(torch.where(first, torch.arange(I, device=dev), torch.zeros(I, dtype=torch.int64, device=dev)), 0)[0]
+        sub = (torch.arange(I, device=dev) - start) // R                # ... cut again where it holds more than R items
+        key = te * (I // R + 2) + sub
+        newt = torch.ones(I, dtype=torch.int64, device=dev)
+        newt[1:] = (key[1:] != key[:-1]).long()
+        it_tile = torch.cumsum(newt, 0) - 1
+        it_first = torch.cummax(torch.where(newt.bool(), torch.arange(I, device=dev), torch.zeros(I, dtype=torch.int64, device=dev)), 0)[0]
+        T = int(it_tile[-1]) + 1
+    else:
+        it_tile = torch.arange(I, device=dev) // R
+        it_first = it_tile * R
+        T = T0
     # ---- position of every item inside its tile: rank by length, quads of ranks, quads dealt to the waves back and forth
     maxlen = int(lens.max()) if I else 0
     order = torch.sort(it_tile * (maxlen + 1) + (maxlen - lens), stable=True)[1]
     rank = torch.empty(I, dtype=torch.int64, device=dev)
-    rank[order] = torch.arange(I, device=dev) - it_tile[order] * R
+    rank[order] = torch.arange(I, device=dev) - it_first[order]
     quad, g = rank // GROUPS, rank % GROUPS
     rnd, w = quad // NC, quad % NC
     cw = torch.where(rnd % 2 == 0, w, NC - 1 - w)
@@ -181,21 +212,29 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2):
     e_chunk[perm], e_slot[perm] = grp_chunk[inv], grp_slot[inv]
     del perm, inv, grp_chunk, grp_slot, uniq
     staged = e_chunk >= 0
-    # ---- LDS streams: one per (chunk, consumer wave)
+    # ---- LDS streams: rows (chunk, cw, j), laid out per (tile, consumer wave) -- contiguous over the chunks of the tile, so the
+    # kernel's prefetch of the next supersteps runs through chunk boundaries
     per_unit = NC * NACC * GROUPS
     sk = e_chunk[staged] * per_unit + e_pos[staged]
-    lds_cnt, lds_base, lds_bytes = _streams(sk, NCH * NC * NACC, e_slot[staged], ZERO_SLOT, torch.uint8)
-    lds_off = lds_base.view(-1)[::NACC].clone() if NCH else torch.zeros(1, dtype=torch.int64, device=dev)
+    nseg = NCH * NC * NACC
+    seg = torch.arange(nseg, device=dev)
+    seg_chunk, seg_cw = seg // (NC * NACC), (seg // NACC) % NC
+    chunk_tile = torch.repeat_interleave(torch.arange(T, device=dev), tile_chunk_ptr[1:] - tile_chunk_ptr[:-1])
+    seg_unit = (chunk_tile[seg_chunk] * NC + seg_cw) if NCH else seg
+    seg_order = torch.sort(seg_unit, stable=True)[1]  # stable: (chunk, j) order kept inside a (tile, cw)
+    lds_cnt, lds_base, lds_total, lds_bytes = _streams(sk, nseg, e_slot[staged], ZERO_SLOT, torch.uint8, seg_order)
+    lds_off = _excl_cumsum(torch.bincount(seg_unit, weights=lds_cnt.double(), minlength=T * NC).long()) if NCH else \
+        torch.zeros(T * NC + 1, dtype=torch.int64, device=dev)
     # ---- direct streams: one per (tile, consumer wave)
     direct = ~staged
     dk = e_tile[direct] * per_unit + e_pos[direct]
-    dir_cnt, dir_base, dir_stream = _streams(dk, T * NC * NACC, e_src[direct], -1, torch.int32)
-    dir_off = dir_base.view(-1)[::NACC].clone()
+    dir_cnt, dir_base, dir_total, dir_stream = _streams(dk, T * NC * NACC, e_src[direct], -1, torch.int32)
+    dir_off = torch.cat([dir_base.view(-1)[::NACC], torch.tensor([dir_total], device=dev)])
     if int(lds_cnt.max() if lds_cnt.numel() else 0) > 65535:
         raise ValueError("tile plan: more than 65535 supersteps in one (chunk, row)")
 
-    def cnt8(c, units, dtype):  # [units * NC, 8] with NACC live columns
-        out = torch.zeros((units * NC, 8), dtype=dtype, device=dev)
+    def cnt8(c, units, dtype):  # [units * NC, CNT_STRIDE] with NACC live columns
+        out = torch.zeros((units * NC, CNT_STRIDE), dtype=dtype, device=dev)
         if units:
             out[:, :NACC] = c.view(units * NC, NACC).to(dtype)
         return out.view(-1)
@@ -210,18 +249,59 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2):
     tables = {
         "tile_chunk_ptr": tile_chunk_ptr.to(torch.int32),
         "chunk_ids": chunk_ids,
-        "lds_off": lds_off.to(torch.int32),            # [NCH * NC + 1] first superstep of (chunk, cw); the last entry closes the table
-        "lds_cnt": cnt8(lds_cnt, NCH, torch.int16),    # supersteps of (chunk, cw, j), 8 uint16 per (chunk, cw)
+        "lds_off": lds_off.to(torch.int32),            # [T * NC + 1] first superstep of (tile, cw): chunks, then rows j, contiguous
+        "lds_cnt": cnt8(lds_cnt, NCH, torch.int16),    # supersteps of (chunk, cw, j), 16 uint16 per (chunk, cw)
         "lds_stream": lds_bytes.view(torch.int32) if lds_bytes.numel() else torch.zeros(0, dtype=torch.int32, device=dev),
         "dir_off": dir_off.to(torch.int32),            # [T * NC + 1]
-        "dir_cnt": cnt8(dir_cnt, T, torch.int32),      # supersteps of (tile, cw, j), 8 int32 per (tile, cw)
+        "dir_cnt": cnt8(dir_cnt, T, torch.int32),      # supersteps of (tile, cw, j), 16 int32 per (tile, cw)
         "dir_stream": dir_stream,                      # [dir_supersteps * 16] source ids, -1 = padding
         "tile_item": tile_item.to(torch.int32),        # [T * R] item_row of the item at every position, NO_ITEM = none
         "zero_row": torch.zeros(64, dtype=torch.float32, device=dev),
     }
-    if int(lds_base[-1]) * 4 >= 2 ** 31 or int(dir_base[-1]) * 16 >= 2 ** 31:
+    if lds_total * 4 >= 2 ** 31 or dir_total * 16 >= 2 ** 31:
         raise ValueError("tile plan: stream offsets exceed 31 bits")
     return TilePlan(base, NC, NACC, loaders, tables, stats)
+
+
+def validate(plan, csr):
+    """Bounds of every index the kernel follows blindly (a wrong table would be an out-of-bounds access on the device)."""
+    NC, NACC, R = plan.consumers, plan.nacc, plan.rows_per_tile
+    T, NCH = plan.num_tiles, plan.num_chunks
+    num_slots = plan.base.num_slots if plan.base is not None else 0
+
+    def ok(cond, what):
+        if not bool(cond):
+            raise ValueError("tile plan: " + what)
+
+    tcp = plan.tile_chunk_ptr.long()
+    ok(tcp.shape[0] == T + 1 and int(tcp[0]) == 0 and int(tcp[-1]) == NCH and bool((tcp[1:] >= tcp[:-1]).all()), "tile_chunk_ptr")
+    ids = plan.chunk_ids
+    ok(ids.shape[0] == NCH * CHUNK_SLOTS and (NCH == 0 or (int(ids.min()) >= -1 and int(ids.max()) < csr.num_cols)), "chunk_ids range")
+    ok(NCH == 0 or bool((ids.view(NCH, CHUNK_SLOTS)[:, ZERO_SLOT] == -1).all()), "zero slot")
+    for off, cnt, stream, units, per in ((plan.lds_off, plan.lds_cnt, plan.lds_stream, NCH, GROUPS),
+                                         (plan.dir_off, plan.dir_cnt, plan.dir_stream, T, 4 * GROUPS)):
+        off = off.long()
+        ok(off.shape[0] == T * NC + 1 and int(off[0]) == 0 and bool((off[1:] >= off[:-1]).all()), "stream offsets")
+        c = cnt.view(units * NC, CNT_STRIDE).long() & 0xFFFFFFFF if cnt.dtype == torch.int32 else cnt.view(units * NC, CNT_STRIDE).long() & 0xFFFF
+        ok(bool((c[:, NACC:] == 0).all()), "superstep counts beyond nacc")
+        per_wave = c.sum(1).view(units, NC)  # supersteps of (unit, cw)
+        if units == NCH:  # chunks of a tile add up to the tile's stream
+            per_tile = torch.zeros((T, NC), dtype=torch.int64, device=c.device)
+            if NCH:
+                per_tile.index_add_(0, torch.repeat_interleave(torch.arange(T, device=c.device), tcp[1:] - tcp[:-1]), per_wave)
+            per_wave = per_tile
+        ok(bool((per_wave.view(-1) == off[1:] - off[:-1]).all()), "superstep counts")
+        ok(stream.shape[0] == (int(off[-1]) + STREAM_TAIL) * per, "stream length")
+    if plan.lds_stream.numel():
+        b = plan.lds_stream.view(torch.uint8)
+        ok(int(b.max()) <= ZERO_SLOT, "lds slots")
+    if plan.dir_stream.numel():
+        ok(int(plan.dir_stream.min()) >= -1 and int(plan.dir_stream.max()) < csr.num_cols, "direct ids")
+    ti = plan.tile_item.long()
+    live = ti[ti != NO_ITEM]
+    ok(ti.shape[0] == T * R and (live.numel() == 0 or (int(live.max()) < csr.num_rows and int(live.min()) >= -num_slots)), "tile_item")
+    ok(plan.zero_row.numel() == 64 and not bool(plan.zero_row.any()), "zero row")
+    return True
 
 
 def emulate(plan, x, out_rows, num_slots=0):
@@ -233,30 +313,33 @@ def emulate(plan, x, out_rows, num_slots=0):
     NC, NACC, R = plan.consumers, plan.nacc, plan.rows_per_tile
     tcp = plan.tile_chunk_ptr.cpu().numpy()
     ids = plan.chunk_ids.cpu().numpy()
-    lds_off, lds_cnt = plan.lds_off.cpu().numpy(), plan.lds_cnt.cpu().numpy().astype(np.uint16).reshape(-1, 8)
+    lds_off, lds_cnt = plan.lds_off.cpu().numpy(), plan.lds_cnt.cpu().numpy().astype(np.uint16).reshape(-1, CNT_STRIDE)
     lds_stream = plan.lds_stream.cpu().numpy().view(np.uint8).reshape(-1, GROUPS, 4)  # [superstep][group][step]
-    dir_off, dir_cnt = plan.dir_off.cpu().numpy(), plan.dir_cnt.cpu().numpy().reshape(-1, 8)
+    dir_off, dir_cnt = plan.dir_off.cpu().numpy(), plan.dir_cnt.cpu().numpy().reshape(-1, CNT_STRIDE)
     dir_stream = plan.dir_stream.cpu().numpy().reshape(-1, GROUPS, 4)
     tile_item = plan.tile_item.cpu().numpy()
     out = np.zeros((out_rows, D))
     partial = np.zeros((max(num_slots, 1), D))
     for t in range(plan.num_tiles):
         acc = np.zeros((R, D))
+        images = []
         for c in range(tcp[t], tcp[t + 1]):
             lds = np.zeros((CHUNK_SLOTS, D))
             cid = ids[c * CHUNK_SLOTS:(c + 1) * CHUNK_SLOTS]
             assert cid[ZERO_SLOT] == -1
             lds[cid >= 0] = x[cid[cid >= 0]]
-            for cw in range(NC):
-                k = c * NC + cw
-                ss = lds_off[k]
+            images.append(lds)
+        for cw in range(NC):
+            ss = lds_off[t * NC + cw]
+            for c in range(tcp[t], tcp[t + 1]):
+                lds = images[c - tcp[t]]
                 for j in range(NACC):
-                    for _ in range(int(lds_cnt[k, j])):
+                    for _ in range(int(lds_cnt[c * NC + cw, j])):
                         for g in range(GROUPS):
                             for u in range(4):
                                 acc[(cw * NACC + j) * GROUPS + g] += lds[lds_stream[ss, g, u]]
                         ss += 1
-                assert ss == lds_off[k + 1]
+            assert ss == lds_off[t * NC + cw + 1]
         for cw in range(NC):
             k = t * NC + cw
             ss = dir_off[k]
@@ -278,6 +361,14 @@ def emulate(plan, x, out_rows, num_slots=0):
             else:
                 partial[-(it + 1)] += acc[p]
     return out, partial
+
+
+TILE_SPLIT = int(os.environ.get("MGX_TILE_SPLIT", 2048))  # hub threshold of the tile kernel's work items
+
+
+def config():
+    """(consumers, nacc, loaders, tau); MGX_TILE_CFG=14x6x2x2 overrides."""
+    return tuple(int(v) for v in os.environ.get("MGX_TILE_CFG", "14x6x2x2").split("x"))
 
 
 def tile_plan_wanted(csr):

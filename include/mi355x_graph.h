@@ -177,25 +177,26 @@ int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan /*
 
 /* LDS-staged copy_u / sum | mean for DENSE neighbourhoods (round 3; csrc/spmm_tile.hip).  On graphs with hundreds of in-edges
  * per node (reddit, proteins: kernel/dgl-new.py:61; main_dgl_reddit_sage.py:73-80) destination rows scheduled next to each other
- * share most of their sources; a TILE of consumers * nacc * 4 work items of the schedule is aggregated by one 1024-thread
- * workgroup that gathers each of the tile's re-used sources ONCE from L2 into LDS (chunks of 127 rows x 64 columns, LDS-DMA,
+ * share most of their sources; a TILE of consumers * nacc * 4 work items of the schedule is aggregated by one workgroup of
+ * consumers + loaders = 16 waves (one per CU) or 8 waves (two per CU) that gathers each of the tile's re-used sources ONCE from L2 into LDS (chunks of 127 rows x 64 columns, LDS-DMA,
  * 4-deep ring, `loaders` loader waves) and serves every edge into it from LDS; sources used once in the tile are gathered
  * directly.  The tables below replace the graph arrays inside the kernel (built once per CSR by the host layer,
  * mi355x_graph/tileplan.py; all device memory, caller-owned):
  *   tile_chunk_ptr [num_tiles+1]            chunks of tile t are [ptr[t], ptr[t+1])
  *   chunk_ids      [num_chunks*128]         source row of every LDS slot, -1 = all-zero row (slot 127 always)
- *   lds_off        [num_chunks*consumers+1] first step of the stream of (chunk, consumer wave)
- *   lds_cnt        [num_chunks*consumers*8] uint16 supersteps (4 steps) of (chunk, wave, accumulator j < nacc)
- *   lds_stream     [lds_steps]              one byte per lane group and step: the LDS slot to add (127 = zero row)
- *   dir_off / dir_cnt (int32) / dir_stream  the same per (tile, wave) for the direct part; dir_stream holds 4 source ids
- *                                           per step, -1 = padding
+ *   lds_off        [num_tiles*consumers+1]  first superstep of the stream of (tile, consumer wave): its chunks, then rows j
+ *   lds_cnt        [num_chunks*consumers*16] uint16 supersteps (4 steps each) of (chunk, wave, accumulator j < nacc)
+ *   lds_stream     [(lds_steps+64)*4]       per superstep and lane group one dword = the LDS slots of its four steps
+ *                                           (127 = zero row); 64 supersteps of padding behind the end (prefetch)
+ *   dir_off        [num_tiles*consumers+1]  the same for the direct part; dir_cnt int32 [num_tiles*consumers*16];
+ *   dir_stream     [(dir_steps+64)*16]      per superstep and lane group four source ids, -1 = padding
  *   tile_item      [num_tiles*R]            item_row of the work item at every (wave, j, lane group), INT32_MIN = none
  *   zero_row       [64] floats of zeros
  * Work items are those of `plan` (hub rows stay split: partial_ws / fix-up as for mgx_spmm_csr; plan may be NULL when the tile
  * plan was built over natural rows).  32-bit indices, D and both strides multiples of 4, 16-byte aligned operands, gathered
  * matrix below 4 GiB; otherwise MGX_ERR_UNSUPPORTED (call mgx_spmm_csr).  Deterministic: no atomics. */
 typedef struct mgx_tile_plan {
-  int64_t num_tiles, num_chunks, lds_steps, dir_steps;
+  int64_t num_tiles, num_chunks, lds_steps, dir_steps; /* steps: supersteps without the padding */
   int32_t consumers, nacc, loaders, reserved;
   const int32_t* tile_chunk_ptr;
   const int32_t* chunk_ids;

@@ -18,7 +18,35 @@ import oracle_backend
 PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dgl-0.5-benchmark_amd")
 
 
-def make_problem():
+def make_ring_problem(world):
+    """`world` UNEVEN blocks of nodes; edges inside a block and between block b and b + 1 only: non-adjacent peer pairs exchange
+    nothing (empty halo both ways), adjacent pairs exchange different amounts, the assignment is given (no partitioner)."""
+    g = torch.Generator().manual_seed(4)
+    sizes = [30 + 17 * ((3 * b) % 5) for b in range(world)]
+    starts = np.concatenate([[0], np.cumsum(sizes)])
+    n = int(starts[-1])
+    assign = torch.repeat_interleave(torch.arange(world), torch.tensor(sizes))
+    src, dst = [], []
+    for b in range(world):
+        k = 6 * sizes[b]
+        src.append(torch.randint(int(starts[b]), int(starts[b + 1]), (k,), generator=g))
+        dst.append(torch.randint(int(starts[b]), int(starts[b + 1]), (k,), generator=g))
+        if b + 1 < world:
+            k = 2 * min(sizes[b], sizes[b + 1]) + 5 * b
+            u = torch.randint(int(starts[b]), int(starts[b + 1]), (k,), generator=g)
+            v = torch.randint(int(starts[b + 1]), int(starts[b + 2]), (k,), generator=g)
+            src += [u, v]
+            dst += [v, u]
+    src, dst = torch.cat(src), torch.cat(dst)
+    feats = torch.rand(n, 12, generator=g)
+    labels = torch.randint(0, 5, (n,), generator=g)
+    train = torch.rand(n, generator=g) < 0.3
+    return n, src, dst, feats, labels, train, assign
+
+
+def make_problem(ring_world=0):
+    if ring_world:
+        return make_ring_problem(ring_world)[:6]
     from mi355x_graph.datasets import synthetic_edges
     n = 600
     src, dst = synthetic_edges(n, 4000, 60, seed=3, symmetric=True)
@@ -36,9 +64,9 @@ def build_model(batch_norm=False):
     return full_graph.GraphSAGE(12, 8, 5, 3, dropout=0.0, batch_norm=batch_norm)
 
 
-def single_process_reference(device="cpu", batch_norm=False):
+def single_process_reference(device="cpu", batch_norm=False, ring_world=0):
     import torch.nn.functional as F
-    n, src, dst, feats, labels, train = [t.to(device) if isinstance(t, torch.Tensor) else t for t in make_problem()]
+    n, src, dst, feats, labels, train = [t.to(device) if isinstance(t, torch.Tensor) else t for t in make_problem(ring_world)]
     g = mg.graph((src, dst), num_nodes=n).int()
     model = build_model(batch_norm).to(device)
     out = model(g, feats)
@@ -60,14 +88,19 @@ def generic_path(g, x):
     return g.ndata["o"]
 
 
-def _worker(rank, world, port, q, device="cpu", batch_norm=False):
+def _worker(rank, world, port, q, device="cpu", batch_norm=False, ring=False):
     import torch.nn.functional as F
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if device == "cpu":
         oracle_backend.install()  # CPU tensors: arithmetic by the test-only oracle backend
-    n, src, dst, feats, labels, train = [t.to(device) if isinstance(t, torch.Tensor) else t for t in make_problem()]
-    assign, stats = mdist.partition_nodes(src, dst, n, world)
+    n, src, dst, feats, labels, train = [t.to(device) if isinstance(t, torch.Tensor) else t for t in make_problem(world if ring else 0)]
+    if ring:
+        assign = make_ring_problem(world)[6].to(device)
+        stats = {"edge_cut": float((assign[src] != assign[dst]).float().mean())}
+    else:
+        assign, stats = mdist.partition_nodes(src, dst, n, world)
     block, plan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
     g = mdist.DistGraph(block, plan)
     model = build_model(batch_norm).to(device)
@@ -111,19 +144,19 @@ def _worker(rank, world, port, q, device="cpu", batch_norm=False):
     dist.destroy_process_group()
 
 
-def _run_two_way(device, batch_norm=False, world=2):
+def _run_two_way(device, batch_norm=False, world=2, ring=False):
     if device == "cpu":
         oracle_backend.install()
     try:
-        ref_out, ref_loss, ref_grads, ref_generic, ref_buffers = single_process_reference(device, batch_norm)
+        ref_out, ref_loss, ref_grads, ref_generic, ref_buffers = single_process_reference(device, batch_norm, world if ring else 0)
     finally:
         oracle_backend.uninstall()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000 + (7 if device != "cpu" else 0)
     port += 11 if batch_norm else 0
-    port += 23 * (world - 2)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, device, batch_norm)) for r in range(world)]
+    port += 23 * (world - 2) + (5 if ring else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, device, batch_norm, ring)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=240) for _ in range(world)]
@@ -144,7 +177,7 @@ def _run_two_way(device, batch_norm=False, world=2):
         assert abs(lsum - ref_loss) < 1e-5
         for g, r in zip(grads, ref_grads):
             assert np.allclose(g, r.numpy(), rtol=1e-4, atol=1e-6)
-        assert 0.0 < stats["edge_cut"] < 0.6 and n_halo > 0 and n_send > 0
+        assert 0.0 < stats["edge_cut"] < 0.6 and (ring or (n_halo > 0 and n_send > 0))
     assert seen.all()
     assert torch.allclose(got, ref_out, rtol=1e-4, atol=1e-6)
     assert torch.allclose(got_generic, ref_generic, rtol=1e-4, atol=1e-6)
@@ -159,6 +192,14 @@ def test_two_way_partition_matches_single_process():
 def test_three_way_partition_matches_single_process():
     """world_size 3: uneven per-peer splits, peers with different halo sizes, the fixed per-peer scatter order."""
     _run_two_way("cpu", world=3)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [4, 8])
+def test_ring_of_uneven_parts_matches_single_process(world):
+    """world_size 4 and 8 with a GIVEN assignment: uneven parts, peer pairs with an empty halo in both directions (only
+    adjacent blocks are linked), DistCopyU's split exchange and GradBucket's flat all_reduce across every rank."""
+    _run_two_way("cpu", world=world, ring=True)
 
 
 @pytest.mark.timeout(300)
@@ -306,3 +347,32 @@ def test_cached_partition_roundtrip(tmp_path):
     src2, dst2 = synthetic_edges(n, 20000, 100, seed=2, symmetric=True)
     _, s3 = mdist.cached_partition(src2[:src.shape[0]], dst2[:src.shape[0]], n, 4, cache_dir=str(tmp_path))
     assert s3["cached"] is False
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_line_of_a_two_rank_run_matches_the_one_rank_run():
+    """`python bench.py --gpus 2` end to end (self-launch -> torch.distributed.run children -> partition -> DistGraph model ->
+    JSON line): both ranks on cuda:0 over gloo staging (MGX_BENCH_SHARE_GPU=1), a 2 % graph, dropout 0.  The line must say
+    n_gpus 2, carry the partition statistics, and end at the loss of the 1-rank run of the same command."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--scale", "0.02", "--steps", "2", "--warmup", "1", "--no-pmc",
+            "--no-controls", "--no-cpu-baseline", "--no-plain", "--dropout", "0"]
+    env = dict(os.environ, MGX_BENCH_SHARE_GPU="1", MGX_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    lines = {}
+    for gpus in (1, 2):
+        p = subprocess.run(base + ["--gpus", str(gpus)], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+        lines[gpus] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    one, two = lines[1], lines[2]
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["steps"] == 2 and two["warmup"] == 1
+    part = two["config"]["partition"]
+    assert 0.0 < part["edge_cut_pct"] < 60.0 and len(part["per_rank"]) == 2
+    assert all(r["owned_rows"] > 0 and r["halo_rows"] > 0 and r["send_rows"] > 0 for r in part["per_rank"])
+    assert sum(r["owned_rows"] for r in part["per_rank"]) == one["roofline"]["rows"]
+    assert two["value"] > 0 and two["ms_per_step"] > 0 and two["scaling"] == "strong"
+    assert abs(two["config"]["final_loss"] - one["config"]["final_loss"]) <= 1e-4 * max(1.0, abs(one["config"]["final_loss"]))
+    assert two["roofline"] is not None and two["roofline"]["frac"] > 0
