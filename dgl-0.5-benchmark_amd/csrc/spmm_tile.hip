@@ -22,6 +22,8 @@
 //   * epilogue: mean / dst_scale / accumulate, one 256-byte store per row; hub chunks write partial rows for
 //     spmm_hub_fixup_kernel.  No atomics: fixed summation order for a given plan.
 // Rows wider than 64 columns run as column passes (grid.y) over the same streams.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mgx {
@@ -31,7 +33,7 @@ constexpr int kPassCols = 64;                           // columns per pass: 16 
 constexpr int kSlotBytes = kPassCols * 4;               // 256
 constexpr int kChunkBytes = kChunkSlots * kSlotBytes;   // 32 KiB
 constexpr int kDmaPerChunk = kChunkBytes / 1024;        // LDS-DMA wave-instructions (1 KiB each) per chunk
-constexpr int kStreamRingBytes = 1024;                  // per consumer wave: 4 stream windows of 16 supersteps x 16 bytes
+constexpr int kStreamRingBytes = 1024;                  // per wave: 4 windows of 16 supersteps x 16 bytes of the staged part's stream
 constexpr int kNoItem = INT32_MIN;
 
 struct TileArgs {
@@ -159,7 +161,7 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int
 #pragma unroll
   for (int j = 0; j < NACC; ++j) acc[j] = (v4f)(0.f);
 #ifdef MGX_TILE_STAMPS
-  unsigned long long t_bar = 0, t_lds = 0, t_dir = 0, n_ss = 0;
+  unsigned long long t_bar = 0, t_lds = 0, t_dir = 0, n_ss = 0, td0 = 0, td1 = 0;
   const unsigned long long t_begin = MGX_STAMP();
 #endif
 
@@ -170,6 +172,7 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int
   // window test is the only branch of the inner loop and has no register results (a load into registers under that branch
   // made hipcc wait for it at the loop's back edge).  Window k is complete when at most ONE younger DMA is outstanding.
   // ---- staged part: chunks from LDS.  Stream layout [superstep][lane group][4 steps]: one dword per lane group and superstep.
+  auto staged_part = [&]() {
   if (n > 0) {
     const auto* cnt = as_const(reinterpret_cast<const v4u*>(a.lds_cnt));  // 16 uint16 = two quads per (chunk, wave)
     int64_t k = (int64_t)cbeg * NC + cw;
@@ -252,19 +255,21 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int
     }
   }
 
+  };
+
   // ---- direct part: sources used once in this tile, gathered from global memory.  Stream layout [superstep][lane group][4 ids]
-  // = 64 bytes per superstep; its windows (1 KiB) live where the chunk ring was: every consumer has left the staged part
-  // (barrier; the loader waves have exited and no longer count).
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // = 64 bytes per superstep; its windows (1 KiB = 16 supersteps) live where the chunk ring was: every consumer has left the
+  // staged part (barrier; the loader waves have exited and no longer count).
+  auto direct_part = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef MGX_TILE_STAMPS
-  const unsigned long long td0 = MGX_STAMP();
+    td0 = MGX_STAMP();
 #endif
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 #ifdef MGX_TILE_STAMPS
-  const unsigned long long td1 = MGX_STAMP();
+    td1 = MGX_STAMP();
 #endif
-  {
     const int64_t k = (int64_t)tile * NC + cw;
     const int so = as_const(a.dir_off)[k], se = as_const(a.dir_off)[k + 1];  // supersteps
     if (se > so) {
@@ -287,7 +292,7 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int
       auto ids = [&](int i) -> v4i { return *reinterpret_cast<const v4i*>(dwin + (i & 63) * 64 + g * 16); };
       auto open_window = [&](int upto) {
         if (upto >= ready) {
-          wait_vmcnt<1>();  // also retires the row gathers of the previous supersteps: they are older than the window
+          wait_vmcnt<1>();  // the row gathers of the previous supersteps have been consumed: only window DMAs are in flight
           dma((ready >> 4) + 2);
           ready += 16;
         }
@@ -333,11 +338,19 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int
         }
       }
     }
-  }
+#ifdef MGX_TILE_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    t_dir = MGX_STAMP() - td1;
+#endif
+  };
+
+  // (Measured and dropped: tiles alternating the ORDER of the two parts by dispatch round, with the direct part's windows in a
+  // private ring, so that half of the resident workgroups stream rows through the fabric while the other half keeps the LDS
+  // pipes busy -- reddit shape D = 64: 1.15 -> 1.27 ms; the direct part of a tile took 260 k cycles instead of 134-191 k.)
+  staged_part();
+  direct_part();
 
 #ifdef MGX_TILE_STAMPS
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  t_dir = MGX_STAMP() - td1;
   if (a.stamps && lane == 0) {
     unsigned long long* o = a.stamps + ((int64_t)tile * 16 + (cw + NL)) * 8;
     o[0] = t_bar; o[1] = t_lds; o[2] = t_dir; o[3] = MGX_STAMP() - t_begin; o[4] = n_ss; o[5] = td1 - td0; o[6] = t_begin; o[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20) /* XCC_ID */;

@@ -37,7 +37,7 @@ class CategoricalEncoder(nn.Module):
         # one GEMM each way instead of num_columns lookups + adds -- and safe to capture in a HIP graph: the sort-based
         # backward of torch.embedding reads a segment count back to the host (thrust::unique_by_key_copy), which under
         # capture bakes whatever that memory held into the following launches (the replay then faulted inside
-        # rocprim::partition_kernel, experiments/dbg_molhiv_graph2.py).
+        # rocprim::partition_kernel; bisected in round 2).
         card = self.tables[0].num_embeddings
         codes = F.one_hot(x, card).to(self.tables[0].weight.dtype).flatten(1)       # [rows, columns * cardinality]
         return codes @ torch.cat([t.weight for t in self.tables], dim=0)
@@ -174,7 +174,7 @@ class GraphedBatchTrainer(object):
     (MaskedBatchNorm1d); the loss is the mean over the real graphs.  A batch larger than the static shape (4.5 sigma above
     the mean batch: ~1 in 300,000) is trained as two half batches.
     One captured graph, no eager steps in between: replaying an older capture after a later, larger one faulted on
-    ROCm 7.2 in this loop (experiments/dbg_molhiv_graph.py), so there is a single static shape rather than buckets."""
+    ROCm 7.2 in this loop (bisected in round 2), so there is a single static shape rather than buckets."""
 
     def __init__(self, model, optimizer, loss_fn, device, batch_size, n_pad, e_pad):
         if not isinstance(loss_fn, nn.BCEWithLogitsLoss) or loss_fn.reduction != "mean":
@@ -247,7 +247,7 @@ class GraphedBatchTrainer(object):
         # Warm-up and capture run on ONE side stream.  Autograd remembers the stream a parameter's gradient accumulator
         # first ran on; capturing on a different stream makes every accumulation a cross-stream fork / join inside the
         # graph, and such a forked graph gave NaNs after a hipDeviceSynchronize between replays on ROCm 7.2 (GIN, 5
-        # layers; experiments/dbg_gin_nan2.py).  Same stream -> a linear graph.
+        # layers; bisected in round 2).  Same stream -> a linear graph.
         side = self.side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         from mi355x_graph import ops as _ops
@@ -290,18 +290,33 @@ class GraphedBatchTrainer(object):
         if self.graph is None:
             self._capture(pad)
             self.done = torch.cuda.Event()
-        else:
-            # The previous replay must have FINISHED before its static inputs are overwritten.  Stream order alone did not
-            # guarantee that here: with only the (blocking) host-to-device copies between replays the loop faulted on
-            # ROCm 7.2 (a kernel of the running graph read a half-rewritten batch_num_nodes), with a host-side wait it
-            # never did (experiments/dbg_molhiv_graph2.py).
-            self.done.synchronize()
+            # pinned staging, two sets in ping-pong: the copies below are then real stream commands (a copy from pageable
+            # memory is carried out by the HOST once the stream has drained what was submitted before it -- which is not
+            # the same thing as "the previous replay has finished" for a graph launch)
+            self.stage = [{k: torch.empty_like(v, device="cpu").pin_memory() for k, v in pad.items()} for _ in range(2)]
+            self.staged = [torch.cuda.Event(), torch.cuda.Event()]
+            self.turn = 0
+        # ONE stream orders everything (round 3): the static inputs are copied and the graph is replayed on
+        # the stream it was captured on, so a replay's kernels, the next step's input copies and the next replay follow each other
+        # in stream order -- no host-side wait for the previous replay, and a device-wide synchronize() anywhere is harmless.
+        i = self.turn
+        self.turn ^= 1
+        self.staged[i].synchronize()  # the copies that last read this staging set (two steps ago) are done
         for k, v in pad.items():
-            self.buf[k].copy_(v)
-        self.graph.replay()
-        self.done.record()
+            self.stage[i][k].copy_(v)
+        with torch.cuda.stream(self.side):
+            for k in pad:
+                self.buf[k].copy_(self.stage[i][k], non_blocking=True)
+            self.staged[i].record()
+            self.graph.replay()
+            self.done.record()
         self.stats["replayed"] += 1
         return self.loss
+
+    def loss_value(self):
+        """The last step's loss on the host (waits for that replay: it ran on the capture stream, not the current one)."""
+        self.done.synchronize()
+        return float(self.loss.detach())
 
 
 def train_epoch_graphed(trainer, loader):
@@ -309,12 +324,12 @@ def train_epoch_graphed(trainer, loader):
     loss = None
     for i, (batched_graph, labels) in enumerate(loader):
         loss = trainer.step(batched_graph, labels)
-        if os.environ.get("MGX_DEBUG_NAN") == "1" and not bool(torch.isfinite(loss)):
+        if os.environ.get("MGX_DEBUG_NAN") == "1" and not (trainer.done.synchronize() or bool(torch.isfinite(loss))):
             bad = [n for n, p_ in trainer.model.named_parameters() if not bool(torch.isfinite(p_).all())]
             raise SystemExit("non-finite loss at step %d: n %d e %d b %d ghosts %d, non-finite parameters %s" % (
                 i, batched_graph.number_of_nodes(), batched_graph.number_of_edges(), labels.shape[0],
                 trainer.n_pad - batched_graph.number_of_nodes(), bad[:4]))
-    return loss.item()
+    return trainer.loss_value()
 
 
 def train_epoch(model, device, loader, optimizer, loss_fn):
@@ -370,11 +385,10 @@ def main():
         t0 = time.time()
         if trainer is not None:
             loss = train_epoch_graphed(trainer, loader)
-            # the epoch's last replay has finished (loss.item() read its output; the event covers the Adam update).  NOT a
-            # device-wide synchronize: with torch.cuda.synchronize() between epochs the 5-layer GIN's replays turned NaN some
-            # 40 steps later on ROCm 7.2, without it (or with any extra per-step allocation) never -- unexplained, see
-            # experiments/dbg_gin_nan2.py (variants D / E); the GCN of the reference is unaffected either way.
-            trainer.done.synchronize()
+            # loss_value() waited for the epoch's last replay (the event covers the Adam update).  Round 2 avoided a device-wide
+            # synchronize here (later replays of the 5-layer GIN turned NaN); with copies and replays ordered on one stream
+            # (GraphedBatchTrainer.step) it is harmless -- tests/test_graphed_batches.py soaks 300 replays with one every 10.
+            torch.cuda.synchronize()
         else:
             loss = train_epoch(model, device, loader, opt, loss_fn)
             torch.cuda.synchronize()

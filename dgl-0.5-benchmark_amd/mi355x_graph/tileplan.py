@@ -367,8 +367,8 @@ TILE_SPLIT = int(os.environ.get("MGX_TILE_SPLIT", 2048))  # hub threshold of the
 
 
 def config():
-    """(consumers, nacc, loaders, tau); MGX_TILE_CFG=14x6x2x2 overrides."""
-    return tuple(int(v) for v in os.environ.get("MGX_TILE_CFG", "14x6x2x2").split("x"))
+    """(consumers, nacc, loaders, tau); MGX_TILE_CFG=14x6x2x3 overrides (default: 8-wave workgroups, two per CU)."""
+    return tuple(int(v) for v in os.environ.get("MGX_TILE_CFG", "7x8x1x3").split("x"))
 
 
 def tile_plan_wanted(csr):
