@@ -495,7 +495,7 @@ def main():
             try:
                 roofline["controls"] = kc.run_controls(device, [k for k in kc.CONTROLS if k != "products"], (D,), args.scale, reps=5)
                 roofline["controls"]["note"] = ("same kernel, same N and E, other edge structure (kernel_controls.py); counter "
-                                                "traffic per control: profiles/r02_controls.txt")
+                                                "traffic per control: profiles/r03_controls.txt")
             except Exception as err:  # a control graph must not lose the bench line
                 roofline["controls"] = {"error": str(err)[:200]}
         if single and args.dataset == "products" and not args.no_pmc:

@@ -80,15 +80,17 @@ def banded_edges(n, e, seed, device, half_width=2048):
     return (dst + off).clamp_(0, n - 1), dst
 
 
-def clustered_edges(n, m, max_deg, seed, device, family=48):
-    """A control with real NEIGHBOURHOOD OVERLAP (the benchmark generator's communities have none inside -- their
-    edges are random pairs): products' node and edge counts and power-law endpoints, but half of the edges stay inside small
-    FAMILIES of ~`family` nodes (dense groups: a node with 50 edges has ~25 of them among its ~48 family members, so two
-    neighbours of a node are likely neighbours of each other -- co-purchase graphs have clustering ~0.4), a quarter inside
-    the usual communities and a quarter anywhere.  Average local clustering of the result: experiments/exp_clustered_control.py."""
+def clustered_edges(n, m, max_deg, seed, device, family=60, family_share=0.75):
+    """A control with real NEIGHBOURHOOD OVERLAP: products' node and edge counts and power-law endpoints, but
+    `family_share` of the edges stay inside small FAMILIES of ~`family` nodes -- dense groups (a node with 50 edges has ~37 of them
+    among its ~60 family members), so two neighbours of a node are likely neighbours of each other; the rest goes half inside the
+    usual communities, half anywhere.  Average local clustering, measured on the full-size graph
+    (experiments/exp_clustered_control.py, profiles/r03_clustered_control.txt): this control ~0.3 (co-purchase graphs: ~0.4), the
+    benchmark generator 0.16 (its power-law hubs close triangles inside a community), a structure-free power law 0.04."""
     from mi355x_graph.datasets import synthetic_edges
-    s1, d1 = synthetic_edges(n, m // 2, max_deg, seed, device, mixing=0.0, avg_comm=family, symmetric=True)
-    s2, d2 = synthetic_edges(n, m - m // 2, max_deg, seed + 1, device, mixing=0.5, symmetric=True)
+    m1 = int(m * family_share)
+    s1, d1 = synthetic_edges(n, m1, max_deg, seed, device, mixing=0.0, avg_comm=family, symmetric=True)
+    s2, d2 = synthetic_edges(n, m - m1, max_deg, seed + 1, device, mixing=0.5, symmetric=True)
     return torch.cat([s1, s2]), torch.cat([d1, d2])
 
 

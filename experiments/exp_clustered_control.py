@@ -66,11 +66,17 @@ def main():
     p.add_argument("--scale", type=float, default=1.0)
     p.add_argument("--widths", default="64")
     p.add_argument("--graphs", default="clustered,products")
+    p.add_argument("--clustering-scale", type=float, default=1.0, help="size of the copy the local clustering is measured on")
+    p.add_argument("--clustering-only", action="store_true")
     args = p.parse_args()
     be = sparse.backend_for(torch.zeros(1, device=dev))
     for kind in args.graphs.split(","):
-        ns, (s, d) = kc.control_edges(kind, dev, 0.02)
-        print("%s: average local clustering %.3f (2 %% copy: N=%d E=%d)" % (kind, clustering(ns, s, d), ns, s.numel()), flush=True)
+        ns, (s, d) = kc.control_edges(kind, dev, args.clustering_scale)
+        print("%s: average local clustering %.3f over 2000 sampled nodes (scale %g: N=%d E=%d)" % (kind, clustering(ns, s, d), args.clustering_scale, ns, s.numel()), flush=True)
+        del s, d
+        torch.cuda.empty_cache()
+        if args.clustering_only:
+            continue
         n, (src, dst) = kc.control_edges(kind, dev, args.scale)
         csr = sparse.coo_to_csr(n, n, dst.int().contiguous(), src.int().contiguous())
         del src, dst

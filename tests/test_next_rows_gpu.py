@@ -236,6 +236,7 @@ def test_fused_sage_layer_node_matches_the_composition(monkeypatch):
     x0 = torch.randn(n, 48, device=DEV)
     w = torch.randn(n, 32, device=DEV)
     res = []
+    monkeypatch.setenv("MGX_SAGE_PROJECT_FIRST", "0")  # 48 -> 32 with a differentiable input would project first (below)
     for fused in ("1", "0"):
         monkeypatch.setenv("MGX_SAGE_FUSED_LAYER", fused)
         x = x0.clone().requires_grad_(True)
@@ -246,6 +247,20 @@ def test_fused_sage_layer_node_matches_the_composition(monkeypatch):
         assert (type(y.grad_fn).__name__ == "SageMeanLayerFnBackward") == (fused == "1")
     for a, b in zip(*res):
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6
+    # the projection BEFORE the aggregation (ops.SageMeanProjectFirstFn; upstream dgl.nn.SAGEConv's lin_before_mp): same layer
+    monkeypatch.setenv("MGX_SAGE_PROJECT_FIRST", "1")
+    x = x0.clone().requires_grad_(True)
+    conv.zero_grad()
+    y = conv(g, x)
+    assert type(y.grad_fn).__name__ == "SageMeanProjectFirstFnBackward"
+    (y * w).sum().backward()
+    for a, b in zip([y.detach(), x.grad] + [p.grad.clone() for p in conv.parameters()], res[1]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6
+    # a constant input and a narrow output (reddit: 602 -> 16): project first; products' 100 -> 64 keeps the aggregation first
+    wide = full_graph.SAGEConv(600, 16).to(DEV)
+    assert type(wide(g, torch.randn(n, 600, device=DEV)).grad_fn).__name__ == "SageMeanProjectFirstFnBackward"
+    keep = full_graph.SAGEConv(100, 64).to(DEV)
+    assert type(keep(g, torch.randn(n, 100, device=DEV)).grad_fn).__name__ != "SageMeanProjectFirstFnBackward"
     assert ops.sage_mean_layer(g, x0.double(), conv.fc_self.weight, conv.fc_neigh.weight) is None  # fp64: not this path
 
 
