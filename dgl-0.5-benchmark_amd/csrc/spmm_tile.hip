@@ -51,6 +51,7 @@ struct TileArgs {
   const int32_t* dir_cnt;
   const int32_t* dir_stream;
   const int32_t* tile_item;
+  const int32_t* tile_order;  // optional: dispatch slot -> tile (longest tiles of an XCD's stretch first)
   const float* zero_row;
   int num_tiles, tiles_per_xcd;
   int D, lds, ldo;  // columns, row strides (floats) of x and out
@@ -386,8 +387,9 @@ __global__ __launch_bounds__(W * kWave, 4) void spmm_tile_kernel(const TileArgs 
   const int lane = threadIdx.x & (kWave - 1);
   // block b serves XCD b % 8 (observed round-robin placement; speed only): consecutive tiles of the schedule -- which share
   // sources -- stay on one XCD's L2
-  const int tile = (int)(blockIdx.x % kXcds) * a.tiles_per_xcd + (int)(blockIdx.x / kXcds);
-  if (tile >= a.num_tiles) return;
+  const int slot = (int)(blockIdx.x % kXcds) * a.tiles_per_xcd + (int)(blockIdx.x / kXcds);
+  if (slot >= a.num_tiles) return;
+  const int tile = a.tile_order ? a.tile_order[slot] : slot;
   const int cbeg = a.tile_chunk_ptr[tile];
   const int n = a.tile_chunk_ptr[tile + 1] - cbeg;
   const int col0 = blockIdx.y * kPassCols;
@@ -454,7 +456,7 @@ extern "C" int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan*
   a.x = ufeat; a.out = out; a.partial = partial_ws; a.dst_scale = dst_scale; a.indptr = (const int32_t*)csr->indptr;
   a.tile_chunk_ptr = tp->tile_chunk_ptr; a.chunk_ids = tp->chunk_ids; a.lds_off = tp->lds_off; a.lds_cnt = tp->lds_cnt;
   a.lds_stream = tp->lds_stream; a.dir_off = tp->dir_off; a.dir_cnt = tp->dir_cnt; a.dir_stream = tp->dir_stream;
-  a.tile_item = tp->tile_item; a.zero_row = tp->zero_row;
+  a.tile_item = tp->tile_item; a.zero_row = tp->zero_row; a.tile_order = tp->tile_order;
   a.num_tiles = (int)tp->num_tiles;
   a.tiles_per_xcd = (int)((tp->num_tiles + kXcds - 1) / kXcds);
   a.D = (int)D; a.lds = (int)u_stride; a.ldo = (int)out_stride;

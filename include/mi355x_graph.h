@@ -192,6 +192,7 @@ int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan /*
  *   dir_stream     [(dir_steps+64)*16]      per superstep and lane group four source ids, -1 = padding
  *   tile_item      [num_tiles*R]            item_row of the work item at every (wave, j, lane group), INT32_MIN = none
  *   zero_row       [64] floats of zeros
+ *   tile_order     [num_tiles] or NULL: the tile each dispatch slot runs (the builder puts an XCD's longest tiles first)
  * Work items are those of `plan` (hub rows stay split: partial_ws / fix-up as for mgx_spmm_csr; plan may be NULL when the tile
  * plan was built over natural rows).  32-bit indices, D and both strides multiples of 4, 16-byte aligned operands, gathered
  * matrix below 4 GiB; otherwise MGX_ERR_UNSUPPORTED (call mgx_spmm_csr).  Deterministic: no atomics. */
@@ -208,6 +209,7 @@ typedef struct mgx_tile_plan {
   const int32_t* dir_stream;
   const int32_t* tile_item;
   const float* zero_row;
+  const int32_t* tile_order; /* optional [num_tiles]: dispatch slot -> tile; slots [x * ceil(T/8), ...) run on XCD x in order */
 } mgx_tile_plan;
 int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, const mgx_tile_plan* tile_plan,
                              int32_t reduce, const float* ufeat, int64_t D, int64_t u_stride, const float* dst_scale /* may be NULL */,
