@@ -57,6 +57,7 @@ struct GatArgs {
   uint64_t seed;
   const float* gat;     // gathered matrix [*, D]: feat (FWD, BWD_DST) or d out (BWD_SRC)
   const float* el;      // [num_src, H]
+  const float* attn;    // ELK kernels: attn_l [H, F] -- el[u,h] = <gat[u,h,:], attn[h,:]> is formed from the gathered row instead
   const float* er;      // [num_dst, H]  (stats kernel)
   const float* nstat;   // [num_dst, H, 4] = (er, m, 1/s, t)
   float* nstat_w;
@@ -137,7 +138,11 @@ struct GatUnroll {
 // lane with dword-aligned accesses; the lane that owns the last 1-3 columns works on the row's LAST four floats instead --
 // nothing is read past a row -- with the components that belong to its neighbour zeroed in the row-constant operand (dot
 // products) and left out of the store (the same windows as spmm.hip / sddmm.hip use).
-template <int G, int LPH, int MODE, bool DROP, bool RAGGED = false>
+// ELK ("el in kernel", several heads per row, unpacked operands: the 8 x 16 layers of BASELINE config 3): the attention term
+// el[u,h] = <feat[u,h,:], attn_l[h,:]> of a gathered source is formed from the row the lane group already holds -- 4 multiply-adds
+// and log2(LPH) lane swaps per edge instead of a fifth L2 request per edge.  The source walk (BWD_SRC) forms its own el[u] from
+// the row-constant feat[u] the same way, so every walk rebuilds the same logit bit for bit.
+template <int G, int LPH, int MODE, bool DROP, bool RAGGED = false, bool ELK = false>
 __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
   typedef v4f v4u __attribute__((aligned(4)));
   typedef typename std::conditional<RAGGED, v4u, v4f>::type V4;
@@ -163,6 +168,14 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
       if (nvalid < 2) v.z = 0.f;
     }
     return v;
+  };
+  v4f al = (v4f)(0.f);
+  if (ELK && fact) al = *reinterpret_cast<const v4f*>(a.attn + f);  // attn_l[head, (l % LPH) * 4 ..]: flat index = this lane's column
+  auto head_dot = [&](const v4f& v) -> float {  // <row[h,:], attn_l[h,:]> over the LPH lanes of this lane's head
+    float e = v.x * al.x + v.y * al.y + v.z * al.z + v.w * al.w;
+#pragma unroll
+    for (int off = 1; off < LPH; off <<= 1) e += __shfl_xor(e, off, kWave);
+    return e;
   };
   const uint32_t hbytes = (uint32_t)a.small_ld * 4u;  // per-node stride of the small per-head array (el: H floats, nstat: 4H; packed: the row stride)
   const uint32_t h4 = (uint32_t)head * (MODE == GAT_BWD_SRC ? 16u : 4u);
@@ -213,8 +226,9 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
     }
     if (MODE == GAT_BWD_SRC && fact) {
       ra = clip((v4f)*reinterpret_cast<const V4*>(a.rowa + row * D + fw));  // feat[u]
-      c_el = a.el[row * H + head];
+      if (!ELK) c_el = a.el[row * H + head];
     }
+    if (MODE == GAT_BWD_SRC && ELK) c_el = head_dot(ra);  // every lane takes part in the swaps (idle lanes hold zeros)
     v4f acc = (v4f)(0.f);
     float hacc = 0.f;  // d er (BWD_DST) / d el (BWD_SRC) of this lane's head
 
@@ -242,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
           ee[u] = DROP ? __builtin_amdgcn_ds_bpermute(bi, eid) : 0;
           val[u] = (v4f)*reinterpret_cast<const V4*>(gatb + off);
           if (MODE == GAT_BWD_SRC) sm[u] = *reinterpret_cast<const v4f*>(smallb + so);
-          else sm[u].x = *reinterpret_cast<const float*>(smallb + so);
+          else if (!ELK) sm[u].x = *reinterpret_cast<const float*>(smallb + so);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -252,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
             const uint64_t rnd = gat_mix64(a.seed ^ ((uint64_t)(uint32_t)ee[u] * (uint64_t)H + (uint64_t)head));
             keep = (uint32_t)rnd >= a.drop_below ? a.keep_scale : 0.f;
           }
+          if (ELK && MODE != GAT_BWD_SRC) sm[u].x = head_dot(val[u]);
           if (MODE == GAT_FWD) {
             const float t = sm[u].x + c_er;
             const float z = t > 0.f ? t : t * a.slope;
@@ -339,6 +354,12 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
 template <int G, int LPH, int MODE>
 static void gat_launch_drop(const GatArgs& a, bool drop, hipStream_t s) {
   const dim3 grid((unsigned)a.nblocks), block(kBlock);
+  if (G >= 16 && LPH >= 2 && LPH < G && a.attn) {  // el formed in the kernel (set by the entry points for unpacked multi-head rows)
+    constexpr int GE = G >= 16 ? G : 16, LE = (LPH >= 2 && LPH < G) ? LPH : 2;
+    if (drop) hipLaunchKernelGGL((gat_fused_kernel<GE, LE, MODE, true, false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gat_fused_kernel<GE, LE, MODE, false, false, true>), grid, block, 0, s, a);
+    return;
+  }
   if (drop) hipLaunchKernelGGL((gat_fused_kernel<G, LPH, MODE, true>), grid, block, 0, s, a);
   else hipLaunchKernelGGL((gat_fused_kernel<G, LPH, MODE, false>), grid, block, 0, s, a);
 }
@@ -490,9 +511,14 @@ extern "C" int64_t mgx_gat_fused_pack_workspace(int64_t num_src, int64_t num_dst
   return rows * ld * (int64_t)sizeof(float);
 }
 
+static bool gat_el_in_kernel(int64_t H, int64_t F, const float* attn_l) {
+  static const bool off = getenv("MGX_GAT_EL_GATHER") != nullptr;  // A/B switch: always gather el
+  return attn_l != nullptr && !off && H > 1 && F % 4 == 0 && F >= 8 && H * F >= 64 && (uintptr_t)attn_l % 16 == 0;
+}
+
 extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, int64_t F, const float* feat,
-                                     const float* el, const float* er, float negative_slope, float drop_p, uint64_t seed,
-                                     float* out, float* nstat, void* workspace, void* pack_ws, void* stream) {
+                                     const float* el, const float* attn_l, const float* er, float negative_slope, float drop_p,
+                                     uint64_t seed, float* out, float* nstat, void* workspace, void* pack_ws, void* stream) {
   using namespace mgx;
   MGX_ENTER();
   int32_t st = gat_check(csr, plan, H, F, csr ? csr->num_cols : 0, drop_p, "mgx_gat_fused_fwd");
@@ -514,6 +540,8 @@ extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* pl
     MGX_CHECK_LAUNCH();
     a.gat = (const float*)pack_ws; a.el = (const float*)pack_ws + round_up(a.D, 4);
     a.gat_ld = pld; a.small_ld = pld;
+  } else if (gat_el_in_kernel(H, F, attn_l)) {
+    a.attn = attn_l;  // unpacked multi-head rows: el from the gathered row
   }
   float* ws = (float*)workspace;  // [slots, D] partial rows, then [slots, 2H] chunk statistics
   a.partial = ws;
@@ -530,9 +558,9 @@ extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* pl
 }
 
 extern "C" int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan, const mgx_csr* csr, const mgx_spmm_plan* csr_plan,
-                                     int64_t H, int64_t F, const float* feat, const float* el, float negative_slope, float drop_p,
-                                     uint64_t seed, const float* out, const float* d_out, float* nstat, float* d_feat, float* d_el,
-                                     float* d_er, void* workspace, void* pack_ws, void* stream) {
+                                     int64_t H, int64_t F, const float* feat, const float* el, const float* attn_l, float negative_slope,
+                                     float drop_p, uint64_t seed, const float* out, const float* d_out, float* nstat, float* d_feat,
+                                     float* d_el, float* d_er, void* workspace, void* pack_ws, void* stream) {
   using namespace mgx;
   MGX_ENTER();
   int32_t st = gat_check(csc, csc_plan, H, F, csc ? csc->num_cols : 0, drop_p, "mgx_gat_fused_bwd");
@@ -560,6 +588,8 @@ extern "C" int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* cs
       MGX_CHECK_LAUNCH();
       a.gat = (const float*)pack_ws; a.el = (const float*)pack_ws + round_up(D, 4);
       a.gat_ld = pld; a.small_ld = pld;
+    } else if (gat_el_in_kernel(H, F, attn_l)) {
+      a.attn = attn_l;
     }
     a.partial_h = (float*)workspace;
     if (!gat_launch<GAT_BWD_DST>(a, drop_p > 0.f, s)) MGX_UNSUPPORTED("mgx_gat_fused_bwd: unsupported head layout");
@@ -574,6 +604,11 @@ extern "C" int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* cs
     GatArgs a;
     gat_fill(a, csr, csr_plan, H, F, negative_slope, drop_p, seed);
     a.gat = d_out; a.el = el; a.nstat = nstat; a.rowa = feat; a.out = d_feat; a.out_h = d_el;
+    {  // the logit's el[u] must be the number the other two walks used: formed in the kernel exactly when they formed it
+      const int pld_el = pack_ws ? gat_pack_ld(H * F, H) : 0;
+      const bool packed_el = pld_el && csc->num_cols * (int64_t)pld_el * 4 < (int64_t(1) << 32);
+      if (!packed_el && gat_el_in_kernel(H, F, attn_l)) a.attn = attn_l;
+    }
     a.small_ld = 4 * (int)H;
     const int pld = pack_ws ? gat_pack_ld(H * F, 4 * H) : 0;
     if (pld && csr->num_cols * (int64_t)pld * 4 < (int64_t(1) << 32)) {  // [d out | (er, m, 1/s, t)] rows: t was written just above

@@ -59,9 +59,9 @@ SIGNATURES = {
     "mgx_gat_attention_bwd": (_i32, [_csr_p, _vp, _i64, _fp, _fp, ctypes.c_float, _fp, _fp, _fp, _fp, _vp]),
     "mgx_gat_fused_workspace": (_i64, [_vp, _i64, _i64]),
     "mgx_gat_fused_pack_workspace": (_i64, [_i64, _i64, _i64, _i64]),
-    "mgx_gat_fused_fwd": (_i32, [_csr_p, _vp, _i64, _i64, _fp, _fp, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _fp, _fp,
+    "mgx_gat_fused_fwd": (_i32, [_csr_p, _vp, _i64, _i64, _fp, _fp, _fp, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _fp, _fp,
                                  _vp, _vp, _vp]),
-    "mgx_gat_fused_bwd": (_i32, [_csr_p, _vp, _csr_p, _vp, _i64, _i64, _fp, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64,
+    "mgx_gat_fused_bwd": (_i32, [_csr_p, _vp, _csr_p, _vp, _i64, _i64, _fp, _fp, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64,
                                  _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _vp]),
     "mgx_head_dot_fwd": (_i32, [_i64, _i64, _i64, _fp, _fp, _fp, _fp, _fp, _vp]),
     "mgx_head_dot_bwd_workspace": (_i64, [_i64, _i64]),

@@ -145,7 +145,8 @@ class GATConv(nn.Module):
             frozen_mask = self.training and self.attn_drop.p > 0.0 and feat_src.is_cuda and ops.capture_path()
             if not get_attention and not frozen_mask and ops.gat_fused_supported(graph, feat_src):
                 # the whole block u_add_v -> leaky_relu -> edge_softmax -> attn_drop -> u_mul_e/sum without any E x H tensor
-                rst = ops.gat_fused(graph, feat_src, el, er, self.leaky_relu.negative_slope, self.attn_drop.p, self.training)
+                rst = ops.gat_fused(graph, feat_src, el, er, self.leaky_relu.negative_slope, self.attn_drop.p, self.training,
+                                    attn_l=self.attn_l)  # el = (feat_src * attn_l).sum(-1), whichever branch above formed it
             # e and a are internal to the module: keep them in in-CSR (destination-major) edge order so that
             # u_add_v, edge_softmax and u_mul_e/sum stream them instead of gathering by edge id
             cidx, perm = graph._index.canonical() if rst is None else (None, None)

@@ -281,9 +281,11 @@ class GATFused(torch.autograd.Function):
     _calls = 0  # advances the counter-based generator: a new mask per call, reproducible after torch.manual_seed
 
     @staticmethod
-    def forward(ctx, gidx, feat, el, er, slope, p):
+    def forward(ctx, gidx, feat, el, er, slope, p, attn_l=None):
         csc = gidx.csc()
         H, F = int(feat.shape[1]), int(feat.shape[2])
+        if attn_l is not None:  # el IS (feat * attn_l).sum(-1): the kernels may form it from the gathered row (no gradient flows
+            attn_l = attn_l.detach().contiguous().view(H, F)  # through this argument: d_el goes back through el's own producer)
         if el.shape[0] != csc.num_cols or er.shape[0] != csc.num_rows or feat.shape[0] != csc.num_cols:
             raise DGLError("gat_fused: expected feat / el with %d source rows and er with %d destination rows, got %d / %d / %d"
                            % (csc.num_cols, csc.num_rows, feat.shape[0], el.shape[0], er.shape[0]))
@@ -293,22 +295,22 @@ class GATFused(torch.autograd.Function):
         if p > 0.0:
             seed = ((torch.initial_seed() & (2 ** 64 - 1)) ^ ((GATFused._calls * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)))
             GATFused._calls += 1
-        out, nstat = sparse.backend_for(feat).gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed)
-        ctx.backward_cache = gidx, float(slope), float(p), seed, el.shape, er.shape
+        out, nstat = sparse.backend_for(feat).gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed, attn_l)
+        ctx.backward_cache = gidx, float(slope), float(p), seed, el.shape, er.shape, attn_l
         ctx.save_for_backward(feat, el2, out, nstat)
         return out
 
     @staticmethod
     @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, d_out):
-        gidx, slope, p, seed, el_shape, er_shape = ctx.backward_cache
+        gidx, slope, p, seed, el_shape, er_shape, attn_l = ctx.backward_cache
         feat, el2, out, nstat = ctx.saved_tensors
         need_src = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         d_feat, d_el, d_er = sparse.backend_for(feat).gat_fused_bwd(gidx.csc(), gidx.csr(), feat, el2, slope, p, seed, out,
-                                                                     d_out.contiguous(), nstat, need_src)
+                                                                     d_out.contiguous(), nstat, need_src, attn_l)
         return (None, d_feat if ctx.needs_input_grad[1] else None,
                 d_el.view(el_shape) if (d_el is not None and ctx.needs_input_grad[2]) else None,
-                d_er.view(er_shape) if ctx.needs_input_grad[3] else None, None, None)
+                d_er.view(er_shape) if ctx.needs_input_grad[3] else None, None, None, None)
 
 
 def gat_fused_supported(graph, feat):
@@ -318,9 +320,11 @@ def gat_fused_supported(graph, feat):
             and sparse.backend_for(feat).gat_fused_supported(gidx.csc(), int(feat.shape[1]), int(feat.shape[2])))
 
 
-def gat_fused(graph, feat, el, er, negative_slope=0.2, attn_drop=0.0, training=True):
+def gat_fused(graph, feat, el, er, negative_slope=0.2, attn_drop=0.0, training=True, attn_l=None):
     """GATConv's u_add_v -> leaky_relu -> edge_softmax -> attn_drop -> u_mul_e/sum block.  feat (N_src, H, F),
-    el (N_src, H[, 1]), er (N_dst, H[, 1]) -> (N_dst, H, F).  Check gat_fused_supported() first."""
+    el (N_src, H[, 1]), er (N_dst, H[, 1]) -> (N_dst, H, F).  Check gat_fused_supported() first.
+    `attn_l` (1 | -, H, F): pass it when el is exactly (feat * attn_l).sum(-1) -- multi-head layers then form el from the gathered
+    feature row inside the kernels instead of gathering it (one L2 request per edge less)."""
     if feat.dtype != torch.float32 or el.dtype != torch.float32 or er.dtype != torch.float32:
         raise DGLError("gat_fused expects float32 inputs")
     p = float(attn_drop) if training else 0.0
@@ -329,7 +333,7 @@ def gat_fused(graph, feat, el, er, negative_slope=0.2, attn_drop=0.0, training=T
     if p > 0.0 and feat.is_cuda and capture_path():
         raise DGLError("gat_fused: attn_drop > 0 under HIP-graph capture would replay ONE dropout mask (the seed is a launch "
                        "argument); use the unfused operators there, as GATConv does")
-    return GATFused.apply(_gidx(graph), feat, el, er, negative_slope, p)
+    return GATFused.apply(_gidx(graph), feat, el, er, negative_slope, p, attn_l)
 
 
 class HeadDot(torch.autograd.Function):
@@ -695,6 +699,9 @@ class CatBuffer(object):
                 and h.stride(0) == self.buf.stride(0) and h.stride(1) == 1)
 
 
+_BWD_OWN_MATRIX = os.environ.get("MGX_SAGE_BWD_OWN_MATRIX", "0") == "1"
+
+
 class SageMeanCatFn(torch.autograd.Function):
     """SageMeanLayerFn over a CatBuffer: the aggregation reads the left half and writes the right half in place
     (mgx_spmm_copy_u_strided), forward and weight gradients are ONE GEMM / ONE mgx_xty against the stacked weights, and the
@@ -731,7 +738,15 @@ class SageMeanCatFn(torch.autograd.Function):
         be = sparse.backend_for(dy)
         K = cat.K
         dh = None
-        if need[2]:
+        if need[2] and _BWD_OWN_MATRIX:
+            # the reversed aggregation gathers from a matrix of its OWN and accumulates into another: gathering the right half of
+            # the matrix whose left half it read-modify-writes costs 2.60 against 2.38 ms per launch on the products shape (the
+            # output rows share 512-byte blocks with the rows being gathered), for a second pass of the dgrad GEMM over dy
+            dh = dy @ w_self
+            dn = dy @ w_neigh
+            dn.mul_(ctx.gidx.csc().inv_degrees().view(-1, 1))
+            be.spmm_copy_u_strided(ctx.gidx.csr(), "sum", dn, dh, accumulate=True)
+        elif need[2]:
             dcat = dy @ torch.cat([w_self, w_neigh], dim=1)       # [N, 2K] = d[h | neigh]
             dcat[:, K:].mul_(ctx.gidx.csc().inv_degrees().view(-1, 1))  # d(sum / deg): one streaming pass, not a per-edge factor
             be.spmm_copy_u_strided(ctx.gidx.csr(), "sum", dcat[:, K:], dcat[:, :K], accumulate=True)

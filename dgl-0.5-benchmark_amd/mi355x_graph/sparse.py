@@ -463,7 +463,7 @@ class HipBackend(object):
         need = max([L.mgx_gat_fused_workspace(self._plan_ptr(p), H, F) for p in plans] + [0])
         return torch.empty(need // 4, dtype=torch.float32, device=dev) if need else None
 
-    def gat_fused_fwd(self, csc, feat3d, el2d, er2d, slope, p, seed):
+    def gat_fused_fwd(self, csc, feat3d, el2d, er2d, slope, p, seed, attn_l=None):
         """feat3d [n_src, H, F], el2d [n_src, H], er2d [n_dst, H] -> (out [n_dst, H, F], nstat [n_dst, H, 4])."""
         dev = self._check_dev(csc.indptr, feat3d, el2d, er2d)
         H, F = int(feat3d.shape[1]), int(feat3d.shape[2])
@@ -474,7 +474,7 @@ class HipBackend(object):
         pack = self._gat_pack_ws(csc, H, F, dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mgx_gat_fused_fwd(ctypes.byref(csc.c_struct()), self._plan_ptr(plan), H, F, _ptr(feat3d), _ptr(el2d),
-                                                    _ptr(er2d), ctypes.c_float(slope), ctypes.c_float(p), ctypes.c_uint64(seed),
+                                                    _ptr(attn_l), _ptr(er2d), ctypes.c_float(slope), ctypes.c_float(p), ctypes.c_uint64(seed),
                                                     _ptr(out), _ptr(nstat), _ptr(ws), _ptr(pack), _stream(dev)))
         return out, nstat
 
@@ -483,7 +483,7 @@ class HipBackend(object):
         need = _lib.lib().mgx_gat_fused_pack_workspace(csc.num_cols, csc.num_rows, H, F)
         return torch.empty(need // 4, dtype=torch.float32, device=dev) if need else None
 
-    def gat_fused_bwd(self, csc, csr, feat3d, el2d, slope, p, seed, out3d, d_out3d, nstat, need_src):
+    def gat_fused_bwd(self, csc, csr, feat3d, el2d, slope, p, seed, out3d, d_out3d, nstat, need_src, attn_l=None):
         """-> (d_feat | None, d_el | None, d_er); nstat[..., 3] is overwritten with <out, d_out> per head."""
         dev = self._check_dev(csc.indptr, csr.indptr, feat3d, el2d, out3d, d_out3d, nstat)
         H, F = int(feat3d.shape[1]), int(feat3d.shape[2])
@@ -495,7 +495,7 @@ class HipBackend(object):
         pack = self._gat_pack_ws(csc, H, F, dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mgx_gat_fused_bwd(ctypes.byref(csc.c_struct()), self._plan_ptr(p_dst), ctypes.byref(csr.c_struct()),
-                                                    self._plan_ptr(p_src), H, F, _ptr(feat3d), _ptr(el2d), ctypes.c_float(slope),
+                                                    self._plan_ptr(p_src), H, F, _ptr(feat3d), _ptr(el2d), _ptr(attn_l), ctypes.c_float(slope),
                                                     ctypes.c_float(p), ctypes.c_uint64(seed), _ptr(out3d), _ptr(d_out3d), _ptr(nstat),
                                                     _ptr(d_feat), _ptr(d_el), _ptr(d_er), _ptr(ws), _ptr(pack), _stream(dev)))
         return d_feat, d_el, d_er

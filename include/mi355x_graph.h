@@ -284,17 +284,23 @@ int32_t mgx_gat_attention_bwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* m
  *   16 or 41 features: yes; 8 x 16: no, the function returns 0), the gathered operands are first packed into rows
  *   [feat | el] (forward, backward destination walk) and [d_out | er, m, 1/s, t] (backward source walk), so that an edge
  *   costs one L2 request instead of two -- these walks are bound by requests, not bytes.  Same results bit for bit.
+ * attn_l (may be NULL; round 3): when el IS (feat * attn_l).sum(-1) -- GATConv's own definition -- pass attn_l [H, F] as well:
+ *   layers whose rows are not packed (several heads, H*F >= 64: the 8 x 16 layers) then form el[u,h] from the gathered feature
+ *   row inside the kernels (4 multiply-adds and a lane swap or two per edge) instead of gathering it -- one L2 request per edge
+ *   less; the `el` array is then only differentiated (d_el), not read.  Pass the same attn_l to the backward.
  * Deterministic: no atomics, hub partial sums combined in slot order. */
 int64_t mgx_gat_fused_workspace(const mgx_spmm_plan* plan /* may be NULL */, int64_t H, int64_t F);
 int64_t mgx_gat_fused_pack_workspace(int64_t num_src, int64_t num_dst, int64_t H, int64_t F);
 int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int64_t H, int64_t F,
-                          const float* feat, const float* el, const float* er, float negative_slope, float drop_p,
-                          uint64_t seed, float* out, float* nstat, void* workspace, void* pack_ws, void* stream);
+                          const float* feat, const float* el, const float* attn_l /* [H, F] or NULL */, const float* er,
+                          float negative_slope, float drop_p, uint64_t seed, float* out, float* nstat, void* workspace,
+                          void* pack_ws, void* stream);
 int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan /* may be NULL */, const mgx_csr* csr,
                           const mgx_spmm_plan* csr_plan /* may be NULL */, int64_t H, int64_t F, const float* feat,
-                          const float* el, float negative_slope, float drop_p, uint64_t seed, const float* out,
-                          const float* d_out, float* nstat, float* d_feat /* may be NULL with d_el */, float* d_el,
-                          float* d_er, void* workspace, void* pack_ws, void* stream);
+                          const float* el, const float* attn_l /* [H, F] or NULL: as passed to the forward */, float negative_slope,
+                          float drop_p, uint64_t seed, const float* out, const float* d_out, float* nstat,
+                          float* d_feat /* may be NULL with d_el */, float* d_el, float* d_er, void* workspace, void* pack_ws,
+                          void* stream);
 
 /* ------------------------------------------------------------------ GAT attention terms
  * el[n,h] = sum_f feat[n,h,f] * attn[h,f] -- GATConv's `(feat * attn_l).sum(-1)` (main_dgl_reddit_gat.py:10, UPSTREAM

@@ -225,3 +225,61 @@ def test_packed_gather_operands_change_nothing(H, F, monkeypatch):
         res.append((out.detach(), feat.grad, el.grad, er.grad))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("n,H,Fd,p", [(900, 8, 16, 0.0), (700, 4, 32, 0.0), (600, 2, 64, 0.0), (500, 16, 8, 0.0), (900, 8, 16, 0.4)])
+def test_el_formed_in_the_kernel_matches_the_gathered_el(oracle, n, H, Fd, p):
+    """Round 3: with attn_l passed, multi-head layers whose rows are not packed (8 x 16, BASELINE config 3) form
+    el[u,h] = <feat[u,h,:], attn_l[h,:]> from the gathered row instead of gathering it.  Same layer: forward against the oracle's
+    composition on el = (feat * attn_l).sum(-1), gradients (through el's own producer) against the unfused operators, the three
+    walks agree with each other under dropout (adjointness), reruns bitwise."""
+    src, dst = hubby_graph(n, 40 * n, seed=H * 31 + Fd)
+    E = src.shape[0]
+    g = mk(n, n, src, dst)
+    torch.manual_seed(H * Fd)
+    feat0 = torch.randn(n, H, Fd, device=DEV)
+    attn0 = torch.randn(1, H, Fd, device=DEV)
+    er0 = torch.randn(n, H, 1, device=DEV) * 2
+    if p == 0.0:
+        with torch.no_grad():
+            el = (feat0 * attn0).sum(-1, keepdim=True)
+            out = ops.gat_fused(g, feat0, el, er0, 0.2, 0.0, True, attn_l=attn0)
+            gathered = ops.gat_fused(g, feat0, el, er0, 0.2, 0.0, True)
+        ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+        z = oracle.sddmm(src, dst, "add", el.cpu().numpy(), er0.cpu().numpy())
+        z = np.where(z > 0, z, 0.2 * z).astype(np.float32)
+        a = oracle.edge_softmax_fwd(ip, ei, z.reshape(E, H))
+        featn = feat0.cpu().numpy()
+        ref = oracle.spmm(ip, ix, ei, "mul", "sum", featn, a.reshape(E, H, 1))
+        row_scale = oracle.spmm(ip, ix, ei, "mul", "sum", np.abs(featn), a.reshape(E, H, 1)).astype(np.float64)
+        for got in (out, gathered):
+            err = np.abs(got.cpu().numpy().astype(np.float64) - ref.astype(np.float64))
+            assert not (err > RTOL * row_scale + 1e-30).any(), float((err / (row_scale + 1e-30)).max())
+        res = []
+        for in_kernel in (True, False):
+            f_, a_, r_ = (t.clone().requires_grad_(True) for t in (feat0, attn0, er0))
+            el_ = (f_ * a_).sum(-1, keepdim=True)
+            o = ops.gat_fused(g, f_, el_, r_, 0.2, 0.0, True, attn_l=a_) if in_kernel else unfused(g, f_, el_, r_, 0.2)
+            (o * torch.sin(torch.arange(o.numel(), device=DEV).view_as(o).float())).sum().backward()
+            res.append([f_.grad, a_.grad, r_.grad])
+        for name, x, y in zip(("d_feat", "d_attn_l", "d_er"), *res):
+            err, scale = float((x - y).abs().max()), float(y.abs().max())
+            assert err < RTOL * max(scale, 1e-6), (name, err, scale)
+        with torch.no_grad():
+            assert torch.equal(out, ops.gat_fused(g, feat0, el, er0, 0.2, 0.0, True, attn_l=attn0))
+    else:  # dropout: the map feat -> out is linear for fixed attention: <A x, y> = <x, A^T y> with the SAME mask in all walks
+        from mi355x_graph.ops import GATFused
+        torch.manual_seed(5)
+        calls = GATFused._calls
+        with torch.no_grad():
+            el = (feat0 * attn0).sum(-1, keepdim=True)
+        f_ = feat0.clone().requires_grad_(True)
+        o = ops.gat_fused(g, f_, el, er0, 0.2, p, True, attn_l=attn0)
+        y = torch.randn_like(o)
+        (o * y).sum().backward()
+        lhs = float((o.detach().double() * y.double()).sum())
+        rhs = float((f_.grad.double() * feat0.double()).sum())  # <x, A^T y> with x = feat (el held fixed: it is its own input)
+        assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
+        GATFused._calls = calls  # same seed -> same mask: bitwise the same output
+        with torch.no_grad():
+            assert torch.equal(o.detach(), ops.gat_fused(g, feat0, el, er0, 0.2, p, True, attn_l=attn0))
