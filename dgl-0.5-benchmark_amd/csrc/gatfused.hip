@@ -513,7 +513,9 @@ extern "C" int64_t mgx_gat_fused_pack_workspace(int64_t num_src, int64_t num_dst
 
 static bool gat_el_in_kernel(int64_t H, int64_t F, const float* attn_l) {
   static const bool off = getenv("MGX_GAT_EL_GATHER") != nullptr;  // A/B switch: always gather el
-  return attn_l != nullptr && !off && H > 1 && F % 4 == 0 && F >= 8 && H * F >= 64 && (uintptr_t)attn_l % 16 == 0;
+  // heads of up to 16 columns only: the reduction over a head's lanes costs log2(F / 4) lane swaps per edge -- measured: 8 x 16
+  // (reddit-small, BASELINE config 3) epoch 5.61 -> 5.51 ms, but 4 x 64 (arxiv) 2.79 -> 2.89 ms with the swaps of 16-lane heads
+  return attn_l != nullptr && !off && H > 1 && F % 4 == 0 && F >= 8 && F <= 16 && H * F >= 64 && (uintptr_t)attn_l % 16 == 0;
 }
 
 extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, int64_t F, const float* feat,

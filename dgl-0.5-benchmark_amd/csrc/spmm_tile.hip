@@ -397,6 +397,255 @@ __global__ __launch_bounds__(W * kWave, 4) void spmm_tile_kernel(const TileArgs 
   else tile_consumer<W, NL, NACC, RING>(a, ring, wave - NL, lane, tile, cbeg, n, col0);
 }
 
+// ---- narrow rows ------------------------------------------------------------------------------------------------------------
+// spmm_tile_narrow_kernel<LG, NACC>: the same tile walk for rows of 32 (LG = 3: 8 lanes per row) or 16 columns (LG = 2: 4 lanes) per
+// pass -- on dense graphs the row kernel is REQUEST bound at these widths (one L2 request per edge whatever the row's bytes,
+// profiles/r02_reddit_l2_requests.txt), and the tile turns re-used sources into LDS reads: a wave-instruction covers 8 / 16 rows,
+// a chunk holds 255 sources (32 / 16 KiB).  8-wave workgroups, two per CU: wave 0 loads (2-chunk ring; the chunk's 256 source ids
+// arrive by ONE DMA into LDS a chunk ahead, so the row gathers need no scalar-load chain), waves 1-7 consume.  Streams as above
+// ([superstep][lane group][4 steps]), through 1-KiB windows (32 / 16 supersteps) in a private 2-window ring per wave.
+template <int LG>
+struct NarrowGeo {
+  static constexpr int G = 1 << LG;                 // lanes per row
+  static constexpr int NBG = kWave / G;             // rows per wave-instruction
+  static constexpr int SLOT = 16 * G;               // bytes per LDS row
+  static constexpr int CS = 256;                    // slots per chunk (255 + the zero row): one-byte stream entries
+  static constexpr int CHB = CS * SLOT;             // chunk bytes
+  static constexpr int PER = CHB / 1024;            // row DMAs per chunk
+  static constexpr int WS = 256 / NBG;              // supersteps per 1-KiB stream window
+  static constexpr int WSD = 64 / NBG;              // supersteps per 1-KiB window of the direct stream
+  static constexpr int kWaves = 8, kConsumers = 7;
+  static constexpr int kIdsOff = 2 * CHB;           // LDS layout: [2 chunks][2 x 1 KiB ids][7 x 2 KiB stream windows]
+  static constexpr int kStreamOff = kIdsOff + 2048;
+  static constexpr int kLdsBytes = kStreamOff + kConsumers * 2048;
+};
+
+template <int LG, int NACC>
+__global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs a) {
+  typedef NarrowGeo<LG> Geo;
+  constexpr int G = Geo::G, NBG = Geo::NBG, NC = Geo::kConsumers;
+  __shared__ __attribute__((aligned(1024))) char ring[Geo::kLdsBytes];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int slotid = (int)(blockIdx.x % kXcds) * a.tiles_per_xcd + (int)(blockIdx.x / kXcds);
+  if (slotid >= a.num_tiles) return;
+  const int tile = a.tile_order ? a.tile_order[slotid] : slotid;
+  const int cbeg = a.tile_chunk_ptr[tile];
+  const int n = a.tile_chunk_ptr[tile + 1] - cbeg;
+  const int col0 = blockIdx.y * (G * 4);
+  const int g = lane >> LG, l = lane & (G - 1);
+  const int col = col0 + l * 4;
+  const bool cvalid = col < a.D;
+  const uint32_t rowbytes = (uint32_t)a.lds * 4u;
+
+  if (wave == 0) {  // ---- the loader wave
+    const char* zrow = reinterpret_cast<const char*>(a.zero_row + l * 4);
+    const char* xcol = reinterpret_cast<const char*>(a.x + col);
+    auto issue_ids = [&](int k) {  // the 256 source ids of chunk k: one 1-KiB DMA
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a.chunk_ids + (int64_t)(cbeg + k) * Geo::CS + lane * 4),
+                                       (lds_ptr_t)(ring + Geo::kIdsOff + (k & 1) * 1024), 16, 0, 0);
+    };
+    auto issue_rows = [&](int k) {  // chunk k -> ring slot k & 1; its ids are in LDS (landed: vmcnt(0) before the barrier)
+      const int* ids = reinterpret_cast<const int*>(ring + Geo::kIdsOff + (k & 1) * 1024) + g;
+      char* dst = ring + (k & 1) * Geo::CHB;
+      int idv[Geo::PER];
+#pragma unroll
+      for (int i = 0; i < Geo::PER; ++i) idv[i] = ids[i * NBG];
+#pragma unroll
+      for (int i = 0; i < Geo::PER; ++i) {
+        const bool live = idv[i] >= 0 && cvalid;
+        const char* src = live ? xcol + (uint32_t)idv[i] * rowbytes : zrow;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
+      }
+    };
+    if (n > 0) {
+      issue_ids(0);
+      wait_vmcnt<0>();
+      issue_rows(0);
+      if (n > 1) issue_ids(1);
+    }
+    for (int c = 0; c < n; ++c) {
+      wait_vmcnt<0>();               // chunk c and the ids of chunk c + 1 have landed
+      __builtin_amdgcn_s_barrier();  // ... and every consumer has finished chunk c - 1
+      asm volatile("" ::: "memory");
+      if (c + 1 < n) issue_rows(c + 1);
+      if (c + 2 < n) issue_ids(c + 2);
+    }
+    return;
+  }
+
+  // ---- consumer waves
+  const int cw = wave - 1;
+  v4f acc[NACC];
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) acc[j] = (v4f)(0.f);
+
+  if (n > 0) {
+    const auto* cnt = as_const(reinterpret_cast<const v4u*>(a.lds_cnt));
+    int64_t k = (int64_t)cbeg * NC + cw;
+    const uint32_t* gs = a.lds_stream + (int64_t)as_const(a.lds_off)[(int64_t)tile * NC + cw] * NBG + lane * 4;
+    char* swin = ring + Geo::kStreamOff + cw * 2048;  // 2 windows x 1 KiB
+    auto dma = [&](int wi) {
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gs + (int64_t)wi * 256), (lds_ptr_t)(swin + (wi & 1) * 1024), 16, 0, 0);
+    };
+    dma(0);
+    dma(1);
+    wait_vmcnt<0>();
+    int ss = 0;                       // supersteps consumed
+    int landed = 2 * Geo::WS;         // supersteps [0, landed) are readable
+    int issue_at = Geo::WS, nextw = 2;  // window nextw may overwrite its ring slot once superstep issue_at is the oldest still to be read
+    auto word = [&](int i) -> uint32_t {
+      return *reinterpret_cast<const uint32_t*>(swin + ((i / Geo::WS) & 1) * 1024 + (i % Geo::WS) * (NBG * 4) + g * 4);
+    };
+    auto prepare = [&](int lo, int hi) {  // the words of supersteps lo .. hi are about to be read
+      if (hi >= landed) {
+        wait_vmcnt<0>();
+        landed = nextw * Geo::WS;
+      }
+      if (lo >= issue_at) {
+        dma(nextw);
+        ++nextw;
+        issue_at += Geo::WS;
+      }
+    };
+    uint32_t w0 = word(0), w1 = word(1);
+    for (int c = 0; c < n; ++c) {
+      const v4u cq = cnt[2 * k];
+      const v4u cr = NACC > 8 ? cnt[2 * k + 1] : (v4u)(0u);
+      const uint32_t cnts[8] = {cq.x, cq.y, cq.z, cq.w, cr.x, cr.y, cr.z, cr.w};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const uint32_t lrow = (uint32_t)(c & 1) * Geo::CHB + (uint32_t)l * 16u;
+      auto gather4 = [&](uint32_t w, v4f (&v)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4f*>(ring + ((((w >> (8 * u)) & 0xffu) << (LG + 4)) + lrow));
+      };
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) {
+        const int nss = (int)((cnts[j >> 1] >> ((j & 1) * 16)) & 0xffffu);
+        int s = 0;
+        for (; s + 2 <= nss; s += 2) {
+          prepare(ss + 2, ss + 3);
+          const uint32_t n0 = word(ss + 2), n1 = word(ss + 3);
+          v4f va[4], vb[4];
+          gather4(w0, va);
+          gather4(w1, vb);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += va[u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += vb[u];
+          w0 = n0;
+          w1 = n1;
+          ss += 2;
+        }
+        if (s < nss) {
+          prepare(ss + 2, ss + 2);
+          const uint32_t n1 = word(ss + 2);
+          v4f va[4];
+          gather4(w0, va);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += va[u];
+          w0 = w1;
+          w1 = n1;
+          ss += 1;
+        }
+      }
+      k += NC;
+    }
+  }
+
+  // ---- direct part: its stream windows (1 KiB = WSD supersteps, ring of 4) live where the chunks were
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  {
+    const int64_t k = (int64_t)tile * NC + cw;
+    const int so = as_const(a.dir_off)[k], se = as_const(a.dir_off)[k + 1];
+    if (se > so) {
+      const auto* dcnt = as_const(reinterpret_cast<const v4u*>(a.dir_cnt)) + k * 4;
+      const v4u c0 = dcnt[0];
+      const v4u c1 = NACC > 4 ? dcnt[1] : (v4u)(0u);
+      const v4u c2 = NACC > 8 ? dcnt[2] : (v4u)(0u);
+      const uint32_t cnts[12] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w};
+      const v4i* gd = reinterpret_cast<const v4i*>(a.dir_stream) + (int64_t)so * NBG + lane;
+      char* dwin = ring + cw * 4096;
+      auto dma = [&](int wi) {
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(gd + (int64_t)wi * 64), (lds_ptr_t)(dwin + (wi & 3) * 1024), 16, 0, 0);
+      };
+      dma(0);
+      dma(1);
+      wait_vmcnt<1>();
+      dma(2);
+      int ss = 0, ready = Geo::WSD;
+      auto ids = [&](int i) -> v4i { return *reinterpret_cast<const v4i*>(dwin + (i % (4 * Geo::WSD)) * (NBG * 16) + g * 16); };
+      auto open_window = [&](int upto) {
+        if (upto >= ready) {
+          wait_vmcnt<1>();
+          dma(ready / Geo::WSD + 2);
+          ready += Geo::WSD;
+        }
+      };
+      v4i i0 = ids(0), i1 = ids(1);
+      const char* xb = reinterpret_cast<const char*>(a.x) + (size_t)(cvalid ? col : 0) * 4u;
+      auto gather4 = [&](const v4i& id, v4f (&v)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4f*>(xb + (id[u] >= 0 ? (uint32_t)id[u] * rowbytes : 0u));
+      };
+#pragma unroll
+      for (int j = 0; j < NACC; ++j) {
+        const int nss = (int)cnts[j];
+        int s = 0;
+        for (; s + 2 <= nss; s += 2) {
+          open_window(ss + 3);
+          const v4i n0 = ids(ss + 2), n1 = ids(ss + 3);
+          v4f va[4], vb[4];
+          gather4(i0, va);
+          gather4(i1, vb);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += i0[u] >= 0 ? va[u] : (v4f)(0.f);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += i1[u] >= 0 ? vb[u] : (v4f)(0.f);
+          i0 = n0;
+          i1 = n1;
+          ss += 2;
+        }
+        if (s < nss) {
+          open_window(ss + 2);
+          const v4i n1 = ids(ss + 2);
+          v4f va[4];
+          gather4(i0, va);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[j] += i0[u] >= 0 ? va[u] : (v4f)(0.f);
+          i0 = i1;
+          i1 = n1;
+          ss += 1;
+        }
+      }
+    }
+  }
+
+  if (!cvalid) return;
+#pragma unroll
+  for (int j = 0; j < NACC; ++j) {
+    const int item = a.tile_item[(int64_t)tile * (NC * NACC * NBG) + (cw * NACC + j) * NBG + g];
+    if (item == kNoItem) continue;
+    v4f r = acc[j];
+    if (item >= 0) {
+      if (a.mean) {
+        const int deg = a.indptr[item + 1] - a.indptr[item];
+        r = r / (float)(deg > 1 ? deg : 1);
+      }
+      if (a.dst_scale) r = r * a.dst_scale[item];
+      float* op = a.out + (int64_t)item * a.ldo + col;
+      if (a.accum) r += *reinterpret_cast<const v4f*>(op);
+      __builtin_nontemporal_store(r, reinterpret_cast<v4f*>(op));
+    } else {
+      *reinterpret_cast<v4f*>(a.partial + (int64_t)(-(item + 1)) * a.D + col) = r;
+    }
+  }
+}
+
 #define MGX_TILE_LAUNCH(W_, NL_, NACC_, RING_)                                                                      \
   do {                                                                                                             \
     hipLaunchKernelGGL((spmm_tile_kernel<W_, NL_, NACC_, RING_>), grid, dim3(W_ * kWave), 0, s, a);                \
@@ -415,6 +664,8 @@ static bool launch_tile(int waves, int loaders, int nacc, const TileArgs& a, dim
     if (nacc == 6) MGX_TILE_LAUNCH(16, 4, 6, 4);
     if (nacc == 8) MGX_TILE_LAUNCH(16, 4, 8, 4);
   } else if (waves == 8 && loaders == 1) {
+    if (nacc == 4) MGX_TILE_LAUNCH(8, 1, 4, 2);
+    if (nacc == 5) MGX_TILE_LAUNCH(8, 1, 5, 2);
     if (nacc == 6) MGX_TILE_LAUNCH(8, 1, 6, 2);
     if (nacc == 8) MGX_TILE_LAUNCH(8, 1, 8, 2);
     if (nacc == 10) MGX_TILE_LAUNCH(8, 1, 10, 2);
@@ -466,9 +717,23 @@ extern "C" int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan*
 #endif
   const dim3 grid((unsigned)(a.tiles_per_xcd * kXcds), (unsigned)((D + kPassCols - 1) / kPassCols));
   hipStream_t s = (hipStream_t)stream;
-  if (!launch_tile(tp->consumers + tp->loaders, tp->loaders, tp->nacc, a, grid, s))
+  const int lg = tp->lanes_log2 == 0 ? 4 : tp->lanes_log2;
+  if (lg != 4) {  // narrow rows: 8-wave workgroups (1 loader + 7 consumers), 32 / 16 columns per pass
+    MGX_CHECK_ARG((lg == 3 || lg == 2) && tp->consumers == 7 && tp->loaders == 1, "mgx_spmm_tile_copy_u: narrow tile plans are 7 + 1 waves");
+    const dim3 ngrid(grid.x, (unsigned)((D + (4 << lg) - 1) / (4 << lg)));
+    const dim3 nblock(512);
+    bool ok = true;
+#define MGX_NARROW(LG_, NACC_) \
+  if (lg == LG_ && tp->nacc == NACC_) hipLaunchKernelGGL((spmm_tile_narrow_kernel<LG_, NACC_>), ngrid, nblock, 0, s, a); else
+    MGX_NARROW(3, 3) MGX_NARROW(3, 4) MGX_NARROW(3, 5) MGX_NARROW(3, 6) MGX_NARROW(3, 8)
+    MGX_NARROW(2, 2) MGX_NARROW(2, 3) MGX_NARROW(2, 4) MGX_NARROW(2, 6) MGX_NARROW(2, 8)
+#undef MGX_NARROW
+      ok = false;
+    if (!ok) MGX_UNSUPPORTED("mgx_spmm_tile_copy_u: no narrow kernel for %d rows per lane group", tp->nacc);
+  } else if (!launch_tile(tp->consumers + tp->loaders, tp->loaders, tp->nacc, a, grid, s)) {
     MGX_UNSUPPORTED("mgx_spmm_tile_copy_u: no kernel for %d consumer + %d loader waves with %d rows per lane group", tp->consumers,
                     tp->loaders, tp->nacc);
+  }
   MGX_CHECK_LAUNCH();
   if (hubs) return spmm_hub_fixup_launch(csr, plan, partial_ws, dst_scale, out, a.D, a.mean, a.accum, a.ldo, s);
   return MGX_OK;

@@ -19,7 +19,7 @@ from ._lib import DGLError, MgxCsr, OP, REDUCE, TARGET
 
 
 PROFILE = None  # set to a list by bench.py to collect per-launch HIP-event timings of mgx_spmm_csr
-TILE_MIN_WIDTH = int(os.environ.get("MGX_TILE_MIN_WIDTH", 48))  # narrower rows stay on the row kernel (a tile pass is 64 columns wide)
+TILE_MIN_WIDTH = int(os.environ.get("MGX_TILE_MIN_WIDTH", 16))  # narrower rows stay on the row kernel (the narrowest tile pass is 16 columns)
 
 
 def _ptr(t):
@@ -95,19 +95,24 @@ class CsrView(object):
             self._plan = schedule.plan_for(self) if self.indptr.is_cuda else None
         return self._plan
 
-    def tile_plan(self):
-        """Tile plan of the LDS-staged g-SpMM (tileplan.py) on graphs with dense neighbourhoods, else None; built on first use."""
+    def tile_plan(self, width=64):
+        """Tile plan of the LDS-staged g-SpMM (tileplan.py) for rows of `width` columns on graphs with dense neighbourhoods, else
+        None; built on first use, one per kernel geometry (64- / 32- / 16-column passes)."""
+        from . import tileplan
+        lg = tileplan.lanes_log2_for(width)
         if self._tile_plan is False:
-            from . import schedule, tileplan
-            self._tile_plan = None
-            if tileplan.tile_plan_wanted(self):
-                self.plan()  # computes (and caches) the locality row order first
-                nc, nacc, nl, tau = tileplan.config()
-                base = schedule.plan_for(self, split=tileplan.TILE_SPLIT)
-                tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau)
-                tileplan.validate(tp, self)
-                self._tile_plan = tp
-        return self._tile_plan
+            self._tile_plan = {} if tileplan.tile_plan_wanted(self) else None
+        if self._tile_plan is None:
+            return None
+        if lg not in self._tile_plan:
+            from . import schedule
+            self.plan()  # computes (and caches) the locality row order first
+            nc, nacc, nl, tau = tileplan.config(lg)
+            base = schedule.plan_for(self, split=tileplan.TILE_SPLIT)
+            tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=lg)
+            tileplan.validate(tp, self)
+            self._tile_plan[lg] = tp
+        return self._tile_plan[lg]
 
     def softmax_plan(self):
         """Schedule of the edge-softmax / fused attention kernels: the g-SpMM plan unless MGX_SOFTMAX_SPLIT asks for a
@@ -273,7 +278,7 @@ class HipBackend(object):
         if (op == "copy_lhs" and reduce in ("sum", "mean") and src_scale is None and u_off is None and e_off is None
                 and u_len == out_len and out_len >= TILE_MIN_WIDTH and out_len % 4 == 0 and csr.idx_bits == 32
                 and csr.num_cols * out_len * 4 < 2 ** 32 and U.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and not want_arg):
-            tp = csr.tile_plan()
+            tp = csr.tile_plan(out_len)
             if tp is not None:  # dense neighbourhoods: the LDS-staged tile kernel
                 self.spmm_tile_copy_u(csr, tp, reduce, U.view(csr.num_cols, out_len), out, accumulate_into is not None, dst_scale)
                 return out, None, None
@@ -342,7 +347,7 @@ class HipBackend(object):
             raise DGLError("spmm_copy_u_strided: expected row-strided [num_cols, D] -> [num_rows, D] views")
         if (D >= TILE_MIN_WIDTH and D % 4 == 0 and csr.idx_bits == 32 and csr.num_cols * int(U2d.stride(0)) * 4 < 2 ** 32
                 and U2d.stride(0) % 4 == 0 and out2d.stride(0) % 4 == 0 and U2d.data_ptr() % 16 == 0 and out2d.data_ptr() % 16 == 0):
-            tp = csr.tile_plan()
+            tp = csr.tile_plan(D)
             if tp is not None:
                 return self.spmm_tile_copy_u(csr, tp, reduce, U2d, out2d, accumulate, dst_scale)
         plan = csr.plan()

@@ -28,10 +28,12 @@ import torch
 GROUPS = 4          # 16-lane groups of a wave (one 64-column pass: 16 lanes x float4)
 CHUNK_SLOTS = 128   # LDS rows per chunk: 127 staged sources + the all-zero slot
 ZERO_SLOT = CHUNK_SLOTS - 1
+# Narrow rows (round 3, later): 8 or 4 lanes per row -> 8 / 16 rows per wave-instruction, 32 / 16 columns per pass, 256 slots per chunk
+GEOMETRY = {4: (4, 128), 3: (8, 256), 2: (16, 256)}  # log2(lanes per row) -> (lane groups per wave, LDS slots per chunk)
 TILE_WAVES = (8, 16)  # workgroups of 8 waves (two per CU, 2-chunk ring) or 16 waves (one per CU, 4-chunk ring)
 CNT_STRIDE = 16     # superstep counts per (chunk | tile, wave) in lds_cnt / dir_cnt
 NO_ITEM = -(2 ** 31)
-STREAM_TAIL = 64    # padding SUPERSTEPS behind every stream (the kernel prefetches two supersteps ahead, unconditionally)
+STREAM_TAIL = 128   # padding SUPERSTEPS behind every stream (the kernels prefetch whole windows of 16-32 supersteps, two ahead)
 
 
 class MgxTilePlan(ctypes.Structure):
@@ -43,7 +45,7 @@ class MgxTilePlan(ctypes.Structure):
         ("consumers", ctypes.c_int32),
         ("nacc", ctypes.c_int32),
         ("loaders", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("lanes_log2", ctypes.c_int32),
         ("tile_chunk_ptr", ctypes.c_void_p),
         ("chunk_ids", ctypes.c_void_p),
         ("lds_off", ctypes.c_void_p),
@@ -61,15 +63,17 @@ class MgxTilePlan(ctypes.Structure):
 class TilePlan(object):
     """Device tables of one tile plan (see build_tile_plan); `base` is the SpmmPlan whose items it tiles."""
 
-    def __init__(self, base, consumers, nacc, loaders, tables, stats):
+    def __init__(self, base, consumers, nacc, loaders, tables, stats, lanes_log2=4):
         self.base, self.consumers, self.nacc, self.loaders = base, int(consumers), int(nacc), int(loaders)
+        self.lanes_log2 = int(lanes_log2)
+        self.groups, self.chunk_slots = GEOMETRY[self.lanes_log2]
         self.__dict__.update(tables)
         self.stats = stats
         self._c = None
 
     @property
     def rows_per_tile(self):
-        return self.consumers * self.nacc * GROUPS
+        return self.consumers * self.nacc * self.groups
 
     @property
     def num_tiles(self):
@@ -77,14 +81,14 @@ class TilePlan(object):
 
     @property
     def num_chunks(self):
-        return int(self.chunk_ids.shape[0]) // CHUNK_SLOTS
+        return int(self.chunk_ids.shape[0]) // self.chunk_slots
 
     def c_struct(self):
         if self._c is None:
             p = lambda t: t.data_ptr() if t.numel() else None
-            self._c = MgxTilePlan(self.num_tiles, self.num_chunks, int(self.lds_stream.shape[0]) // GROUPS - STREAM_TAIL,
-                                  int(self.dir_stream.shape[0]) // (4 * GROUPS) - STREAM_TAIL,
-                                  self.consumers, self.nacc, self.loaders, 0, p(self.tile_chunk_ptr), p(self.chunk_ids), p(self.lds_off),
+            self._c = MgxTilePlan(self.num_tiles, self.num_chunks, int(self.lds_stream.shape[0]) // self.groups - STREAM_TAIL,
+                                  int(self.dir_stream.shape[0]) // (4 * self.groups) - STREAM_TAIL,
+                                  self.consumers, self.nacc, self.loaders, self.lanes_log2, p(self.tile_chunk_ptr), p(self.chunk_ids), p(self.lds_off),
                                   p(self.lds_cnt), p(self.lds_stream), p(self.dir_off), p(self.dir_cnt), p(self.dir_stream),
                                   p(self.tile_item), p(self.zero_row),
                                   p(self.tile_order) if getattr(self, "tile_order", None) is not None else None)
@@ -97,14 +101,14 @@ def _excl_cumsum(x):
     return out
 
 
-def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None):
+def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None, groups=GROUPS):
     """Edges with segment key (seg * 4 + g), seg = a (unit, cw, j) row of the stream -> (superstep counts per seg, first superstep
     of each seg, stream).  A row has max_g(count) steps rounded up to whole SUPERSTEPS (4 steps); layout
     [superstep][lane group g][step u]: one payload per entry, `pad` where a group has run out.  `seg_order`: the order in which
     the rows are laid out in the stream (default: seg order).  Edges keep their storage order inside a group (stable sort)."""
     dev = seg_key.device
-    cnt4 = torch.bincount(seg_key, minlength=nseg * GROUPS)
-    steps = cnt4.view(nseg, GROUPS).max(dim=1)[0]
+    cnt4 = torch.bincount(seg_key, minlength=nseg * groups)
+    steps = cnt4.view(nseg, groups).max(dim=1)[0]
     ssteps = (steps + 3) // 4
     if seg_order is None:
         base = _excl_cumsum(ssteps)  # first superstep of every row
@@ -115,18 +119,19 @@ def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None):
         total = int(laid[-1])
         base = torch.empty(nseg, dtype=torch.int64, device=dev)
         base[seg_order] = laid[:-1]
-    stream = torch.full(((total + STREAM_TAIL) * GROUPS * 4,), pad, dtype=dtype, device=dev)
+    stream = torch.full(((total + STREAM_TAIL) * groups * 4,), pad, dtype=dtype, device=dev)
     if seg_key.numel():
         order = torch.sort(seg_key, stable=True)[1]
         sk = seg_key[order]
         seg_start = _excl_cumsum(cnt4)
         rank = torch.arange(sk.shape[0], device=dev) - seg_start[sk]
-        idx = ((base[sk // GROUPS] + rank // 4) * GROUPS + (sk % GROUPS)) * 4 + rank % 4
+        idx = ((base[sk // groups] + rank // 4) * groups + (sk % groups)) * 4 + rank % 4
         stream[idx] = payload[order].to(dtype)
     return ssteps, base, total, stream
 
 
 NUM_CUS = 256
+WG_SLOTS = 2 * NUM_CUS  # 8-wave workgroups, two per CU
 
 
 def _longest_first(tile_edges, T, xcds=8):
@@ -140,12 +145,14 @@ def _longest_first(tile_edges, T, xcds=8):
     return torch.sort(key, stable=True)[1].to(torch.int32)
 
 
-def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False):
+def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4):
     """csr: CsrView (int32, device or host); base: SpmmPlan over it (items in schedule order; None = natural rows)."""
     dev = csr.indptr.device
     NC, NACC = int(consumers), int(nacc)
     if NC + int(loaders) not in TILE_WAVES or not 1 <= NACC <= CNT_STRIDE or int(loaders) not in (1, 2, 4):
         raise ValueError("tile plan: consumers + loaders must be 8 or 16, nacc in 1..16, loaders 1, 2 or 4")
+    GROUPS, CHUNK_SLOTS = GEOMETRY[int(lanes_log2)]  # shadow the module defaults: lane groups per wave, LDS slots per chunk
+    ZERO_SLOT = CHUNK_SLOTS - 1
     R = NC * NACC * GROUPS
     n_src = csr.num_cols
     if base is not None:
@@ -157,13 +164,15 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     I = int(item_row.shape[0])
     lens = end - beg
     E = int(lens.sum())
-    # ---- tiles: consecutive items of the schedule, at most R of them and about the same number of EDGES each.  A launch runs
-    # only a few tiles per CU (one 1024-thread workgroup fills a CU), so tiles of unequal length leave CUs idle at the end;
-    # the edge budget is chosen so that the tile count lands just under a whole number of rounds over the 256 CUs.
+    # ---- tiles: consecutive items of the schedule, at most R of them.  balance = S (workgroup slots of the chip: 2 per CU) cuts them
+    # to the same number of EDGES each, and so many that the launch is a whole number of rounds over the S slots: XCD x takes its
+    # stretch of tiles in order as slots free, so a launch of 1.1 rounds of equal tiles -- or of 2.9 rounds of unequal ones -- idles
+    # most of the chip for its last round (tile_costs / simulate_dispatch model this; profiles/r03_tile_dispatch.txt).
     T0 = max((I + R - 1) // R, 1)
-    if balance and T0 >= NUM_CUS + NUM_CUS // 2:
-        rounds = (T0 + NUM_CUS - 1) // NUM_CUS
-        budget = max(E // max(rounds * NUM_CUS - NUM_CUS // 32, 1), 1)
+    S = WG_SLOTS if balance is True else int(balance)
+    if S and T0 >= S // 2:
+        rounds = (T0 + S - 1) // S
+        budget = max(E // max(rounds * S - S // 32, 1), 1)
         te = (torch.cumsum(lens, 0) - lens) // budget              # tile by edge count ...
         first = torch.ones(I, dtype=torch.bool, device=dev)
         first[1:] = te[1:] != te[:-1]
@@ -235,13 +244,13 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     chunk_tile = torch.repeat_interleave(torch.arange(T, device=dev), tile_chunk_ptr[1:] - tile_chunk_ptr[:-1])
     seg_unit = (chunk_tile[seg_chunk] * NC + seg_cw) if NCH else seg
     seg_order = torch.sort(seg_unit, stable=True)[1]  # stable: (chunk, j) order kept inside a (tile, cw)
-    lds_cnt, lds_base, lds_total, lds_bytes = _streams(sk, nseg, e_slot[staged], ZERO_SLOT, torch.uint8, seg_order)
+    lds_cnt, lds_base, lds_total, lds_bytes = _streams(sk, nseg, e_slot[staged], ZERO_SLOT, torch.uint8, seg_order, GROUPS)
     lds_off = _excl_cumsum(torch.bincount(seg_unit, weights=lds_cnt.double(), minlength=T * NC).long()) if NCH else \
         torch.zeros(T * NC + 1, dtype=torch.int64, device=dev)
     # ---- direct streams: one per (tile, consumer wave)
     direct = ~staged
     dk = e_tile[direct] * per_unit + e_pos[direct]
-    dir_cnt, dir_base, dir_total, dir_stream = _streams(dk, T * NC * NACC, e_src[direct], -1, torch.int32)
+    dir_cnt, dir_base, dir_total, dir_stream = _streams(dk, T * NC * NACC, e_src[direct], -1, torch.int32, None, GROUPS)
     dir_off = torch.cat([dir_base.view(-1)[::NACC], torch.tensor([dir_total], device=dev)])
     if int(lds_cnt.max() if lds_cnt.numel() else 0) > 65535:
         raise ValueError("tile plan: more than 65535 supersteps in one (chunk, row)")
@@ -274,12 +283,42 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     }
     if lds_total * 4 >= 2 ** 31 or dir_total * 16 >= 2 ** 31:
         raise ValueError("tile plan: stream offsets exceed 31 bits")
-    return TilePlan(base, NC, NACC, loaders, tables, stats)
+    return TilePlan(base, NC, NACC, loaders, tables, stats, lanes_log2)
+
+
+def tile_costs(plan, dir_weight=1.6, chunk_cost=2.0):
+    """Estimated duration of every tile in superstep units: a workgroup lasts as long as its slowest consumer wave -- its LDS
+    supersteps, its direct supersteps (each worth `dir_weight`: rows from L2 / the fabric) -- plus a barrier per chunk."""
+    NC, T = plan.consumers, plan.num_tiles
+    lds = (plan.lds_off[1:] - plan.lds_off[:-1]).view(T, NC).double()
+    dr = (plan.dir_off[1:] - plan.dir_off[:-1]).view(T, NC).double()
+    chunks = (plan.tile_chunk_ptr[1:] - plan.tile_chunk_ptr[:-1]).double()
+    return (lds + dir_weight * dr).max(dim=1)[0] + chunk_cost * chunks
+
+
+def simulate_dispatch(cost, slots_per_xcd=64, xcds=8, order=None):
+    """The launch as the hardware runs it: workgroup b goes to XCD b % 8, which takes its workgroups in order whenever one of its
+    `slots_per_xcd` workgroup slots frees.  cost: per-tile durations in dispatch-slot order (slot = xcd * per + i, as the kernel maps
+    blockIdx).  Returns (makespan, sum(cost) / (xcds * slots_per_xcd)): what the launch takes against perfectly divisible work."""
+    import heapq
+    c = cost.cpu().tolist() if hasattr(cost, "cpu") else list(cost)
+    T = len(c)
+    per = (T + xcds - 1) // xcds
+    worst = 0.0
+    for x in range(xcds):
+        mine = c[x * per:min((x + 1) * per, T)] if order is None else [c[t] for t in order[x]]
+        heap = [0.0] * slots_per_xcd
+        for d in mine:
+            heapq.heappush(heap, heapq.heappop(heap) + d)
+        worst = max(worst, max(heap))
+    return worst, sum(c) / (xcds * slots_per_xcd)
 
 
 def validate(plan, csr):
     """Bounds of every index the kernel follows blindly (a wrong table would be an out-of-bounds access on the device)."""
     NC, NACC, R = plan.consumers, plan.nacc, plan.rows_per_tile
+    GROUPS, CHUNK_SLOTS = plan.groups, plan.chunk_slots
+    ZERO_SLOT = CHUNK_SLOTS - 1
     T, NCH = plan.num_tiles, plan.num_chunks
     num_slots = plan.base.num_slots if plan.base is not None else 0
 
@@ -327,6 +366,8 @@ def emulate(plan, x, out_rows, num_slots=0):
     x = x.detach().cpu().double().numpy()
     D = x.shape[1]
     NC, NACC, R = plan.consumers, plan.nacc, plan.rows_per_tile
+    GROUPS, CHUNK_SLOTS = plan.groups, plan.chunk_slots
+    ZERO_SLOT = CHUNK_SLOTS - 1
     tcp = plan.tile_chunk_ptr.cpu().numpy()
     ids = plan.chunk_ids.cpu().numpy()
     lds_off, lds_cnt = plan.lds_off.cpu().numpy(), plan.lds_cnt.cpu().numpy().astype(np.uint16).reshape(-1, CNT_STRIDE)
@@ -382,9 +423,18 @@ def emulate(plan, x, out_rows, num_slots=0):
 TILE_SPLIT = int(os.environ.get("MGX_TILE_SPLIT", 2048))  # hub threshold of the tile kernel's work items
 
 
-def config():
-    """(consumers, nacc, loaders, tau); MGX_TILE_CFG=14x6x2x3 overrides (default: 8-wave workgroups, two per CU)."""
-    return tuple(int(v) for v in os.environ.get("MGX_TILE_CFG", "7x8x1x3").split("x"))
+def config(lanes_log2=4):
+    """(consumers, nacc, loaders, tau); MGX_TILE_CFG=14x6x2x3 overrides (default: 8-wave workgroups, two per CU);
+    MGX_TILE_CFG_NARROW for the 32- / 16-column kernels (always 7 + 1 waves)."""
+    if lanes_log2 == 4:
+        return tuple(int(v) for v in os.environ.get("MGX_TILE_CFG", "7x8x1x3").split("x"))
+    return tuple(int(v) for v in os.environ.get("MGX_TILE_CFG_NARROW", "7x8x1x3").split("x"))
+
+
+def lanes_log2_for(width):
+    """Lanes per feature row (log2) of the tile kernel that takes rows of `width` columns: 16 lanes x float4 = 64-column passes from
+    48 columns up, 8 lanes (32-column passes) from 24, 4 lanes (16-column passes) below."""
+    return 4 if width >= 48 else (3 if width >= 24 else 2)
 
 
 def tile_plan_wanted(csr):

@@ -44,10 +44,14 @@ def check_small():
     csr = make_csr(n, src, dst)
     base = schedule.build_plan(csr, torch.randperm(n, device=dev), split=512, order_kind="cluster")
     ok = True
-    for (nc, nacc, nl, tau) in ((12, 6, 4, 2), (14, 5, 2, 2), (7, 12, 1, 3), (14, 8, 2, 2), (7, 8, 1, 2)):
-        tp = tileplan.build_tile_plan(csr, base, nc, nacc, nl, tau)
+    for (nc, nacc, nl, tau, lg) in ((12, 6, 4, 2, 4), (14, 5, 2, 2, 4), (7, 12, 1, 3, 4), (14, 8, 2, 2, 4), (7, 8, 1, 2, 4),
+                                    (7, 8, 1, 3, 3), (7, 6, 1, 2, 3), (7, 8, 1, 3, 2), (7, 4, 1, 2, 2), (7, 6, 1, 2, 2)):
+        tp = tileplan.build_tile_plan(csr, base, nc, nacc, nl, tau, lanes_log2=lg)
         tileplan.validate(tp, csr)
-        for D, stride in ((64, 64), (128, 128), (100, 100), (64, 160), (256, 256), (36, 36)):
+        shapes = {4: ((64, 64), (128, 128), (100, 100), (64, 160), (256, 256), (36, 36)),
+                  3: ((32, 32), (24, 24), (64, 64), (36, 36), (32, 96), (16, 16)),
+                  2: ((16, 16), (8, 8), (12, 12), (32, 32), (20, 20), (16, 48))}[lg]
+        for D, stride in shapes:
             xw = torch.rand(n, stride, device=dev)
             x = xw[:, :D]
             ref = torch.zeros(n, D, dtype=torch.float64, device=dev).index_add_(0, dst, x.double()[src])
@@ -60,11 +64,11 @@ def check_small():
                 err2 = float(((got2.double() - want - acc0.double()).abs() / (want.abs() + 1.0)).max())
                 bad = err > 1e-5 or err2 > 1e-5
                 ok = ok and not bad
-                if bad or D == 64:
-                    print("small %s D=%d stride=%d %s: rel err %.2e, accumulate %.2e %s" % ((nc, nacc, nl, tau), D, stride, reduce,
+                if bad or D == shapes[0][0]:
+                    print("small %s D=%d stride=%d %s: rel err %.2e, accumulate %.2e %s" % ((nc, nacc, nl, tau, lg), D, stride, reduce,
                                                                                         err, err2, "FAIL" if bad else "ok"), flush=True)
         # bitwise rerun
-        x = torch.rand(n, 64, device=dev)
+        x = torch.rand(n, shapes[0][0], device=dev)
         a, b = be.spmm_tile_copy_u(csr, tp, "sum", x), be.spmm_tile_copy_u(csr, tp, "sum", x)
         ok = ok and bool(torch.equal(a, b))
     print("small graph:", "PASS" if ok else "FAIL", flush=True)
@@ -77,7 +81,9 @@ def main():
     p.add_argument("--widths", default="64,128")
     p.add_argument("--configs", default="12x6x4x2,12x6x4x3,12x4x4x2,14x8x2x2")
     p.add_argument("--split", type=int, default=2048)
+    p.add_argument("--lg", type=int, default=4, help="log2 lanes per row: 4 = 64-column passes, 3 = 32, 2 = 16")
     p.add_argument("--scale", type=float, default=1.0)
+    p.add_argument("--balance", default="0", help="workgroup slots the tiles are balanced over (0 = tiles of equal item count), e.g. 0,512")
     p.add_argument("--skip-small", action="store_true")
     p.add_argument("--small-only", action="store_true")
     args = p.parse_args()
@@ -105,10 +111,11 @@ def main():
         med, best = timeit(lambda: sparse.gspmm_raw(csr, "copy_lhs", "sum", x, None))
         row_out[D] = sparse.gspmm_raw(csr, "copy_lhs", "sum", x, None)[0]
         print("row kernel  D=%-4d %.3f ms (best %.3f)  delivered %.1f TB/s" % (D, med, best, E * D * 4 / med / 1e9), flush=True)
-    for cfg in args.configs.split(","):
+    for cfg, bal in [(c, int(b)) for c in args.configs.split(",") for b in args.balance.split(",")]:
         nc, nacc, nl, tau = [int(v) for v in cfg.split("x")]
         t0 = time.time()
-        tp = tileplan.build_tile_plan(csr, base, nc, nacc, nl, tau)
+        tp = tileplan.build_tile_plan(csr, base, nc, nacc, nl, tau, balance=bal, lanes_log2=args.lg)
+        cfg = "%s balance %d" % (cfg, bal)
         torch.cuda.synchronize()
         tb = time.time() - t0
         tileplan.validate(tp, csr)
@@ -116,6 +123,12 @@ def main():
         print("config %s: build %.1fs tiles %d chunks %d staged %.1f%% gathered rows/edge %.3f lds fill %.2f dir fill %.2f" %
               (cfg, tb, st["tiles"], st["chunks"], 100.0 * st["staged_edges"] / st["edges"], st["gathered_rows_per_edge"],
                st["lds_slot_fill"], st["dir_slot_fill"]), flush=True)
+        cost = tileplan.tile_costs(tp)
+        span, ideal = tileplan.simulate_dispatch(cost)
+        per = (st["tiles"] + 7) // 8
+        xs_sum = [float(cost[i * per:(i + 1) * per].sum()) for i in range(8)]
+        print("  dispatch model: makespan %.0f against %.0f divisible (%.2f); per-XCD work max / mean %.3f; tile cost max / mean %.2f" %
+              (span, ideal, span / max(ideal, 1e-9), max(xs_sum) / (sum(xs_sum) / 8), float(cost.max() / cost.mean())), flush=True)
         for D in widths:
             x = xs[D]
             out = be.spmm_tile_copy_u(csr, tp, "sum", x)

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+O=gpurun_out
+timeout 900 python experiments/exp_tile_kernel.py reddit --skip-small --lg 4 --widths 64,128 --balance 0,512 --configs 7x6x1x3,7x8x1x3,7x6x1x2 2>&1 | grep -v amdgpu | tail -26
+timeout 900 python experiments/exp_tile_kernel.py reddit --skip-small --lg 3 --widths 32 --balance 0,512 --configs 7x3x1x3,7x5x1x3,7x6x1x2 2>&1 | grep -v amdgpu | tail -20
+timeout 900 python experiments/exp_tile_kernel.py reddit --skip-small --lg 2 --widths 16 --balance 0,512,768 --configs 7x3x1x2,7x4x1x3 2>&1 | grep -v amdgpu | tail -20
+timeout 900 python experiments/exp_tile_kernel.py proteins --skip-small --lg 4 --widths 64,128 --balance 0,512 --configs 7x8x1x3,7x6x1x3,7x5x1x3 2>&1 | grep -v amdgpu | tail -26
+timeout 900 python experiments/exp_tile_kernel.py proteins --skip-small --lg 3 --widths 32 --balance 0,512 --configs 7x6x1x3,7x5x1x3 2>&1 | grep -v amdgpu | tail -14
+timeout 900 python experiments/exp_tile_kernel.py proteins --skip-small --lg 2 --widths 16 --balance 0,512,768 --configs 7x3x1x2,7x4x1x3 2>&1 | grep -v amdgpu | tail -20

@@ -186,10 +186,10 @@ int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan /*
  *   chunk_ids      [num_chunks*128]         source row of every LDS slot, -1 = all-zero row (slot 127 always)
  *   lds_off        [num_tiles*consumers+1]  first superstep of the stream of (tile, consumer wave): its chunks, then rows j
  *   lds_cnt        [num_chunks*consumers*16] uint16 supersteps (4 steps each) of (chunk, wave, accumulator j < nacc)
- *   lds_stream     [(lds_steps+64)*4]       per superstep and lane group one dword = the LDS slots of its four steps
- *                                           (127 = zero row); 64 supersteps of padding behind the end (prefetch)
+ *   lds_stream     [(lds_steps+128)*4]       per superstep and lane group one dword = the LDS slots of its four steps
+ *                                           (127 = zero row); 128 supersteps of padding behind the end (prefetch)
  *   dir_off        [num_tiles*consumers+1]  the same for the direct part; dir_cnt int32 [num_tiles*consumers*16];
- *   dir_stream     [(dir_steps+64)*16]      per superstep and lane group four source ids, -1 = padding
+ *   dir_stream     [(dir_steps+128)*16]      per superstep and lane group four source ids, -1 = padding
  *   tile_item      [num_tiles*R]            item_row of the work item at every (wave, j, lane group), INT32_MIN = none
  *   zero_row       [64] floats of zeros
  *   tile_order     [num_tiles] or NULL: the tile each dispatch slot runs (the builder puts an XCD's longest tiles first)
@@ -198,7 +198,8 @@ int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan /*
  * matrix below 4 GiB; otherwise MGX_ERR_UNSUPPORTED (call mgx_spmm_csr).  Deterministic: no atomics. */
 typedef struct mgx_tile_plan {
   int64_t num_tiles, num_chunks, lds_steps, dir_steps; /* steps: supersteps without the padding */
-  int32_t consumers, nacc, loaders, reserved;
+  int32_t consumers, nacc, loaders, lanes_log2; /* lanes per row: 0 | 4 = 16 lanes (64-column passes), 3 = 8 (32), 2 = 4 (16): narrow rows,
+                                                    256 slots per chunk, consumers = 7, loaders = 1 */
   const int32_t* tile_chunk_ptr;
   const int32_t* chunk_ids;
   const int32_t* lds_off;

@@ -32,7 +32,8 @@ def host_csr(n, src, dst):
     return sparse.coo_to_csr_host(n, n, torch.from_numpy(dst).int(), torch.from_numpy(src).int())
 
 
-@pytest.mark.parametrize("cfg", [(12, 2, 4, 2), (14, 5, 2, 2), (12, 6, 4, 3), (14, 8, 2, 1), (7, 12, 1, 2)])
+@pytest.mark.parametrize("cfg", [(12, 2, 4, 2, 4), (14, 5, 2, 2, 4), (12, 6, 4, 3, 4), (14, 8, 2, 1, 4), (7, 12, 1, 2, 4),
+                                 (7, 8, 1, 3, 3), (7, 4, 1, 2, 2)])
 def test_tile_plan_walks_to_the_dense_product(cfg, monkeypatch):
     monkeypatch.setenv("MGX_PLAN_BUILDER", "host")
     n = 500
@@ -40,8 +41,8 @@ def test_tile_plan_walks_to_the_dense_product(cfg, monkeypatch):
     csr = host_csr(n, src, dst)
     base = schedule.build_plan(csr, torch.randperm(n, generator=torch.Generator().manual_seed(1)), split=256, order_kind="cluster")
     assert base.num_hubs >= 1
-    tp = tileplan.build_tile_plan(csr, base, *cfg)
-    assert tileplan.validate(tp, csr)
+    tp = tileplan.build_tile_plan(csr, base, *cfg[:4], lanes_log2=cfg[4])  # 16 / 8 / 4 lanes per row: 4 / 8 / 16 rows per step
+    assert tileplan.validate(tp, csr) and tp.rows_per_tile == cfg[0] * cfg[1] * (64 >> cfg[4])
     st = tp.stats
     assert st["staged_edges"] + st["direct_edges"] == csr.nnz and (cfg[3] > 1 or st["direct_edges"] == 0)
     x = torch.rand(n, 5, generator=torch.Generator().manual_seed(2))
@@ -79,7 +80,8 @@ def rel(a, b):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", [(12, 6, 4, 2), (14, 6, 2, 2), (14, 5, 2, 3), (12, 4, 4, 1), (14, 8, 2, 2), (7, 12, 1, 3), (7, 8, 1, 2)])
+@pytest.mark.parametrize("cfg", [(12, 6, 4, 2, 4), (14, 6, 2, 2, 4), (14, 5, 2, 3, 4), (12, 4, 4, 1, 4), (14, 8, 2, 2, 4), (7, 12, 1, 3, 4),
+                                 (7, 8, 1, 2, 4), (7, 8, 1, 3, 3), (7, 6, 1, 2, 3), (7, 8, 1, 3, 2), (7, 4, 1, 2, 2)])
 def test_tile_kernel_matches_the_oracle_with_a_21k_edge_hub(oracle, cfg):
     n = 3000
     src, dst, hub = hub_graph(n, 150000, 21000, seed=11)
@@ -87,12 +89,15 @@ def test_tile_kernel_matches_the_oracle_with_a_21k_edge_hub(oracle, cfg):
     order = torch.randperm(n, generator=torch.Generator().manual_seed(4)).to(DEV)
     base = schedule.build_plan(csr, order, split=2048, order_kind="cluster")
     assert base.num_hubs >= 1
-    tp = tileplan.build_tile_plan(csr, base, *cfg)
+    tp = tileplan.build_tile_plan(csr, base, *cfg[:4], lanes_log2=cfg[4])
     tileplan.validate(tp, csr)
     be = sparse.backend_for(csr.indptr)
     ip, ix = csr.indptr.cpu().numpy(), csr.indices.cpu().numpy()
     rng = np.random.default_rng(0)
-    for D, stride in ((64, 64), (128, 128), (100, 100), (36, 36), (64, 192), (320, 320)):
+    shapes = {4: ((64, 64), (128, 128), (100, 100), (36, 36), (64, 192), (320, 320)),     # 64-column passes
+              3: ((32, 32), (24, 24), (64, 64), (36, 36), (32, 96), (16, 16)),            # 32-column passes (8 lanes per row)
+              2: ((16, 16), (8, 8), (12, 12), (32, 32), (20, 20), (16, 48))}[cfg[4]]      # 16-column passes (4 lanes per row)
+    for D, stride in shapes:
         xw = rng.random((n, stride), dtype=np.float32)
         x = torch.from_numpy(xw).to(DEV)[:, :D]
         for reduce in ("sum", "mean"):
@@ -105,7 +110,7 @@ def test_tile_kernel_matches_the_oracle_with_a_21k_edge_hub(oracle, cfg):
             be.spmm_tile_copy_u(csr, tp, reduce, x, out2d=wide[:, D:], accumulate=True)
             assert torch.equal(wide[:, :D], before[:, :D])
             assert rel((wide[:, D:] - before[:, D:]).cpu().numpy(), want) < 2e-4  # one more rounding: (acc + old) - old
-    x = torch.rand(n, 64, device=DEV)
+    x = torch.rand(n, shapes[0][0], device=DEV)
     a, b = be.spmm_tile_copy_u(csr, tp, "sum", x), be.spmm_tile_copy_u(csr, tp, "sum", x)
     assert torch.equal(a, b)  # no atomics: reruns are bitwise identical
     hub_sum = x[torch.from_numpy(src[dst == hub]).to(DEV)].double().sum(0)
@@ -128,6 +133,10 @@ def test_gspmm_takes_the_tile_kernel_on_dense_neighbourhoods(oracle, monkeypatch
         assert (g._index.csc().tile_plan() is not None) == (mode == "1")
         x = torch.from_numpy(np.random.default_rng(1).random((n, 128), dtype=np.float32)).to(DEV)
         outs[mode] = {r: ops.gspmm(g, "copy_lhs", r, x, None) for r in ("sum", "mean")}
+        for width in (16, 32):  # narrow rows: the 16- / 32-column kernels
+            outs[mode][width] = ops.gspmm(g, "copy_lhs", "sum", x[:, :width].contiguous(), None)
+            if mode == "1":
+                assert g._index.csc().tile_plan(width).lanes_log2 == {16: 2, 32: 3}[width]
         xg = x.clone().requires_grad_(True)  # backward = the same kernel on the reversed graph
         ops.gspmm(g, "copy_lhs", "sum", xg, None).square().sum().backward()
         outs[mode]["grad"] = xg.grad
@@ -137,3 +146,6 @@ def test_gspmm_takes_the_tile_kernel_on_dense_neighbourhoods(oracle, monkeypatch
         assert rel(outs["1"][r].cpu().numpy(), want) < RTOL
         assert rel(outs["1"][r].cpu().numpy(), outs["0"][r].cpu().numpy()) < RTOL
     assert rel(outs["1"]["grad"].cpu().numpy(), outs["0"]["grad"].cpu().numpy()) < RTOL
+    for width in (16, 32):
+        want = oracle.spmm(ip, ix, None, "copy_lhs", "sum", np.ascontiguousarray(x_np[:, :width]), None)
+        assert rel(outs["1"][width].cpu().numpy(), want) < RTOL and rel(outs["0"][width].cpu().numpy(), want) < RTOL
