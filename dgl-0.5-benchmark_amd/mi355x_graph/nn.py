@@ -6,6 +6,8 @@
 Parameter names, shapes and initialisation follow DGL v0.6.x so state_dicts and the scripts'
 reset_parameters() calls (main_dgl_reddit_gat.py:57-59) line up.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -105,6 +107,19 @@ class GATConv(nn.Module):
     def set_allow_zero_in_degree(self, set_value):
         self._allow_zero_in_degree = set_value
 
+    def _aggregate_first(self, graph, feat, get_attention):
+        """One-head layers that WIDEN (in < out, e.g. 16 hidden -> 41 classes): aggregate the input rows, project afterwards.
+        Taken when the fused block exists for the input width and it saves a 16-column gather pass; MGX_GAT_AGG_FIRST=0 never."""
+        if (self._num_heads != 1 or isinstance(feat, tuple) or get_attention or not hasattr(self, "fc") or not torch.is_tensor(feat)
+                or feat.dim() != 2 or os.environ.get("MGX_GAT_AGG_FIRST", "1") == "0"):
+            return False
+        k, f = self._in_src_feats, self._out_feats
+        if k % 4 != 0 or (k + 15) // 16 >= (f + 15) // 16:
+            return False
+        if self.training and self.attn_drop.p > 0.0 and feat.is_cuda and ops.capture_path():
+            return False  # frozen mask under capture: see forward
+        return ops.gat_fused_supported(graph, feat.view(feat.shape[0], 1, k))
+
     def forward(self, graph, feat, get_attention=False):
         with graph.local_scope():
             if not self._allow_zero_in_degree:
@@ -115,6 +130,26 @@ class GATConv(nn.Module):
                         "Adding self-loop on the input graph by calling `g = dgl.add_self_loop(g)` will resolve "
                         "the issue. Setting ``allow_zero_in_degree`` to be `True` when constructing this module "
                         "will suppress the check and let the code run.")
+            if self._aggregate_first(graph, feat, get_attention):
+                # ONE head: a[e] is a scalar, so sum_e a[e] (h[u] W^T) = (sum_e a[e] h[u]) W^T and el = h (W^T attn_l): the
+                # fused block runs at the INPUT width and the projection follows it (reddit GAT's 16 -> 41 output layer:
+                # three gather walks at 64-byte rows instead of 164-byte ones).  Same function, other fp32 summation order.
+                h = self.feat_drop(feat)
+                w = self.fc.weight                                    # [F, in]
+                v = torch.cat([self.attn_l.view(1, -1), self.attn_r.view(1, -1)], 0) @ w  # [2, in]
+                lr = h @ v.t()                                        # [N, 2]: el, er
+                n_dst = graph.number_of_dst_nodes()
+                el, er = lr[:, 0:1].unsqueeze(-1), lr[:n_dst, 1:2].unsqueeze(-1)
+                agg = ops.gat_fused(graph, h.view(h.shape[0], 1, -1), el.contiguous(), er.contiguous(),
+                                    self.leaky_relu.negative_slope, self.attn_drop.p, self.training)
+                rst = (agg.view(n_dst, -1) @ w.t()).view(n_dst, 1, self._out_feats)
+                if self.res_fc is not None:
+                    rst = rst + self.res_fc(h[:n_dst]).view(n_dst, -1, self._out_feats)
+                if self.bias is not None:
+                    rst = ops.bias_add(rst, self.bias)
+                if self.activation:
+                    rst = self.activation(rst)
+                return rst
             if isinstance(feat, tuple):
                 h_src = self.feat_drop(feat[0])
                 h_dst = self.feat_drop(feat[1])

@@ -19,7 +19,7 @@ from ._lib import DGLError, MgxCsr, OP, REDUCE, TARGET
 
 
 PROFILE = None  # set to a list by bench.py to collect per-launch HIP-event timings of mgx_spmm_csr
-TILE_MIN_WIDTH = int(os.environ.get("MGX_TILE_MIN_WIDTH", 16))  # narrower rows stay on the row kernel (the narrowest tile pass is 16 columns)
+TILE_MIN_WIDTH = int(os.environ.get("MGX_TILE_MIN_WIDTH", 4))  # rows of 4 .. 20 columns take the 16-column tile pass, 24 .. 44 the 32-column one, wider the 64-column one
 
 
 def _ptr(t):
@@ -281,6 +281,20 @@ class HipBackend(object):
             tp = csr.tile_plan(out_len)
             if tp is not None:  # dense neighbourhoods: the LDS-staged tile kernel
                 self.spmm_tile_copy_u(csr, tp, reduce, U.view(csr.num_cols, out_len), out, accumulate_into is not None, dst_scale)
+                return out, None, None
+        if (op == "copy_lhs" and reduce in ("sum", "mean") and src_scale is None and u_off is None and e_off is None
+                and u_len == out_len and out_len % 4 != 0 and TILE_MIN_WIDTH <= 4 and csr.idx_bits == 32 and not want_arg
+                and csr.num_cols * (out_len + 3) * 4 < 2 ** 32):
+            padded = (out_len + 3) // 4 * 4
+            tp = csr.tile_plan(padded)
+            if tp is not None:  # odd widths (1, 2, 41 ...) on dense neighbourhoods: through zero-padded copies of both operands
+                up = torch.zeros((csr.num_cols, padded), dtype=torch.float32, device=dev)
+                up[:, :out_len] = U.view(csr.num_cols, out_len)
+                res = self.spmm_tile_copy_u(csr, tp, reduce, up, None, False, dst_scale)[:, :out_len]
+                if accumulate_into is not None:
+                    out += res
+                else:
+                    out.copy_(res)
                 return out, None, None
         plan = csr.plan() if reduce in ("sum", "mean") else None
         partial = None

@@ -423,18 +423,20 @@ def emulate(plan, x, out_rows, num_slots=0):
 TILE_SPLIT = int(os.environ.get("MGX_TILE_SPLIT", 2048))  # hub threshold of the tile kernel's work items
 
 
+_DEFAULT_CFG = {4: "7x6x1x3", 3: "7x3x1x3", 2: "7x3x1x2"}  # 168 / 168 / 336 items per tile (profiles/r03_tile_narrow.txt)
+
+
 def config(lanes_log2=4):
-    """(consumers, nacc, loaders, tau); MGX_TILE_CFG=14x6x2x3 overrides (default: 8-wave workgroups, two per CU);
-    MGX_TILE_CFG_NARROW for the 32- / 16-column kernels (always 7 + 1 waves)."""
-    if lanes_log2 == 4:
-        return tuple(int(v) for v in os.environ.get("MGX_TILE_CFG", "7x8x1x3").split("x"))
-    return tuple(int(v) for v in os.environ.get("MGX_TILE_CFG_NARROW", "7x8x1x3").split("x"))
+    """(consumers, nacc, loaders, tau) of the 64- / 32- / 16-column kernel: 8-wave workgroups (7 consumers + 1 loader), two or three
+    per CU.  MGX_TILE_CFG=14x6x2x3 overrides the 64-column kernel's, MGX_TILE_CFG_NARROW the other two."""
+    env = os.environ.get("MGX_TILE_CFG" if lanes_log2 == 4 else "MGX_TILE_CFG_NARROW", "") or _DEFAULT_CFG[int(lanes_log2)]
+    return tuple(int(v) for v in env.split("x"))
 
 
 def lanes_log2_for(width):
-    """Lanes per feature row (log2) of the tile kernel that takes rows of `width` columns: 16 lanes x float4 = 64-column passes from
-    48 columns up, 8 lanes (32-column passes) from 24, 4 lanes (16-column passes) below."""
-    return 4 if width >= 48 else (3 if width >= 24 else 2)
+    """Lanes per feature row (log2) of the tile kernel that takes rows of `width` columns in the fewest passes: 4 lanes x float4
+    (16-column passes) up to 16 columns, 8 lanes up to 32, 16 lanes (64-column passes) beyond."""
+    return 2 if width <= 16 else (3 if width <= 32 else 4)
 
 
 def tile_plan_wanted(csr):

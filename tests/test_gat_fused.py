@@ -188,6 +188,38 @@ def test_gatconv_uses_the_fused_block_and_matches_the_unfused_module(monkeypatch
     assert att.shape == (g.number_of_edges(), 8, 1) and float((y3 - y1).abs().max()) < RTOL * float(y1.abs().max())
 
 
+@pytest.mark.parametrize("k,f,residual", [(16, 41, False), (8, 47, True), (32, 64, False)])
+def test_one_head_widening_layer_aggregates_first(k, f, residual, monkeypatch):
+    """GATConv(k, f, 1 head) with k < f (main_dgl_reddit_gat.py:62-64: the 16 -> 41 output layer): the fused block runs on the
+    k-column input rows and the projection follows; outputs and every gradient equal the project-first order (1e-4 relative)."""
+    from mi355x_graph.nn import GATConv
+    n = 1200
+    src, dst = hubby_graph(n, 40 * n, seed=29)
+    loops = np.arange(n)
+    g = mk(n, n, np.concatenate([src, loops]), np.concatenate([dst, loops]))
+    torch.manual_seed(1)
+    conv = GATConv(k, f, 1, 0.0, 0.0, 0.2, residual=residual).to(DEV)
+    x0 = torch.randn(n, k, device=DEV)
+    w = torch.randn(n, 1, f, device=DEV)
+    widths, res = [], []
+    real = ops.gat_fused
+    monkeypatch.setattr(ops, "gat_fused", lambda g_, feat, *a, **kw: (widths.append(int(feat.shape[-1])), real(g_, feat, *a, **kw))[1])
+    for first in ("1", "0"):
+        monkeypatch.setenv("MGX_GAT_AGG_FIRST", first)
+        x = x0.clone().requires_grad_(True)
+        conv.zero_grad()
+        y = conv(g, x)
+        assert y.shape == (n, 1, f)
+        (y * w).sum().backward()
+        res.append([y.detach(), x.grad] + [p.grad.clone() for p in conv.parameters()])
+    assert widths == [k, f]
+    for a_, b_ in zip(*res):
+        assert float((a_ - b_).abs().max()) < RTOL * float(b_.abs().max()) + 1e-6, (a_.shape, float((a_ - b_).abs().max()), float(b_.abs().max()))
+    widths.clear()
+    GATConv(f, k, 1).to(DEV)(g, torch.randn(n, f, device=DEV))  # a narrowing layer keeps the usual order
+    assert widths == [k]
+
+
 def test_fused_rejects_mismatched_rows():
     n = 100
     src, dst = random_graph(n, n, 1000, seed=1)

@@ -133,10 +133,11 @@ def test_gspmm_takes_the_tile_kernel_on_dense_neighbourhoods(oracle, monkeypatch
         assert (g._index.csc().tile_plan() is not None) == (mode == "1")
         x = torch.from_numpy(np.random.default_rng(1).random((n, 128), dtype=np.float32)).to(DEV)
         outs[mode] = {r: ops.gspmm(g, "copy_lhs", r, x, None) for r in ("sum", "mean")}
-        for width in (16, 32):  # narrow rows: the 16- / 32-column kernels
+        for width in (16, 32, 1, 2, 41, 4, 20):  # narrow rows: the 16- / 32-column kernels; odd widths through padded operands
             outs[mode][width] = ops.gspmm(g, "copy_lhs", "sum", x[:, :width].contiguous(), None)
+            assert outs[mode][width].shape == (n, width) and outs[mode][width].is_contiguous()
             if mode == "1":
-                assert g._index.csc().tile_plan(width).lanes_log2 == {16: 2, 32: 3}[width]
+                assert g._index.csc().tile_plan(width).lanes_log2 == {16: 2, 32: 3, 1: 2, 2: 2, 41: 4, 4: 2, 20: 3}[width]
         xg = x.clone().requires_grad_(True)  # backward = the same kernel on the reversed graph
         ops.gspmm(g, "copy_lhs", "sum", xg, None).square().sum().backward()
         outs[mode]["grad"] = xg.grad
@@ -146,6 +147,6 @@ def test_gspmm_takes_the_tile_kernel_on_dense_neighbourhoods(oracle, monkeypatch
         assert rel(outs["1"][r].cpu().numpy(), want) < RTOL
         assert rel(outs["1"][r].cpu().numpy(), outs["0"][r].cpu().numpy()) < RTOL
     assert rel(outs["1"]["grad"].cpu().numpy(), outs["0"]["grad"].cpu().numpy()) < RTOL
-    for width in (16, 32):
+    for width in (16, 32, 1, 2, 41, 4, 20):
         want = oracle.spmm(ip, ix, None, "copy_lhs", "sum", np.ascontiguousarray(x_np[:, :width]), None)
         assert rel(outs["1"][width].cpu().numpy(), want) < RTOL and rel(outs["0"][width].cpu().numpy(), want) < RTOL
