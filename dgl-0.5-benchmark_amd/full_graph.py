@@ -223,7 +223,7 @@ def build_sage(name, device, scale=1.0):
         g.ndata["feat"] = feats_keep
     g = g.int().formats(["csr", "csc"]).to(device)
     model = GraphSAGE(data.features.shape[1], cfg["hidden"], data.num_classes, cfg["num_layers"], cfg["dropout"],
-                      cfg["batch_norm"], cfg["neigh_bias"]).to(device)
+                      cfg["batch_norm"], cfg["neigh_bias"], plain=os.environ.get("MGX_PLAIN_MODEL", "0") == "1").to(device)
     train_idx = torch.nonzero(data.train_mask).flatten()
     model.rows_are_distinct = True  # nonzero() of a mask
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
