@@ -404,7 +404,7 @@ __global__ __launch_bounds__(W * kWave, 4) void spmm_tile_kernel(const TileArgs 
 // a chunk holds 255 sources (32 / 16 KiB).  8-wave workgroups, two per CU: wave 0 loads (2-chunk ring; the chunk's 256 source ids
 // arrive by ONE DMA into LDS a chunk ahead, so the row gathers need no scalar-load chain), waves 1-7 consume.  Streams as above
 // ([superstep][lane group][4 steps]), through 1-KiB windows (32 / 16 supersteps) in a private 2-window ring per wave.
-template <int LG>
+template <int LG, int RING>
 struct NarrowGeo {
   static constexpr int G = 1 << LG;                 // lanes per row
   static constexpr int NBG = kWave / G;             // rows per wave-instruction
@@ -415,14 +415,18 @@ struct NarrowGeo {
   static constexpr int WS = 256 / NBG;              // supersteps per 1-KiB stream window
   static constexpr int WSD = 64 / NBG;              // supersteps per 1-KiB window of the direct stream
   static constexpr int kWaves = 8, kConsumers = 7;
-  static constexpr int kIdsOff = 2 * CHB;           // LDS layout: [2 chunks][2 x 1 KiB ids][7 x 2 KiB stream windows]
-  static constexpr int kStreamOff = kIdsOff + 2048;
+  static constexpr int kIdsOff = RING * CHB;        // LDS layout: [RING chunks][RING x 1 KiB ids][7 x 2 KiB stream windows]
+  static constexpr int kStreamOff = kIdsOff + RING * 1024;
   static constexpr int kLdsBytes = kStreamOff + kConsumers * 2048;
+  // the loader's queue in steady state: [rows(c) ids(c + RING - 1)] [rows(c + 1) ids(c + RING)] ...: rows(c) and the ids the next
+  // gather needs have landed once at most this many DMAs are outstanding
+  static constexpr int kAhead = (RING - 2) * (PER + 1);
+  static_assert(kAhead <= 63, "vmcnt is a 6-bit counter");
 };
 
-template <int LG, int NACC>
+template <int LG, int NACC, int RING>
 __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs a) {
-  typedef NarrowGeo<LG> Geo;
+  typedef NarrowGeo<LG, RING> Geo;
   constexpr int G = Geo::G, NBG = Geo::NBG, NC = Geo::kConsumers;
   __shared__ __attribute__((aligned(1024))) char ring[Geo::kLdsBytes];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -443,11 +447,11 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
     const char* xcol = reinterpret_cast<const char*>(a.x + col);
     auto issue_ids = [&](int k) {  // the 256 source ids of chunk k: one 1-KiB DMA
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a.chunk_ids + (int64_t)(cbeg + k) * Geo::CS + lane * 4),
-                                       (lds_ptr_t)(ring + Geo::kIdsOff + (k & 1) * 1024), 16, 0, 0);
+                                       (lds_ptr_t)(ring + Geo::kIdsOff + (k % RING) * 1024), 16, 0, 0);
     };
-    auto issue_rows = [&](int k) {  // chunk k -> ring slot k & 1; its ids are in LDS (landed: vmcnt(0) before the barrier)
-      const int* ids = reinterpret_cast<const int*>(ring + Geo::kIdsOff + (k & 1) * 1024) + g;
-      char* dst = ring + (k & 1) * Geo::CHB;
+    auto issue_rows = [&](int k) {  // chunk k -> ring slot k % RING; its ids are in LDS (landed: the wait before the barrier)
+      const int* ids = reinterpret_cast<const int*>(ring + Geo::kIdsOff + (k % RING) * 1024) + g;
+      char* dst = ring + (k % RING) * Geo::CHB;
       int idv[Geo::PER];
 #pragma unroll
       for (int i = 0; i < Geo::PER; ++i) idv[i] = ids[i * NBG];
@@ -458,18 +462,21 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)(dst + i * 1024), 16, 0, 0);
       }
     };
-    if (n > 0) {
-      issue_ids(0);
-      wait_vmcnt<0>();
-      issue_rows(0);
-      if (n > 1) issue_ids(1);
+    // ids run RING - 1 chunks ahead of the rows, the rows RING - 1 chunks ahead of the consumers
+    for (int k = 0; k < RING - 1 && k < n; ++k) issue_ids(k);
+    wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int k = 0; k < RING - 1; ++k) {
+      if (k < n) issue_rows(k);
+      if (k + RING - 1 < n) issue_ids(k + RING - 1);
     }
     for (int c = 0; c < n; ++c) {
-      wait_vmcnt<0>();               // chunk c and the ids of chunk c + 1 have landed
-      __builtin_amdgcn_s_barrier();  // ... and every consumer has finished chunk c - 1
+      if (c + 2 * RING - 2 <= n) wait_vmcnt<Geo::kAhead>();  // chunk c and the ids of chunk c + RING - 1 have landed
+      else wait_vmcnt<0>();                                   // (the queue is shorter at the end of the tile)
+      __builtin_amdgcn_s_barrier();                           // ... and every consumer has finished chunk c - 1
       asm volatile("" ::: "memory");
-      if (c + 1 < n) issue_rows(c + 1);
-      if (c + 2 < n) issue_ids(c + 2);
+      if (c + RING - 1 < n) issue_rows(c + RING - 1);
+      if (c + 2 * RING - 2 < n) issue_ids(c + 2 * RING - 2);
     }
     return;
   }
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      const uint32_t lrow = (uint32_t)(c & 1) * Geo::CHB + (uint32_t)l * 16u;
+      const uint32_t lrow = (uint32_t)(c % RING) * Geo::CHB + (uint32_t)l * 16u;
       auto gather4 = [&](uint32_t w, v4f (&v)[4]) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4f*>(ring + ((((w >> (8 * u)) & 0xffu) << (LG + 4)) + lrow));
@@ -723,8 +730,12 @@ extern "C" int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan*
     const dim3 ngrid(grid.x, (unsigned)((D + (4 << lg) - 1) / (4 << lg)));
     const dim3 nblock(512);
     bool ok = true;
+    static const int ring = getenv("MGX_TILE_RING") ? atoi(getenv("MGX_TILE_RING")) : 2;
 #define MGX_NARROW(LG_, NACC_) \
-  if (lg == LG_ && tp->nacc == NACC_) hipLaunchKernelGGL((spmm_tile_narrow_kernel<LG_, NACC_>), ngrid, nblock, 0, s, a); else
+  if (lg == LG_ && tp->nacc == NACC_) { \
+    if (LG_ == 2 && ring == 3) hipLaunchKernelGGL((spmm_tile_narrow_kernel<LG_, NACC_, LG_ == 2 ? 3 : 2>), ngrid, nblock, 0, s, a); \
+    else hipLaunchKernelGGL((spmm_tile_narrow_kernel<LG_, NACC_, 2>), ngrid, nblock, 0, s, a); \
+  } else
     MGX_NARROW(3, 3) MGX_NARROW(3, 4) MGX_NARROW(3, 5) MGX_NARROW(3, 6) MGX_NARROW(3, 8)
     MGX_NARROW(2, 2) MGX_NARROW(2, 3) MGX_NARROW(2, 4) MGX_NARROW(2, 6) MGX_NARROW(2, 8)
 #undef MGX_NARROW
