@@ -27,7 +27,7 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "tile_common.h"
 
 namespace mgx {
 
@@ -495,6 +495,8 @@ static void gat_fixup(const mgx_spmm_plan* plan, int L, const float* partial, fl
 
 }  // namespace mgx
 
+#include "gat_tile.inc"
+
 extern "C" int64_t mgx_gat_fused_workspace(const mgx_spmm_plan* plan, int64_t H, int64_t F) {
   const int64_t slots = plan ? plan->num_slots : 0;
   const int64_t per = H * F + 2 * H;  // [slots, D] partial rows + [slots, 2H] chunk statistics (forward) / [slots, H] (backward)
@@ -627,6 +629,113 @@ extern "C" int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* cs
     if (hubs_src) {
       gat_fixup(csr_plan, D, a.partial, d_feat, s);
       gat_fixup(csr_plan, (int)H, a.partial_h, d_el, s);
+      MGX_CHECK_LAUNCH();
+    }
+  }
+  return MGX_OK;
+}
+
+// ---- tile forms (gat_tile.inc): one head of 4 .. 16 columns on a graph with a tile plan that carries edge ids and node ids.
+// `plan` is the tile plan's BASE plan (its hub tables and slots size the workspace: mgx_gat_fused_workspace(plan, 1, F)).
+extern "C" int32_t mgx_gat_tile_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, const mgx_tile_plan* tp, int64_t H, int64_t F,
+                                    const float* feat, const float* el, const float* er, float negative_slope, float drop_p,
+                                    uint64_t seed, float* out, float* nstat, void* workspace, void* pack_ws, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  int32_t st = gat_check(csr, plan, H, F, csr ? csr->num_cols : 0, drop_p, "mgx_gat_tile_fwd");
+  if (st != MGX_OK) return st;
+  if (!gat_tile_shape_ok(tp, H, F)) MGX_UNSUPPORTED("mgx_gat_tile_fwd: one head of 4 .. 16 columns and a 4-lane tile plan with node ids");
+  if (csr->num_rows == 0 || tp->num_tiles == 0) return MGX_OK;
+  MGX_CHECK_ARG(el && er && out && nstat && feat, "mgx_gat_tile_fwd: NULL pointer");
+  MGX_CHECK_ARG((uintptr_t)feat % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)nstat % 16 == 0, "mgx_gat_tile_fwd: pointers must be 16-byte aligned");
+  const bool hubs = plan && plan->num_slots > 0;
+  MGX_CHECK_ARG(!hubs || workspace, "mgx_gat_tile_fwd: plan has split rows but no workspace");
+  hipStream_t s = (hipStream_t)stream;
+  GatTileArgs a;
+  gat_tile_fill(a, tp, F, negative_slope, drop_p, seed);
+  a.gat = feat; a.small = el; a.er = er; a.nstat_w = nstat; a.out = out;
+  const int pld = pack_ws ? gat_pack_ld(F, 1) : 0;
+  if (pld && csr->num_cols * (int64_t)pld * 4 < (int64_t(1) << 32)) {  // [feat | el] rows: a source's row and record share a line
+    gat_pack(csr->num_cols, (int)F, 1, pld, feat, el, (float*)pack_ws, s);
+    MGX_CHECK_LAUNCH();
+    a.gat = (const float*)pack_ws; a.small = (const float*)pack_ws + round_up(F, 4);
+    a.gat_ld = pld; a.small_ld = pld;
+  }
+  float* ws = (float*)workspace;
+  a.partial = ws;
+  a.partial_h = hubs ? ws + plan->num_slots * F : nullptr;
+  if (!gat_tile_launch<GAT_FWD>(a, tp->nacc, drop_p > 0.f, s)) MGX_UNSUPPORTED("mgx_gat_tile_fwd: no kernel for %d rows per lane group", tp->nacc);
+  MGX_CHECK_LAUNCH();
+  if (hubs) {
+    hipLaunchKernelGGL(gat_online_fixup_kernel, dim3((unsigned)((plan->num_hubs + kWavesPerBlock - 1) / kWavesPerBlock)), dim3(kBlock), 0, s,
+                       plan->hub_row, plan->hub_slot_ptr, plan->num_hubs, 1, (int)F, er, (const float*)a.partial,
+                       (const float*)a.partial_h, out, nstat);
+    MGX_CHECK_LAUNCH();
+  }
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_gat_tile_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan, const mgx_tile_plan* csc_tp, const mgx_csr* csr,
+                                    const mgx_spmm_plan* csr_plan, const mgx_tile_plan* csr_tp, int64_t H, int64_t F, const float* feat,
+                                    const float* el, float negative_slope, float drop_p, uint64_t seed, const float* out,
+                                    const float* d_out, float* nstat, float* d_feat, float* d_el, float* d_er, void* workspace,
+                                    void* pack_ws, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  int32_t st = gat_check(csc, csc_plan, H, F, csc ? csc->num_cols : 0, drop_p, "mgx_gat_tile_bwd");
+  if (st != MGX_OK) return st;
+  st = gat_check(csr, csr_plan, H, F, csr ? csr->num_cols : 0, drop_p, "mgx_gat_tile_bwd");
+  if (st != MGX_OK) return st;
+  if (!gat_tile_shape_ok(csc_tp, H, F) || !gat_tile_shape_ok(csr_tp, H, F))
+    MGX_UNSUPPORTED("mgx_gat_tile_bwd: one head of 4 .. 16 columns and 4-lane tile plans with node ids on both CSRs");
+  MGX_CHECK_ARG(csc->num_rows == csr->num_cols && csc->num_cols == csr->num_rows && csc->nnz == csr->nnz,
+                "mgx_gat_tile_bwd: the two CSRs are not transposes of each other");
+  if (csc->num_rows == 0 || csr->num_rows == 0) return MGX_OK;
+  MGX_CHECK_ARG(feat && el && out && d_out && nstat && d_er, "mgx_gat_tile_bwd: NULL pointer");
+  MGX_CHECK_ARG((uintptr_t)feat % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)d_out % 16 == 0 && (uintptr_t)nstat % 16 == 0 &&
+                (!d_feat || (uintptr_t)d_feat % 16 == 0), "mgx_gat_tile_bwd: pointers must be 16-byte aligned");
+  const bool hubs_dst = csc_plan && csc_plan->num_slots > 0, hubs_src = csr_plan && csr_plan->num_slots > 0;
+  MGX_CHECK_ARG(!(hubs_dst || hubs_src) || workspace, "mgx_gat_tile_bwd: plan has split rows but no workspace");
+  hipStream_t s = (hipStream_t)stream;
+  if (csc_tp->num_tiles > 0) {  // destination side: t[v] and d er
+    GatTileArgs a;
+    gat_tile_fill(a, csc_tp, F, negative_slope, drop_p, seed);
+    a.gat = feat; a.small = el; a.nstat = nstat; a.nstat_w = nstat; a.rowa = d_out; a.rowb = out; a.out_h = d_er;
+    const int pld = pack_ws ? gat_pack_ld(F, 1) : 0;
+    if (pld && csc->num_cols * (int64_t)pld * 4 < (int64_t(1) << 32)) {
+      gat_pack(csc->num_cols, (int)F, 1, pld, feat, el, (float*)pack_ws, s);
+      MGX_CHECK_LAUNCH();
+      a.gat = (const float*)pack_ws; a.small = (const float*)pack_ws + round_up(F, 4);
+      a.gat_ld = pld; a.small_ld = pld;
+    }
+    a.partial_h = (float*)workspace;
+    if (!gat_tile_launch<GAT_BWD_DST>(a, csc_tp->nacc, drop_p > 0.f, s)) MGX_UNSUPPORTED("mgx_gat_tile_bwd: no kernel for this tile plan");
+    MGX_CHECK_LAUNCH();
+    if (hubs_dst) {
+      gat_fixup(csc_plan, 1, (const float*)workspace, d_er, s);
+      MGX_CHECK_LAUNCH();
+    }
+  }
+  if ((d_feat || d_el) && csr_tp->num_tiles > 0) {  // source side: d feat and d el (t of every destination was written just above)
+    MGX_CHECK_ARG(d_feat && d_el, "mgx_gat_tile_bwd: d_feat and d_el come together");
+    GatTileArgs a;
+    gat_tile_fill(a, csr_tp, F, negative_slope, drop_p, seed);
+    a.gat = d_out; a.small = nstat; a.small_ld = 4; a.rowa = feat; a.el_row = el; a.out = d_feat; a.out_h = d_el;
+    const int pld = pack_ws ? gat_pack_ld(F, 4) : 0;
+    if (pld && csr->num_cols * (int64_t)pld * 4 < (int64_t(1) << 32)) {  // [d out | (er, m, 1/s, t)] rows
+      gat_pack(csr->num_cols, (int)F, 4, pld, d_out, nstat, (float*)pack_ws, s);
+      MGX_CHECK_LAUNCH();
+      a.gat = (const float*)pack_ws; a.small = (const float*)pack_ws + round_up(F, 4);
+      a.gat_ld = pld; a.small_ld = pld;
+    }
+    float* ws = (float*)workspace;
+    a.partial = ws;
+    a.partial_h = ws ? ws + (csr_plan ? csr_plan->num_slots : 0) * F : nullptr;
+    if (!gat_tile_launch<GAT_BWD_SRC>(a, csr_tp->nacc, drop_p > 0.f, s)) MGX_UNSUPPORTED("mgx_gat_tile_bwd: no kernel for this tile plan");
+    MGX_CHECK_LAUNCH();
+    if (hubs_src) {
+      gat_fixup(csr_plan, (int)F, a.partial, d_feat, s);
+      gat_fixup(csr_plan, 1, a.partial_h, d_el, s);
       MGX_CHECK_LAUNCH();
     }
   }

@@ -24,7 +24,7 @@
 // Rows wider than 64 columns run as column passes (grid.y) over the same streams.
 #include <stdlib.h>
 
-#include "common.h"
+#include "tile_common.h"
 
 namespace mgx {
 
@@ -34,7 +34,6 @@ constexpr int kSlotBytes = kPassCols * 4;               // 256
 constexpr int kChunkBytes = kChunkSlots * kSlotBytes;   // 32 KiB
 constexpr int kDmaPerChunk = kChunkBytes / 1024;        // LDS-DMA wave-instructions (1 KiB each) per chunk
 constexpr int kStreamRingBytes = 1024;                  // per wave: 4 windows of 16 supersteps x 16 bytes of the staged part's stream
-constexpr int kNoItem = INT32_MIN;
 
 struct TileArgs {
   const float* x;
@@ -65,24 +64,6 @@ struct TileArgs {
 static unsigned long long* g_tile_stamps = nullptr;
 #define MGX_STAMP() __builtin_amdgcn_s_memtime()
 #endif
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-// Plan tables are read-only for the whole launch: reading them through the CONSTANT address space lets a wave-uniform address
-// become a scalar load (s_load_*, lgkmcnt) -- a vector load would share the in-order vmcnt queue with the LDS-DMA / the stream
-// prefetches and every wait for it would drain them.
-template <typename T>
-__device__ __forceinline__ const __attribute__((address_space(4))) T* as_const(const T* p) {
-  return (const __attribute__((address_space(4))) T*)p;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 
 // ---- loader waves ---------------------------------------------------------------------------------------------------------
 template <int W, int NL, int RING>
@@ -470,14 +451,37 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
       if (k < n) issue_rows(k);
       if (k + RING - 1 < n) issue_ids(k + RING - 1);
     }
+#ifdef MGX_TILE_STAMPS
+    unsigned long long t_wait = 0, t_bar = 0, t_issue = 0;
+    const unsigned long long t_begin = MGX_STAMP();
+#endif
     for (int c = 0; c < n; ++c) {
+#ifdef MGX_TILE_STAMPS
+      const unsigned long long t0 = MGX_STAMP();
+#endif
       if (c + 2 * RING - 2 <= n) wait_vmcnt<Geo::kAhead>();  // chunk c and the ids of chunk c + RING - 1 have landed
       else wait_vmcnt<0>();                                   // (the queue is shorter at the end of the tile)
+#ifdef MGX_TILE_STAMPS
+      const unsigned long long t1 = MGX_STAMP();
+#endif
       __builtin_amdgcn_s_barrier();                           // ... and every consumer has finished chunk c - 1
       asm volatile("" ::: "memory");
+#ifdef MGX_TILE_STAMPS
+      const unsigned long long t2 = MGX_STAMP();
+#endif
       if (c + RING - 1 < n) issue_rows(c + RING - 1);
       if (c + 2 * RING - 2 < n) issue_ids(c + 2 * RING - 2);
+#ifdef MGX_TILE_STAMPS
+      const unsigned long long t3 = MGX_STAMP();
+      t_wait += t1 - t0; t_bar += t2 - t1; t_issue += t3 - t2;
+#endif
     }
+#ifdef MGX_TILE_STAMPS
+    if (a.stamps && lane == 0 && blockIdx.y == 0) {
+      unsigned long long* o = a.stamps + ((int64_t)tile * 16 + 0) * 8;
+      o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = MGX_STAMP() - t_begin; o[4] = n;
+    }
+#endif
     return;
   }
 
@@ -486,6 +490,10 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
   v4f acc[NACC];
 #pragma unroll
   for (int j = 0; j < NACC; ++j) acc[j] = (v4f)(0.f);
+#ifdef MGX_TILE_STAMPS
+  unsigned long long t_bar = 0, t_lds = 0, t_dir = 0, n_ss = 0, td0 = 0, td1 = 0;
+  const unsigned long long t_begin = MGX_STAMP();
+#endif
 
   if (n > 0) {
     const auto* cnt = as_const(reinterpret_cast<const v4u*>(a.lds_cnt));
@@ -521,8 +529,16 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
       const v4u cr = NACC > 8 ? cnt[2 * k + 1] : (v4u)(0u);
       const uint32_t cnts[8] = {cq.x, cq.y, cq.z, cq.w, cr.x, cr.y, cr.z, cr.w};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef MGX_TILE_STAMPS
+      const unsigned long long tb0 = MGX_STAMP();
+#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef MGX_TILE_STAMPS
+      const unsigned long long tb1 = MGX_STAMP();
+      t_bar += tb1 - tb0;
+      const int ss_before = ss;
+#endif
       const uint32_t lrow = (uint32_t)(c % RING) * Geo::CHB + (uint32_t)l * 16u;
       auto gather4 = [&](uint32_t w, v4f (&v)[4]) {
 #pragma unroll
@@ -558,14 +574,25 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
           ss += 1;
         }
       }
+#ifdef MGX_TILE_STAMPS
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t_lds += MGX_STAMP() - tb1;
+      n_ss += ss - ss_before;
+#endif
       k += NC;
     }
   }
 
   // ---- direct part: its stream windows (1 KiB = WSD supersteps, ring of 4) live where the chunks were
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef MGX_TILE_STAMPS
+  td0 = MGX_STAMP();
+#endif
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+#ifdef MGX_TILE_STAMPS
+  td1 = MGX_STAMP();
+#endif
   {
     const int64_t k = (int64_t)tile * NC + cw;
     const int so = as_const(a.dir_off)[k], se = as_const(a.dir_off)[k + 1];
@@ -632,6 +659,15 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
     }
   }
 
+#ifdef MGX_TILE_STAMPS
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  t_dir = MGX_STAMP() - td1;
+  if (a.stamps && lane == 0 && blockIdx.y == 0) {
+    unsigned long long* o = a.stamps + ((int64_t)tile * 16 + (cw + 1)) * 8;
+    o[0] = t_bar; o[1] = t_lds; o[2] = t_dir; o[3] = MGX_STAMP() - t_begin; o[4] = n_ss; o[5] = td1 - td0; o[6] = t_begin;
+    o[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20) /* XCC_ID */;
+  }
+#endif
   if (!cvalid) return;
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {

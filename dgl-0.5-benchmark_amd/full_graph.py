@@ -195,6 +195,15 @@ def gat_train_step(model, feats, labels, train_mask, optimizer, loss_fcn):
     return loss.item()
 
 
+GAT_CONFIGS = {
+    # the reference scripts' defaults: layers, hidden, heads (hidden layers / output layer), feat_drop = attn_drop
+    "reddit": dict(num_layers=3, hidden=16, heads=1, out_heads=1, dropout=0.18074706609292976),   # main_dgl_reddit_gat.py:87-96,145-147
+    "arxiv": dict(num_layers=3, hidden=16, heads=4, out_heads=4, dropout=0.18074706609292976),    # main_dgl_arxiv_gat.py:102-111,139-141
+    "cora": dict(num_layers=3, hidden=8, heads=8, out_heads=1, dropout=0.6),                      # main_dgl_citation_gat.py:87-96,146-148
+    "pubmed": dict(num_layers=3, hidden=8, heads=8, out_heads=1, dropout=0.6),
+    "reddit-small": dict(num_layers=2, hidden=16, heads=8, out_heads=1, dropout=0.0),             # BASELINE config 3 (2-layer, 8 heads)
+}
+
 SAGE_CONFIGS = {
     # name: dataset, layers, hidden, dropout, lr, batch_norm, bidirect, neigh_bias   (script defaults)
     "products": dict(dataset="products", num_layers=3, hidden=64, dropout=0.5, lr=0.01, batch_norm=False,
@@ -241,9 +250,11 @@ def main():
     p.add_argument("--dataset", default="products")
     p.add_argument("--epochs", type=int, default=10)
     p.add_argument("--scale", type=float, default=1.0)
-    p.add_argument("--heads", type=int, default=8)
-    p.add_argument("--num-layers", type=int, default=2)
-    p.add_argument("--num-hidden", type=int, default=16)
+    p.add_argument("--heads", type=int, default=None, help="heads of the hidden layers (default: the reference script's)")
+    p.add_argument("--out-heads", type=int, default=None, help="heads of the output layer (default: the reference script's)")
+    p.add_argument("--num-layers", type=int, default=None)
+    p.add_argument("--num-hidden", type=int, default=None)
+    p.add_argument("--dropout", type=float, default=None, help="GAT: feat_drop = attn_drop (default: the reference script's)")
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--hipgraph", action="store_true",
                    help="capture the training step in a HIP graph and replay it (launch-bound small graphs)")
@@ -274,8 +285,15 @@ def main():
         from mi355x_graph.datasets import NodeData
         data = NodeData(args.dataset, device=device, scale=args.scale)
         g = dgl.add_self_loop(data.graph).int().to(device)
-        heads = [args.heads] * (args.num_layers - 1) + [1]
-        model = GAT(g, args.num_layers, data.features.shape[1], args.num_hidden, data.num_classes, heads).to(device)
+        gcfg = dict(GAT_CONFIGS.get(args.dataset, GAT_CONFIGS["reddit-small"]))
+        for key, val in (("heads", args.heads), ("out_heads", args.out_heads), ("num_layers", args.num_layers),
+                         ("hidden", args.num_hidden), ("dropout", args.dropout)):
+            if val is not None:
+                gcfg[key] = val
+        heads = [gcfg["heads"]] * (gcfg["num_layers"] - 1) + [gcfg["out_heads"]]
+        print("GAT: %d layers, heads %s, hidden %d, feat_drop = attn_drop = %g" % (gcfg["num_layers"], heads, gcfg["hidden"], gcfg["dropout"]))
+        model = GAT(g, gcfg["num_layers"], data.features.shape[1], gcfg["hidden"], data.num_classes, heads,
+                    feat_drop=gcfg["dropout"], attn_drop=gcfg["dropout"]).to(device)
         opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=2.4e-5)
         loss_fcn = nn.CrossEntropyLoss()
         if args.hipgraph:

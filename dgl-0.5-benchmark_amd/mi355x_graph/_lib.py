@@ -63,6 +63,10 @@ SIGNATURES = {
                                  _vp, _vp, _vp]),
     "mgx_gat_fused_bwd": (_i32, [_csr_p, _vp, _csr_p, _vp, _i64, _i64, _fp, _fp, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64,
                                  _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _vp]),
+    "mgx_gat_tile_fwd": (_i32, [_csr_p, _vp, _vp, _i64, _i64, _fp, _fp, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64, _fp, _fp,
+                                _vp, _vp, _vp]),
+    "mgx_gat_tile_bwd": (_i32, [_csr_p, _vp, _vp, _csr_p, _vp, _vp, _i64, _i64, _fp, _fp, ctypes.c_float, ctypes.c_float, ctypes.c_uint64,
+                                _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp, _vp]),
     "mgx_head_dot_fwd": (_i32, [_i64, _i64, _i64, _fp, _fp, _fp, _fp, _fp, _vp]),
     "mgx_head_dot_bwd_workspace": (_i64, [_i64, _i64]),
     "mgx_head_dot_bwd": (_i32, [_i64, _i64, _i64, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _vp, _vp]),

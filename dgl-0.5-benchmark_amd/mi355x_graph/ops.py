@@ -295,7 +295,11 @@ class GATFused(torch.autograd.Function):
         if p > 0.0:
             seed = ((torch.initial_seed() & (2 ** 64 - 1)) ^ ((GATFused._calls * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)))
             GATFused._calls += 1
-        out, nstat = sparse.backend_for(feat).gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed, attn_l)
+        be = sparse.backend_for(feat)
+        if p > 0.0 and be.name == "hip":  # training with attn_drop: the backward needs the out-CSR anyway; the forward's choice of kernel too
+            out, nstat = be.gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed, attn_l, csr=gidx.csr())
+        else:
+            out, nstat = be.gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed, attn_l)
         ctx.backward_cache = gidx, float(slope), float(p), seed, el.shape, er.shape, attn_l
         ctx.save_for_backward(feat, el2, out, nstat)
         return out

@@ -95,6 +95,26 @@ class CsrView(object):
             self._plan = schedule.plan_for(self) if self.indptr.is_cuda else None
         return self._plan
 
+    def gat_tile_plan(self, F):
+        """Tile plan for the fused GAT walks over this CSR (one head of 4 .. 16 columns, dense neighbourhoods: gat_tile.inc), else None.
+        Its own plan: 4 lanes per row with the node of every position; stats["parallel_edges"] says whether attn_drop may use it."""
+        from . import tileplan
+        if F % 4 != 0 or not 4 <= F <= 16 or os.environ.get("MGX_GAT_TILE", "0") != "1":  # opt-in: measured slower than the row walks (DESIGN 4.4e)
+            return None
+        if self._tile_plan is False:
+            self._tile_plan = {} if tileplan.tile_plan_wanted(self) else None
+        if self._tile_plan is None:
+            return None
+        if "gat" not in self._tile_plan:
+            from . import schedule
+            self.plan()
+            nc, nacc, nl, tau = tileplan.gat_config()
+            base = schedule.plan_for(self, split=tileplan.TILE_SPLIT)
+            held = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=2, check_parallel=True)
+            tileplan.validate(held, self)
+            self._tile_plan["gat"] = held
+        return self._tile_plan["gat"]
+
     def tile_plan(self, width=64):
         """Tile plan of the LDS-staged g-SpMM (tileplan.py) for rows of `width` columns on graphs with dense neighbourhoods, else
         None; built on first use, one per kernel geometry (64- / 32- / 16-column passes)."""
@@ -482,12 +502,38 @@ class HipBackend(object):
         need = max([L.mgx_gat_fused_workspace(self._plan_ptr(p), H, F) for p in plans] + [0])
         return torch.empty(need // 4, dtype=torch.float32, device=dev) if need else None
 
-    def gat_fused_fwd(self, csc, feat3d, el2d, er2d, slope, p, seed, attn_l=None):
-        """feat3d [n_src, H, F], el2d [n_src, H], er2d [n_dst, H] -> (out [n_dst, H, F], nstat [n_dst, H, 4])."""
+    @staticmethod
+    def _gat_tile_plans(csc, csr, H, F, p):
+        """(tile plan of the in-CSR, of the out-CSR | None) when a layer's walks run as tile kernels, else None.  With attn_drop the
+        two forms key the mask differently (edge id / endpoint pair), so a layer takes the tile form for ALL three walks or for
+        none: it needs both plans and a graph without parallel edges."""
+        if H != 1:
+            return None
+        t_dst = csc.gat_tile_plan(F)
+        if t_dst is None:
+            return None
+        t_src = csr.gat_tile_plan(F) if csr is not None else None
+        if p > 0.0 and (t_src is None or t_dst.stats["parallel_edges"] or t_src.stats["parallel_edges"]):
+            return None
+        return t_dst, t_src
+
+    def gat_fused_fwd(self, csc, feat3d, el2d, er2d, slope, p, seed, attn_l=None, csr=None):
+        """feat3d [n_src, H, F], el2d [n_src, H], er2d [n_dst, H] -> (out [n_dst, H, F], nstat [n_dst, H, 4]).
+        csr: the out-CSR, needed to choose the tile form when p > 0 (see _gat_tile_plans)."""
         dev = self._check_dev(csc.indptr, feat3d, el2d, er2d)
         H, F = int(feat3d.shape[1]), int(feat3d.shape[2])
         out = torch.empty((csc.num_rows, H, F), dtype=torch.float32, device=dev)
         nstat = torch.empty((csc.num_rows, H, 4), dtype=torch.float32, device=dev)
+        tiles = self._gat_tile_plans(csc, csr, H, F, p)
+        if tiles is not None:  # dense neighbourhoods, one narrow head: the LDS-staged tile walk
+            tp = tiles[0]
+            ws = self._gat_ws([tp.base], H, F, dev)
+            pack = self._gat_pack_ws(csc, H, F, dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().mgx_gat_tile_fwd(ctypes.byref(csc.c_struct()), self._plan_ptr(tp.base), ctypes.byref(tp.c_struct()),
+                                                       H, F, _ptr(feat3d), _ptr(el2d), _ptr(er2d), ctypes.c_float(slope), ctypes.c_float(p),
+                                                       ctypes.c_uint64(seed), _ptr(out), _ptr(nstat), _ptr(ws), _ptr(pack), _stream(dev)))
+            return out, nstat
         plan = csc.plan()
         ws = self._gat_ws([plan], H, F, dev)
         pack = self._gat_pack_ws(csc, H, F, dev)
@@ -509,6 +555,20 @@ class HipBackend(object):
         d_er = torch.empty((csc.num_rows, H), dtype=torch.float32, device=dev)
         d_feat = torch.empty_like(feat3d) if need_src else None
         d_el = torch.empty((csc.num_cols, H), dtype=torch.float32, device=dev) if need_src else None
+        tiles = self._gat_tile_plans(csc, csr, H, F, p)
+        if tiles is not None and tiles[1] is not None:
+            t_dst, t_src = tiles
+            if not need_src:  # the kernel's source walk is skipped when both are NULL
+                d_feat = d_el = None
+            ws = self._gat_ws([t_dst.base, t_src.base], H, F, dev)
+            pack = self._gat_pack_ws(csc, H, F, dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().mgx_gat_tile_bwd(ctypes.byref(csc.c_struct()), self._plan_ptr(t_dst.base), ctypes.byref(t_dst.c_struct()),
+                                                       ctypes.byref(csr.c_struct()), self._plan_ptr(t_src.base), ctypes.byref(t_src.c_struct()),
+                                                       H, F, _ptr(feat3d), _ptr(el2d), ctypes.c_float(slope), ctypes.c_float(p),
+                                                       ctypes.c_uint64(seed), _ptr(out3d), _ptr(d_out3d), _ptr(nstat), _ptr(d_feat),
+                                                       _ptr(d_el), _ptr(d_er), _ptr(ws), _ptr(pack), _stream(dev)))
+            return d_feat, d_el, d_er
         p_dst, p_src = csc.plan(), csr.plan()
         ws = self._gat_ws([p_dst, p_src], H, F, dev)
         pack = self._gat_pack_ws(csc, H, F, dev)

@@ -57,6 +57,7 @@ class MgxTilePlan(ctypes.Structure):
         ("tile_item", ctypes.c_void_p),
         ("zero_row", ctypes.c_void_p),
         ("tile_order", ctypes.c_void_p),
+        ("tile_node", ctypes.c_void_p),
     ]
 
 
@@ -91,7 +92,8 @@ class TilePlan(object):
                                   self.consumers, self.nacc, self.loaders, self.lanes_log2, p(self.tile_chunk_ptr), p(self.chunk_ids), p(self.lds_off),
                                   p(self.lds_cnt), p(self.lds_stream), p(self.dir_off), p(self.dir_cnt), p(self.dir_stream),
                                   p(self.tile_item), p(self.zero_row),
-                                  p(self.tile_order) if getattr(self, "tile_order", None) is not None else None)
+                                  p(self.tile_order) if getattr(self, "tile_order", None) is not None else None,
+                                  p(self.tile_node) if getattr(self, "tile_node", None) is not None else None)
         return self._c
 
 
@@ -101,7 +103,7 @@ def _excl_cumsum(x):
     return out
 
 
-def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None, groups=GROUPS, extra=None):
+def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None, groups=GROUPS):
     """Edges with segment key (seg * 4 + g), seg = a (unit, cw, j) row of the stream -> (superstep counts per seg, first superstep
     of each seg, stream).  A row has max_g(count) steps rounded up to whole SUPERSTEPS (4 steps); layout
     [superstep][lane group g][step u]: one payload per entry, `pad` where a group has run out.  `seg_order`: the order in which
@@ -127,11 +129,6 @@ def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None, groups=GROUPS, 
         rank = torch.arange(sk.shape[0], device=dev) - seg_start[sk]
         idx = ((base[sk // groups] + rank // 4) * groups + (sk % groups)) * 4 + rank % 4
         stream[idx] = payload[order].to(dtype)
-    if extra is not None:  # a second int32 payload per entry (the edge ids that key attn_drop), same layout, -1 where padded
-        second = torch.full(((total + STREAM_TAIL) * groups * 4,), -1, dtype=torch.int32, device=dev)
-        if seg_key.numel():
-            second[idx] = extra[order].to(torch.int32)
-        return ssteps, base, total, stream, second
     return ssteps, base, total, stream
 
 
@@ -150,10 +147,10 @@ def _longest_first(tile_edges, T, xcds=8):
     return torch.sort(key, stable=True)[1].to(torch.int32)
 
 
-def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, edge_ids=False):
+def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, check_parallel=False):
     """csr: CsrView (int32, device or host); base: SpmmPlan over it (items in schedule order; None = natural rows).
-    edge_ids: also lay out every entry's EDGE ID (csr.eids, or the CSR position) beside the two streams -- the fused GAT walks
-    regenerate the attn_drop mask of an edge from it (gat_tile.hip)."""
+    check_parallel: also find out whether the graph has parallel edges (stats["parallel_edges"]) -- the fused GAT walks over a
+    tile plan key the attn_drop mask by (destination, source) and are taken with attn_drop > 0 only when that is a key per edge."""
     dev = csr.indptr.device
     NC, NACC = int(consumers), int(nacc)
     if NC + int(loaders) not in TILE_WAVES or not 1 <= NACC <= CNT_STRIDE or int(loaders) not in (1, 2, 4):
@@ -206,16 +203,20 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     pos = (cw * NACC + rnd) * GROUPS + g
     tile_item = torch.full((T * R,), NO_ITEM, dtype=torch.int64, device=dev)
     tile_item[it_tile * R + pos] = item_row
+    tile_node = torch.zeros((T * R,), dtype=torch.int32, device=dev)  # the NODE of every position's item (hub chunks: their row)
+    tile_node[it_tile * R + pos] = (base.item_node if base is not None and base.item_node is not None else item_row).to(torch.int32)
     # ---- edges: (tile, position in tile, source)
     e_item = torch.repeat_interleave(torch.arange(I, device=dev), lens)
     first = _excl_cumsum(lens)[:-1]
-    e_csr = beg[e_item] + (torch.arange(E, device=dev) - first[e_item])  # position of the edge in the CSR
-    e_src = csr.indices[e_csr].long()
-    e_key = None
-    if edge_ids:
-        e_key = csr.eids[e_csr].to(torch.int32) if getattr(csr, "eids", None) is not None else e_csr.to(torch.int32)
+    e_src = csr.indices[beg[e_item] + (torch.arange(E, device=dev) - first[e_item])].long()
+    parallel = None
+    if check_parallel:  # two edges with the same (row, source): equal neighbours in the sorted pair keys
+        node = (base.item_node if base is not None and base.item_node is not None else item_row).long()
+        pk = torch.sort(node[e_item] * n_src + e_src)[0]
+        parallel = bool((pk[1:] == pk[:-1]).any()) if E > 1 else False
+        del pk, node
     e_tile, e_pos = it_tile[e_item], pos[e_item]
-    del e_item, first, e_csr
+    del e_item, first
     # ---- sources gathered >= tau times inside a tile are staged; per tile they are ordered by multiplicity (dense chunks first)
     skey, perm = torch.sort(e_tile * n_src + e_src)
     uniq, inv, counts = torch.unique_consecutive(skey, return_inverse=True, return_counts=True)
@@ -255,22 +256,13 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     chunk_tile = torch.repeat_interleave(torch.arange(T, device=dev), tile_chunk_ptr[1:] - tile_chunk_ptr[:-1])
     seg_unit = (chunk_tile[seg_chunk] * NC + seg_cw) if NCH else seg
     seg_order = torch.sort(seg_unit, stable=True)[1]  # stable: (chunk, j) order kept inside a (tile, cw)
-    lds_eid = dir_eid = None
-    if edge_ids:
-        lds_cnt, lds_base, lds_total, lds_bytes, lds_eid = _streams(sk, nseg, e_slot[staged], ZERO_SLOT, torch.uint8, seg_order, GROUPS,
-                                                                    extra=e_key[staged])
-    else:
-        lds_cnt, lds_base, lds_total, lds_bytes = _streams(sk, nseg, e_slot[staged], ZERO_SLOT, torch.uint8, seg_order, GROUPS)
+    lds_cnt, lds_base, lds_total, lds_bytes = _streams(sk, nseg, e_slot[staged], ZERO_SLOT, torch.uint8, seg_order, GROUPS)
     lds_off = _excl_cumsum(torch.bincount(seg_unit, weights=lds_cnt.double(), minlength=T * NC).long()) if NCH else \
         torch.zeros(T * NC + 1, dtype=torch.int64, device=dev)
     # ---- direct streams: one per (tile, consumer wave)
     direct = ~staged
     dk = e_tile[direct] * per_unit + e_pos[direct]
-    if edge_ids:
-        dir_cnt, dir_base, dir_total, dir_stream, dir_eid = _streams(dk, T * NC * NACC, e_src[direct], -1, torch.int32, None, GROUPS,
-                                                                     extra=e_key[direct])
-    else:
-        dir_cnt, dir_base, dir_total, dir_stream = _streams(dk, T * NC * NACC, e_src[direct], -1, torch.int32, None, GROUPS)
+    dir_cnt, dir_base, dir_total, dir_stream = _streams(dk, T * NC * NACC, e_src[direct], -1, torch.int32, None, GROUPS)
     dir_off = torch.cat([dir_base.view(-1)[::NACC], torch.tensor([dir_total], device=dev)])
     if int(lds_cnt.max() if lds_cnt.numel() else 0) > 65535:
         raise ValueError("tile plan: more than 65535 supersteps in one (chunk, row)")
@@ -287,7 +279,8 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
              "dir_supersteps": int(dir_stream.shape[0]) // (4 * GROUPS) - STREAM_TAIL,
              "gathered_rows_per_edge": (int(sel.shape[0]) + E - n_staged) / max(E, 1),
              "lds_slot_fill": n_staged / max(int(lds_bytes.shape[0]) - STREAM_TAIL * GROUPS * 4, 1),
-             "dir_slot_fill": (E - n_staged) / max(int(dir_stream.shape[0]) - STREAM_TAIL * GROUPS * 4, 1)}
+             "dir_slot_fill": (E - n_staged) / max(int(dir_stream.shape[0]) - STREAM_TAIL * GROUPS * 4, 1),
+             "parallel_edges": parallel}
     tables = {
         "tile_chunk_ptr": tile_chunk_ptr.to(torch.int32),
         "chunk_ids": chunk_ids,
@@ -299,8 +292,7 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         "dir_stream": dir_stream,                      # [dir_supersteps * 16] source ids, -1 = padding
         "tile_item": tile_item.to(torch.int32),        # [T * R] item_row of the item at every position, NO_ITEM = none
         "zero_row": torch.zeros(64, dtype=torch.float32, device=dev),
-        "lds_eid": lds_eid,                            # [lds_supersteps * groups * 4] edge id of every staged entry (edge_ids=True)
-        "dir_eid": dir_eid,                            # [dir_supersteps * groups * 4]
+        "tile_node": tile_node,
         "tile_order": _longest_first(torch.bincount(e_tile, minlength=T), T) if os.environ.get("MGX_TILE_LPT", "0") == "1" else None,
     }
     if lds_total * 4 >= 2 ** 31 or dir_total * 16 >= 2 ** 31:
@@ -453,6 +445,11 @@ def config(lanes_log2=4):
     per CU.  MGX_TILE_CFG=14x6x2x3 overrides the 64-column kernel's, MGX_TILE_CFG_NARROW the other two."""
     env = os.environ.get("MGX_TILE_CFG" if lanes_log2 == 4 else "MGX_TILE_CFG_NARROW", "") or _DEFAULT_CFG[int(lanes_log2)]
     return tuple(int(v) for v in env.split("x"))
+
+
+def gat_config():
+    """(consumers, nacc, loaders, tau) of the tile plans behind the fused GAT walks (gat_tile.inc: 7 + 1 waves, nacc 3 or 4)."""
+    return tuple(int(v) for v in (os.environ.get("MGX_GAT_TILE_CFG", "") or "7x3x1x2").split("x"))
 
 
 def lanes_log2_for(width):

@@ -1,7 +1,7 @@
 """Where a tile of the LDS-staged g-SpMM spends its cycles (diagnostic build of csrc/spmm_tile.hip with -DMGX_TILE_STAMPS: s_memtime
 stamps per wave, written to a side buffer; the product build executes no stamp).
 
-  MGX_LIB_PATH=experiments/tile_spmm/libmgx_stamps.so python experiments/exp_tile_stamps.py reddit 14x6x2x2 [D]
+  MGX_LIB_PATH=experiments/tile_spmm/libmgx_stamps.so python experiments/exp_tile_stamps.py reddit 14x6x2x2 [D] [lanes_log2]
 """
 import ctypes
 import os
@@ -18,6 +18,7 @@ dev = torch.device("cuda:0")
 name = sys.argv[1] if len(sys.argv) > 1 else "reddit"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "14x6x2x2"
 D = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+LG = int(sys.argv[4]) if len(sys.argv) > 4 else 4  # lanes per row (log2): 3 / 2 = the narrow kernels
 nc, nacc, nl, tau = [int(v) for v in cfg.split("x")]
 spec = SHAPES[name]
 n, m = spec["n"], spec["m"]
@@ -25,7 +26,7 @@ src, dst = synthetic_edges(n, m, min(spec["max_deg"], n - 1), spec["seed"], dev,
 csr = sparse.coo_to_csr(n, n, dst.int().contiguous(), src.int().contiguous())
 del src, dst
 base = schedule.plan_for(csr, split=2048)
-tp = tileplan.build_tile_plan(csr, base, nc, nacc, nl, tau)
+tp = tileplan.build_tile_plan(csr, base, nc, nacc, nl, tau, lanes_log2=LG)
 be = sparse.backend_for(torch.zeros(1, device=dev))
 x = torch.rand(n, D, device=dev)
 L = _lib.lib()
@@ -46,7 +47,7 @@ torch.cuda.synchronize()
 fn(None)
 ms = e0.elapsed_time(e1)
 s = stamps.cpu().double()
-ld, co = s[:, :nl], s[:, nl:]
+ld, co = s[:, :nl], s[:, nl:nl + nc]
 tot = co[:, :, 3]
 t0 = co[:, :, 6]
 span = float((t0 + tot).max() - t0.min())

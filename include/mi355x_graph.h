@@ -211,6 +211,7 @@ typedef struct mgx_tile_plan {
   const int32_t* tile_item;
   const float* zero_row;
   const int32_t* tile_order; /* optional [num_tiles]: dispatch slot -> tile; slots [x * ceil(T/8), ...) run on XCD x in order */
+  const int32_t* tile_node; /* optional [num_tiles*R]: the NODE of the item at every position (hub chunks: their row); mgx_gat_tile_* */
 } mgx_tile_plan;
 int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, const mgx_tile_plan* tile_plan,
                              int32_t reduce, const float* ufeat, int64_t D, int64_t u_stride, const float* dst_scale /* may be NULL */,
@@ -302,6 +303,22 @@ int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan /* m
                           float drop_p, uint64_t seed, const float* out, const float* d_out, float* nstat,
                           float* d_feat /* may be NULL with d_el */, float* d_el, float* d_er, void* workspace, void* pack_ws,
                           void* stream);
+
+/* The same three walks over a TILE plan (csrc/gat_tile.inc): one head of 4, 8, 12 or 16 columns on a graph with dense
+ * neighbourhoods (main_dgl_reddit_gat.py on reddit).  `tile_plan`: 4 lanes per row (lanes_log2 = 2), 7 + 1 waves, nacc 3 or 4, with
+ * tile_node; `plan`: the tile plan's base plan (its hub tables; workspace = mgx_gat_fused_workspace(plan, 1, F)).  Same arguments,
+ * results and statistics as mgx_gat_fused_fwd / _bwd, another fp32 summation order (deterministic for a given plan).  attn_drop:
+ * the mask bit of an edge is a function of (seed, destination, source) here -- of (seed, edge id) in the row kernels --, so (i) use
+ * the tile form for all three walks of a layer or for none when drop_p > 0, and (ii) parallel edges would share a bit: the caller
+ * takes this form with drop_p > 0 only on graphs without parallel edges.  Other shapes: MGX_ERR_UNSUPPORTED. */
+int32_t mgx_gat_tile_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, const mgx_tile_plan* tile_plan, int64_t H, int64_t F,
+                         const float* feat, const float* el, const float* er, float negative_slope, float drop_p, uint64_t seed,
+                         float* out, float* nstat, void* workspace, void* pack_ws, void* stream);
+int32_t mgx_gat_tile_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan, const mgx_tile_plan* csc_tile_plan, const mgx_csr* csr,
+                         const mgx_spmm_plan* csr_plan, const mgx_tile_plan* csr_tile_plan, int64_t H, int64_t F, const float* feat,
+                         const float* el, float negative_slope, float drop_p, uint64_t seed, const float* out, const float* d_out,
+                         float* nstat, float* d_feat /* may be NULL with d_el */, float* d_el, float* d_er, void* workspace,
+                         void* pack_ws, void* stream);
 
 /* ------------------------------------------------------------------ GAT attention terms
  * el[n,h] = sum_f feat[n,h,f] * attn[h,f] -- GATConv's `(feat * attn_l).sum(-1)` (main_dgl_reddit_gat.py:10, UPSTREAM

@@ -36,9 +36,12 @@ def hubby_graph(n, nnz, seed, hub_deg=3000):
     return src.astype(np.int64), dst.astype(np.int64)
 
 
+def unfused_attention(g, el, er, slope):
+    return ops.edge_softmax(g, F.leaky_relu(ops.gsddmm(g, "add", el, er, "u", "v"), slope))
+
+
 def unfused(g, feat, el, er, slope):
-    a = ops.edge_softmax(g, F.leaky_relu(ops.gsddmm(g, "add", el, er, "u", "v"), slope))
-    return ops.gspmm(g, "mul", "sum", feat, a)
+    return ops.gspmm(g, "mul", "sum", feat, unfused_attention(g, el, er, slope))
 
 
 @pytest.mark.parametrize("n,H,Fd", [(900, 1, 16), (900, 8, 16), (700, 4, 8), (500, 2, 64), (300, 1, 4), (600, 3, 16), (400, 1, 256),
@@ -218,6 +221,85 @@ def test_one_head_widening_layer_aggregates_first(k, f, residual, monkeypatch):
     widths.clear()
     GATConv(f, k, 1).to(DEV)(g, torch.randn(n, f, device=DEV))  # a narrowing layer keeps the usual order
     assert widths == [k]
+
+
+def pair_keep(seed, dst, src, p):
+    """The tile walks' attn_drop mask (csrc/gat_tile.inc: gat_pair_keep): splitmix64 of seed ^ (dst << 32 | src), kept when the
+    low 32 bits are >= p * 2^32; in wrapping int64 arithmetic."""
+    def c(v):
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    def shr(z, k):  # logical shift of a two's-complement int64
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    z = torch.full_like(dst, c(seed & ((1 << 64) - 1))) ^ ((dst << 32) | src)
+    z = z + c(0x9E3779B97F4A7C15)
+    z = (z ^ shr(z, 30)) * c(0xBF58476D1CE4E5B9)
+    z = (z ^ shr(z, 27)) * c(0x94D049BB133111EB)
+    z = z ^ shr(z, 31)
+    return (z & 0xFFFFFFFF) >= min(int(p * 4294967296.0), 4294967295)
+
+
+@pytest.mark.parametrize("Fd,p", [(16, 0.0), (16, 0.3), (8, 0.0), (4, 0.25), (12, 0.4)])
+def test_tile_walks_match_the_row_kernels(Fd, p, monkeypatch):
+    """One head of up to 16 columns on a graph with dense neighbourhoods (main_dgl_reddit_gat.py on reddit): the three walks run
+    as LDS-staged tile kernels (csrc/gat_tile.inc) -- same outputs and gradients (1e-4 relative) as the row kernels at p = 0, and
+    with attn_drop as the unfused operators with the tile walks' mask (one bit per (seed, destination, source)) applied to the
+    attention; hub rows split by the tile plan included."""
+    n = 2500
+    src, dst = random_graph(n, n, 600000, seed=31)
+    rng = np.random.default_rng(5)
+    hub_in, hub_out = rng.integers(0, n, 21000), rng.integers(0, n, 9000)   # > 2,048 edges: split work items on both sides
+    src = np.concatenate([src, hub_in, np.full(9000, 17)]).astype(np.int64)
+    dst = np.concatenate([dst, np.full(21000, 23), hub_out]).astype(np.int64)
+    pairs = np.unique(dst * n + src)                                        # attn_drop on a tile plan: no parallel edges
+    src, dst = pairs % n, pairs // n
+    feat0 = torch.randn(n, 1, Fd, device=DEV)
+    el0, er0 = torch.randn(n, 1, 1, device=DEV), torch.randn(n, 1, 1, device=DEV)
+    w = torch.randn(n, 1, Fd, device=DEV)
+    monkeypatch.setenv("MGX_TILE", "1")
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MGX_GAT_TILE", mode)
+        g = mk(n, n, src, dst)
+        feat, el, er = (t.clone().requires_grad_(True) for t in (feat0, el0, er0))
+        torch.manual_seed(7)
+        ops.GATFused._calls = 0  # the mask's seed = (torch seed, call counter)
+        if mode == "1" or p == 0.0:
+            out = ops.gat_fused(g, feat, el, er, 0.2, p, True)
+        else:  # the reference under attn_drop: unfused operators, the mask applied to the attention
+            keep = pair_keep(7, T(dst), T(src), p).float().view(-1, 1, 1) / (1.0 - p)
+            out = ops.gspmm(g, "mul", "sum", feat, unfused_attention(g, el, er, 0.2) * keep)
+        held = g._index.csc()._tile_plan
+        assert (isinstance(held, dict) and "gat" in held) == (mode == "1"), "the tile walk was %staken" % ("not " if mode == "1" else "")
+        (out * w).sum().backward()
+        res[mode] = [out.detach(), feat.grad, el.grad, er.grad]
+        if mode == "1":
+            assert held["gat"].stats["parallel_edges"] is False and held["gat"].base.num_slots > 0
+            ops.GATFused._calls = 0
+            again = ops.gat_fused(g, feat0, el0, er0, 0.2, p, True)
+            assert torch.equal(again, out.detach())  # no atomics: bitwise reruns
+    for name, a_, b_ in zip(("out", "d_feat", "d_el", "d_er"), res["1"], res["0"]):
+        assert float((a_ - b_).abs().max()) < RTOL * float(b_.abs().max()) + 1e-6, (name, float((a_ - b_).abs().max()), float(b_.abs().max()))
+
+
+def test_tile_walks_leave_attn_drop_on_a_multigraph_to_the_row_kernels(monkeypatch):
+    """Parallel edges would share a mask bit in the tile walks (keyed by endpoint pair): with attn_drop > 0 such a graph keeps the
+    row kernels (edge-id keys) for all three walks; without dropout it takes the tile walks."""
+    n = 2000
+    src, dst = random_graph(n, n, 500000, seed=37)  # sampled with replacement: a few thousand repeated pairs
+    assert np.unique(dst * n + src).shape[0] < src.shape[0]
+    monkeypatch.setenv("MGX_TILE", "1")
+    monkeypatch.setenv("MGX_GAT_TILE", "1")
+    g = mk(n, n, src, dst)
+    feat = torch.randn(n, 1, 16, device=DEV, requires_grad=True)
+    el, er = torch.randn(n, 1, 1, device=DEV), torch.randn(n, 1, 1, device=DEV)
+    be = __import__("mi355x_graph").sparse.backend_for(feat)
+    csc, csr = g._index.csc(), g._index.csr()
+    assert be._gat_tile_plans(csc, csr, 1, 16, 0.0) is not None and csc.gat_tile_plan(16).stats["parallel_edges"] is True
+    assert be._gat_tile_plans(csc, csr, 1, 16, 0.3) is None
+    ops.gat_fused(g, feat, el, er, 0.2, 0.3, True).sum().backward()  # row kernels: runs, finite
+    assert bool(torch.isfinite(feat.grad).all())
 
 
 def test_fused_rejects_mismatched_rows():
