@@ -16,7 +16,7 @@
 //             gat_fused_kernel<BWD_SRC> walks the out-CSR (gathers d out[v] and nstat[v]): d feat[u,h,:] = sum_e a' d out[v,h,:]
 //                                       and d el[u,h] = sum_e d z
 // using  sum_e a' d a = <out[v,h,:], d out[v,h,:]>  (out IS that weighted sum), so the softmax backward needs no pass
-// of its own.  attn_drop is a counter-based mask keyed by (seed, edge id, head): every kernel regenerates the same bit.
+// of its own.  attn_drop is a counter-based mask keyed by (seed, edge id, head): every kernel regenerates the same bit (gat_hash).
 //
 // All three gather kernels are laid out like the summing g-SpMM (spmm.hip): one wave per work item of the
 // mgx_spmm_plan, lanes ALONG the H*F feature row with 16-byte loads, 64/G neighbour rows per wave-instruction, ids
@@ -31,11 +31,19 @@
 
 namespace mgx {
 
-__device__ __forceinline__ uint64_t gat_mix64(uint64_t z) {  // splitmix64 finaliser (same generator as elementwise.hip)
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
+// attn_drop: one bit per (seed, key): key = (edge id, head) in the row kernels, (source, destination) in the tile walks.  A 32-bit
+// multiply-xorshift mixer (lowbias32's constants; the second key word and the seed's high half enter between its two rounds):
+// two 32-bit multiplies per bit -- the splitmix64 finaliser used before costs two 64-bit multiplies, eight quarter-rate 32-bit ones
+// on CDNA, per edge and lane (reddit GAT walks with attn_drop: 1.08 / 0.97 / 1.02 -> see profiles/r03_gat_reddit_kernel_stats.txt).
+__device__ __forceinline__ uint32_t gat_hash(uint64_t seed, uint32_t klo, uint32_t khi) {
+  uint32_t x = klo ^ (uint32_t)seed;
+  x ^= x >> 16;
+  x *= 0x7feb352du;
+  x ^= x >> 15;
+  x ^= khi + (uint32_t)(seed >> 32);
+  x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
 }
 
 struct GatArgs {
@@ -263,8 +271,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
           const bool live = k + u * NB + sub < cnt;
           float keep = 1.f;
           if (DROP) {
-            const uint64_t rnd = gat_mix64(a.seed ^ ((uint64_t)(uint32_t)ee[u] * (uint64_t)H + (uint64_t)head));
-            keep = (uint32_t)rnd >= a.drop_below ? a.keep_scale : 0.f;
+            keep = gat_hash(a.seed, (uint32_t)ee[u], (uint32_t)head) >= a.drop_below ? a.keep_scale : 0.f;
           }
           if (ELK && MODE != GAT_BWD_SRC) sm[u].x = head_dot(val[u]);
           if (MODE == GAT_FWD) {

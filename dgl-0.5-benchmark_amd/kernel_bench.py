@@ -57,10 +57,18 @@ def sddmm_bytes(n_src, n_dst, nnz, D, op):
     return 8 * nnz + 4 * n_src * D + 4 * n_dst * D + 4 * nnz * (1 if op == "dot" else D)
 
 
-def get_graph(name, device, scale):
+def get_graph(name, device, scale, edge_order="generated"):
+    """edge_order: the stand-in's edge list comes out of the generator in RANDOM order -- the worst case for an edge-parallel
+    g-SDDMM (both endpoint rows of consecutive edges are unrelated) and not how the datasets are stored: an adjacency kept as a
+    scipy matrix (RedditDataset) or exported from one lists its edges sorted by row.  "dst" / "src" sort the same edges by
+    (destination, source) / (source, destination) before the graph is built; edge ids follow the list, as in dgl.graph()."""
     spec = SHAPES[name]
     n, m = int(spec["n"] * scale), int(spec["m"] * scale)
     src, dst = synthetic_edges(n, m, min(spec["max_deg"], n - 1), spec["seed"], device, symmetric=spec["symmetric"])
+    if edge_order != "generated":
+        major, minor = (dst, src) if edge_order == "dst" else (src, dst)
+        order = torch.argsort(major.long() * n + minor.long())
+        src, dst = src[order].contiguous(), dst[order].contiguous()
     return dgl.graph((src, dst), num_nodes=n)
 
 
@@ -74,6 +82,9 @@ def main():
     p.add_argument("--hidden", type=str, default="1,2,4,8,16,32,64,128")
     p.add_argument("--scale", type=float, default=1.0)
     p.add_argument("--no-sddmm", action="store_true")
+    p.add_argument("--no-spmm", action="store_true")
+    p.add_argument("--edge-order", choices=["generated", "dst", "src"], default="generated",
+                   help="order of the edge list (= of the edge ids): as generated (random), or sorted by destination / source")
     p.add_argument("--json", type=str, default=None)
     args = p.parse_args()
     if args.gpu == "-1":
@@ -81,12 +92,14 @@ def main():
     ctx = torch.device("cuda:%d" % int(args.gpu))
     results = []
     for ds in args.datasets.split(","):
-        g = get_graph(ds, ctx, args.scale).int().to(ctx)
+        g = get_graph(ds, ctx, args.scale, args.edge_order).int().to(ctx)
         print(g)
+        if args.edge_order != "generated":
+            print("(edge list sorted by %s)" % ("destination" if args.edge_order == "dst" else "source"))
         n_src, n_dst, nnz = g.number_of_src_nodes(), g.number_of_dst_nodes(), g.number_of_edges()
         print("SPMM\n----------------------------")
         with torch.no_grad():
-            for n_hid in [int(h) for h in args.hidden.split(",")]:
+            for n_hid in ([] if args.no_spmm else [int(h) for h in args.hidden.split(",")]):
                 # every width measured on freshly placed operands: inside a sweep that reuses the allocator's cached blocks
                 # the proteins D = 128 launch took 6.4 ms against 2.07 ms on its own (same kernel, same sizes; only the
                 # placement of the 68 / 153 / 68 MB operands differs -- observed twice, not understood)

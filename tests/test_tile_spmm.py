@@ -150,3 +150,45 @@ def test_gspmm_takes_the_tile_kernel_on_dense_neighbourhoods(oracle, monkeypatch
     for width in (16, 32, 1, 2, 41, 4, 20):
         want = oracle.spmm(ip, ix, None, "copy_lhs", "sum", np.ascontiguousarray(x_np[:, :width]), None)
         assert rel(outs["1"][width].cpu().numpy(), want) < RTOL and rel(outs["0"][width].cpu().numpy(), want) < RTOL
+
+
+@pytest.mark.gpu
+def test_product_path_fuzz_over_graph_shapes_and_widths(oracle, monkeypatch):
+    """dgl.ops.gspmm(copy_lhs, sum | mean) forced onto the tile path (MGX_TILE=1) over 24 random graphs -- a handful of nodes to a
+    few thousand, sparse to dense, bipartite, with hub rows and hub sources, rows without in-edges, sources nobody gathers,
+    parallel edges -- and widths 1 .. 130 (every kernel geometry, the padded odd widths, two passes): equal to the CPU oracle."""
+    import mi355x_graph as mg
+    from mi355x_graph import ops
+    monkeypatch.setenv("MGX_TILE", "1")
+    rng = np.random.default_rng(2024)
+    widths = [1, 2, 3, 4, 8, 12, 16, 20, 24, 32, 36, 41, 48, 64, 100, 128, 130]
+    for trial in range(24):
+        n_src = int(rng.choice([3, 17, 64, 129, 700, 2500, 4000]))
+        n_dst = n_src if trial % 3 else int(rng.choice([5, 90, 1100]))
+        nnz = int(rng.choice([0, 1, 50, 3000, 40000, 250000])) if trial else 0
+        src = rng.integers(0, n_src, nnz)
+        dst = rng.integers(0, max(1, n_dst - n_dst // 4), nnz)  # the last quarter of the rows receives nothing
+        if trial % 4 == 1 and nnz:  # a hub row and a hub source beyond the split threshold
+            src = np.concatenate([src, rng.integers(0, n_src, 5000), np.full(3000, n_src - 1)])
+            dst = np.concatenate([dst, np.full(5000, 1 % n_dst), rng.integers(0, n_dst, 3000)])
+        src, dst = src.astype(np.int64), dst.astype(np.int64)
+        g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=torch.int32, device=DEV)
+        ip, ix, _ = oracle.coo_to_csr(n_dst, dst, src)
+        for D in rng.choice(widths, 4, replace=False):
+            D = int(D)
+            x_np = rng.random((n_src, D), dtype=np.float32)  # non-negative terms: the element-wise relative bound IS the row-scaled one
+            x = torch.from_numpy(x_np).to(DEV)
+            truth = np.zeros((n_dst, D))
+            np.add.at(truth, dst, x_np.astype(np.float64)[src])
+            deg = np.bincount(dst, minlength=n_dst).astype(np.float64).reshape(-1, 1)
+            for reduce in ("sum", "mean"):
+                got = ops.gspmm(g, "copy_lhs", reduce, x, None)
+                assert got.shape == (n_dst, D)
+                want = oracle.spmm(ip, ix, None, "copy_lhs", reduce, x_np, None)
+                # the truth (float64) within 1e-4; the fp32 oracle sums a row sequentially and is itself off by up to ~1e-8 per
+                # term of the row (1.25e-4 on the 20 k-term rows of trial 5, where both kernels are within 1.3e-5 of the truth:
+                # experiments/exp_tile_fuzz_case.py), so its bound grows with the longest row
+                assert rel(got.cpu().numpy(), truth / (np.maximum(deg, 1.0) if reduce == "mean" else 1.0)) < RTOL, (trial, D, reduce)
+                assert rel(got.cpu().numpy(), want) < RTOL + 1e-8 * float(deg.max()), (trial, n_src, n_dst, src.shape[0], D, reduce)
+        if src.shape[0]:
+            assert g._index.csc()._tile_plan, "the tile path was not taken"
