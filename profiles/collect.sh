@@ -15,7 +15,7 @@ python3 $R/experiments/epoch_timeline.py $O/${TAG}_bench_trace > $O/${TAG}_epoch
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_bench_fetch -- $BENCH --steps 3 --warmup 1 > $O/${TAG}_bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_bench_write -- $BENCH --steps 3 --warmup 1 > $O/${TAG}_bench_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/${TAG}_bench_l2 -- $BENCH --steps 3 --warmup 1 > $O/${TAG}_bench_l2.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_gat_trace -- python3 $R/dgl-0.5-benchmark_amd/full_graph.py --model gat --dataset reddit --heads 1 --num-layers 3 --num-hidden 16 --epochs 6 > $O/${TAG}_gat_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_gat_trace -- python3 $R/dgl-0.5-benchmark_amd/full_graph.py --model gat --dataset reddit --epochs 6 > $O/${TAG}_gat_trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_gat8_trace -- python3 $R/dgl-0.5-benchmark_amd/full_graph.py --model gat --dataset reddit-small --heads 8 --num-layers 2 --epochs 6 > $O/${TAG}_gat8_trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_molhiv_trace -- python3 $R/dgl-0.5-benchmark_amd/graph_classification.py --epochs 2 --num_graphs 8192 > $O/${TAG}_molhiv_trace.log 2>&1
 python3 $R/profiles/summarize.py $TAG $O/${TAG}_bench_trace $O/${TAG}_bench_fetch $O/${TAG}_bench_write $O/${TAG}_bench_l2 > $O/${TAG}_summarize.log 2>&1
