@@ -652,6 +652,8 @@ extern "C" int32_t mgx_gat_tile_fwd(const mgx_csr* csr, const mgx_spmm_plan* pla
   int32_t st = gat_check(csr, plan, H, F, csr ? csr->num_cols : 0, drop_p, "mgx_gat_tile_fwd");
   if (st != MGX_OK) return st;
   if (!gat_tile_shape_ok(tp, H, F)) MGX_UNSUPPORTED("mgx_gat_tile_fwd: one head of 4 .. 16 columns and a 4-lane tile plan with node ids");
+  MGX_CHECK_ARG(drop_p == 0.f || tp->lds_stream16, "mgx_gat_tile_fwd: attn_drop needs a tile plan with the (slot, rank) stream");
+  if (csr->num_cols >= (int64_t(1) << 24)) MGX_UNSUPPORTED("mgx_gat_tile_fwd: sources beyond 24 bits");
   if (csr->num_rows == 0 || tp->num_tiles == 0) return MGX_OK;
   MGX_CHECK_ARG(el && er && out && nstat && feat, "mgx_gat_tile_fwd: NULL pointer");
   MGX_CHECK_ARG((uintptr_t)feat % 16 == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)nstat % 16 == 0, "mgx_gat_tile_fwd: pointers must be 16-byte aligned");
@@ -695,6 +697,9 @@ extern "C" int32_t mgx_gat_tile_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc
   if (st != MGX_OK) return st;
   if (!gat_tile_shape_ok(csc_tp, H, F) || !gat_tile_shape_ok(csr_tp, H, F))
     MGX_UNSUPPORTED("mgx_gat_tile_bwd: one head of 4 .. 16 columns and 4-lane tile plans with node ids on both CSRs");
+  MGX_CHECK_ARG(drop_p == 0.f || (csc_tp->lds_stream16 && csr_tp->lds_stream16),
+                "mgx_gat_tile_bwd: attn_drop needs tile plans with the (slot, rank) stream");
+  if (csc->num_cols >= (int64_t(1) << 24) || csr->num_cols >= (int64_t(1) << 24)) MGX_UNSUPPORTED("mgx_gat_tile_bwd: nodes beyond 24 bits");
   MGX_CHECK_ARG(csc->num_rows == csr->num_cols && csc->num_cols == csr->num_rows && csc->nnz == csr->nnz,
                 "mgx_gat_tile_bwd: the two CSRs are not transposes of each other");
   if (csc->num_rows == 0 || csr->num_rows == 0) return MGX_OK;

@@ -9,6 +9,7 @@ constexpr int kNoItem = INT32_MIN;  // tile_item of a position without a work it
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 

@@ -97,9 +97,9 @@ class CsrView(object):
 
     def gat_tile_plan(self, F):
         """Tile plan for the fused GAT walks over this CSR (one head of 4 .. 16 columns, dense neighbourhoods: gat_tile.inc), else None.
-        Its own plan: 4 lanes per row with the node of every position; stats["parallel_edges"] says whether attn_drop may use it."""
+        Its own plan: 4 lanes per row with the node of every position and every entry's rank among parallel edges (attn_drop keys)."""
         from . import tileplan
-        if F % 4 != 0 or not 4 <= F <= 16 or os.environ.get("MGX_GAT_TILE", "0") != "1":  # opt-in: measured slower than the row walks (DESIGN 4.4e)
+        if F % 4 != 0 or not 4 <= F <= 16 or os.environ.get("MGX_GAT_TILE", "1") == "0" or self.num_cols >= (1 << 24):
             return None
         if self._tile_plan is False:
             self._tile_plan = {} if tileplan.tile_plan_wanted(self) else None
@@ -110,7 +110,7 @@ class CsrView(object):
             self.plan()
             nc, nacc, nl, tau = tileplan.gat_config()
             base = schedule.plan_for(self, split=tileplan.TILE_SPLIT)
-            held = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=2, check_parallel=True)
+            held = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=2, pair_rank=True)
             tileplan.validate(held, self)
             self._tile_plan["gat"] = held
         return self._tile_plan["gat"]
@@ -505,15 +505,15 @@ class HipBackend(object):
     @staticmethod
     def _gat_tile_plans(csc, csr, H, F, p):
         """(tile plan of the in-CSR, of the out-CSR | None) when a layer's walks run as tile kernels, else None.  With attn_drop the
-        two forms key the mask differently (edge id / endpoint pair), so a layer takes the tile form for ALL three walks or for
-        none: it needs both plans and a graph without parallel edges."""
+        two forms key the mask differently (edge id / (destination, source, rank among parallel edges)), so a layer takes the tile
+        form for ALL three walks or for none: it needs both plans with their rank streams."""
         if H != 1:
             return None
         t_dst = csc.gat_tile_plan(F)
         if t_dst is None:
             return None
         t_src = csr.gat_tile_plan(F) if csr is not None else None
-        if p > 0.0 and (t_src is None or t_dst.stats["parallel_edges"] or t_src.stats["parallel_edges"]):
+        if p > 0.0 and (t_src is None or not t_dst.stats["pair_rank_streams"] or not t_src.stats["pair_rank_streams"]):
             return None
         return t_dst, t_src
 

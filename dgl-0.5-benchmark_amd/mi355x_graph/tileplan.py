@@ -58,6 +58,7 @@ class MgxTilePlan(ctypes.Structure):
         ("zero_row", ctypes.c_void_p),
         ("tile_order", ctypes.c_void_p),
         ("tile_node", ctypes.c_void_p),
+        ("lds_stream16", ctypes.c_void_p),
     ]
 
 
@@ -93,7 +94,8 @@ class TilePlan(object):
                                   p(self.lds_cnt), p(self.lds_stream), p(self.dir_off), p(self.dir_cnt), p(self.dir_stream),
                                   p(self.tile_item), p(self.zero_row),
                                   p(self.tile_order) if getattr(self, "tile_order", None) is not None else None,
-                                  p(self.tile_node) if getattr(self, "tile_node", None) is not None else None)
+                                  p(self.tile_node) if getattr(self, "tile_node", None) is not None else None,
+                                  p(self.lds_stream16) if getattr(self, "lds_stream16", None) is not None else None)
         return self._c
 
 
@@ -147,10 +149,14 @@ def _longest_first(tile_edges, T, xcds=8):
     return torch.sort(key, stable=True)[1].to(torch.int32)
 
 
-def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, check_parallel=False):
+def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, pair_rank=False):
     """csr: CsrView (int32, device or host); base: SpmmPlan over it (items in schedule order; None = natural rows).
-    check_parallel: also find out whether the graph has parallel edges (stats["parallel_edges"]) -- the fused GAT walks over a
-    tile plan key the attn_drop mask by (destination, source) and are taken with attn_drop > 0 only when that is a key per edge."""
+    pair_rank (the plans of the fused GAT walks, gat_tile.inc): every entry also carries the RANK k of its edge among the parallel
+    edges of its (row, source) pair, in edge-id order -- (destination, source, k) is then a key per edge that both CSRs of a graph
+    agree on, which is what the walks key attn_drop by.  Staged entries: a second stream of 16-bit entries, slot | k << 8
+    (`lds_stream16`); direct entries: k in bits 24-30 of the source id.  k is kept mod 128: a pair with MORE than 128 parallel
+    edges (the heavy-tailed stand-ins have hub pairs with thousands; the datasets have none) re-uses keys, i.e. its edges with
+    equal k mod 128 share a mask bit -- both CSRs still see the same multiset of bits per pair, so the three walks stay consistent."""
     dev = csr.indptr.device
     NC, NACC = int(consumers), int(nacc)
     if NC + int(loaders) not in TILE_WAVES or not 1 <= NACC <= CNT_STRIDE or int(loaders) not in (1, 2, 4):
@@ -209,12 +215,20 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     e_item = torch.repeat_interleave(torch.arange(I, device=dev), lens)
     first = _excl_cumsum(lens)[:-1]
     e_src = csr.indices[beg[e_item] + (torch.arange(E, device=dev) - first[e_item])].long()
-    parallel = None
-    if check_parallel:  # two edges with the same (row, source): equal neighbours in the sorted pair keys
+    e_rank = None
+    if pair_rank:  # rank of every edge among the edges of its (row, source) pair, by edge id
         node = (base.item_node if base is not None and base.item_node is not None else item_row).long()
-        pk = torch.sort(node[e_item] * n_src + e_src)[0]
-        parallel = bool((pk[1:] == pk[:-1]).any()) if E > 1 else False
-        del pk, node
+        e_csr = beg[e_item] + (torch.arange(E, device=dev) - first[e_item])
+        eid = csr.eids[e_csr].long() if getattr(csr, "eids", None) is not None else e_csr
+        o1 = torch.sort(eid)[1]
+        pk, o2 = torch.sort((node[e_item] * n_src + e_src)[o1], stable=True)
+        order = o1[o2]
+        start = torch.ones(E, dtype=torch.bool, device=dev)
+        start[1:] = pk[1:] != pk[:-1]
+        run0 = torch.cummax(torch.where(start, torch.arange(E, device=dev), torch.zeros(E, dtype=torch.int64, device=dev)), 0)[0]
+        e_rank = torch.empty(E, dtype=torch.int64, device=dev)
+        e_rank[order] = torch.arange(E, device=dev) - run0
+        del pk, o1, o2, order, start, run0, node, eid, e_csr
     e_tile, e_pos = it_tile[e_item], pos[e_item]
     del e_item, first
     # ---- sources gathered >= tau times inside a tile are staged; per tile they are ordered by multiplicity (dense chunks first)
@@ -259,10 +273,17 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     lds_cnt, lds_base, lds_total, lds_bytes = _streams(sk, nseg, e_slot[staged], ZERO_SLOT, torch.uint8, seg_order, GROUPS)
     lds_off = _excl_cumsum(torch.bincount(seg_unit, weights=lds_cnt.double(), minlength=T * NC).long()) if NCH else \
         torch.zeros(T * NC + 1, dtype=torch.int64, device=dev)
+    lds16 = None
+    max_rank = int(e_rank.max()) if e_rank is not None and E else 0
+    if e_rank is not None:  # the same stream with 16-bit entries: slot | (rank mod 128) << 8
+        lds16 = _streams(sk, nseg, e_slot[staged] + ((e_rank[staged] & 127) << 8), ZERO_SLOT, torch.int16, seg_order, GROUPS)[3]
     # ---- direct streams: one per (tile, consumer wave)
     direct = ~staged
     dk = e_tile[direct] * per_unit + e_pos[direct]
-    dir_cnt, dir_base, dir_total, dir_stream = _streams(dk, T * NC * NACC, e_src[direct], -1, torch.int32, None, GROUPS)
+    dir_payload = e_src[direct]
+    if e_rank is not None and n_src < (1 << 24):
+        dir_payload = dir_payload | ((e_rank[direct] & 127) << 24)
+    dir_cnt, dir_base, dir_total, dir_stream = _streams(dk, T * NC * NACC, dir_payload, -1, torch.int32, None, GROUPS)
     dir_off = torch.cat([dir_base.view(-1)[::NACC], torch.tensor([dir_total], device=dev)])
     if int(lds_cnt.max() if lds_cnt.numel() else 0) > 65535:
         raise ValueError("tile plan: more than 65535 supersteps in one (chunk, row)")
@@ -280,7 +301,9 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
              "gathered_rows_per_edge": (int(sel.shape[0]) + E - n_staged) / max(E, 1),
              "lds_slot_fill": n_staged / max(int(lds_bytes.shape[0]) - STREAM_TAIL * GROUPS * 4, 1),
              "dir_slot_fill": (E - n_staged) / max(int(dir_stream.shape[0]) - STREAM_TAIL * GROUPS * 4, 1),
-             "parallel_edges": parallel}
+             "parallel_edges": None if e_rank is None else max_rank > 0,
+             "max_pair_rank": None if e_rank is None else max_rank,
+             "pair_rank_streams": lds16 is not None and n_src < (1 << 24)}
     tables = {
         "tile_chunk_ptr": tile_chunk_ptr.to(torch.int32),
         "chunk_ids": chunk_ids,
@@ -293,6 +316,7 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         "tile_item": tile_item.to(torch.int32),        # [T * R] item_row of the item at every position, NO_ITEM = none
         "zero_row": torch.zeros(64, dtype=torch.float32, device=dev),
         "tile_node": tile_node,
+        "lds_stream16": None if lds16 is None else lds16.view(torch.int32),  # [lds_supersteps * groups * 2] words: 4 x (slot | rank << 8)
         "tile_order": _longest_first(torch.bincount(e_tile, minlength=T), T) if os.environ.get("MGX_TILE_LPT", "0") == "1" else None,
     }
     if lds_total * 4 >= 2 ** 31 or dir_total * 16 >= 2 ** 31:
@@ -363,7 +387,10 @@ def validate(plan, csr):
         b = plan.lds_stream.view(torch.uint8)
         ok(int(b.max()) <= ZERO_SLOT, "lds slots")
     if plan.dir_stream.numel():
-        ok(int(plan.dir_stream.min()) >= -1 and int(plan.dir_stream.max()) < csr.num_cols, "direct ids")
+        ids = plan.dir_stream
+        if plan.stats.get("pair_rank_streams"):  # bits 24-30: the edge's rank among parallel edges (gat_tile.inc masks them off)
+            ids = torch.where(ids >= 0, ids & 0xFFFFFF, ids)
+        ok(int(ids.min()) >= -1 and int(ids.max()) < csr.num_cols, "direct ids")
     ti = plan.tile_item.long()
     live = ti[ti != NO_ITEM]
     ok(ti.shape[0] == T * R and (live.numel() == 0 or (int(live.max()) < csr.num_rows and int(live.min()) >= -num_slots)), "tile_item")
@@ -388,6 +415,8 @@ def emulate(plan, x, out_rows, num_slots=0):
     lds_stream = plan.lds_stream.cpu().numpy().view(np.uint8).reshape(-1, GROUPS, 4)  # [superstep][group][step]
     dir_off, dir_cnt = plan.dir_off.cpu().numpy(), plan.dir_cnt.cpu().numpy().reshape(-1, CNT_STRIDE)
     dir_stream = plan.dir_stream.cpu().numpy().reshape(-1, GROUPS, 4)
+    if plan.stats.get("pair_rank_streams"):
+        dir_stream = np.where(dir_stream >= 0, dir_stream & 0xFFFFFF, dir_stream)
     tile_item = plan.tile_item.cpu().numpy()
     out = np.zeros((out_rows, D))
     partial = np.zeros((max(num_slots, 1), D))

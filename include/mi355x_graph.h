@@ -212,6 +212,9 @@ typedef struct mgx_tile_plan {
   const float* zero_row;
   const int32_t* tile_order; /* optional [num_tiles]: dispatch slot -> tile; slots [x * ceil(T/8), ...) run on XCD x in order */
   const int32_t* tile_node; /* optional [num_tiles*R]: the NODE of the item at every position (hub chunks: their row); mgx_gat_tile_* */
+  const uint32_t* lds_stream16; /* optional, mgx_gat_tile_* with drop_p > 0: lds_stream with 16-bit entries, slot | rank << 8, rank = the
+                                   edge's rank among the parallel edges of its (row, source) pair by edge id, mod 128; such a plan's
+                                   dir_stream carries the rank in bits 24-30 of every source id (sources < 2^24) */
 } mgx_tile_plan;
 int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, const mgx_tile_plan* tile_plan,
                              int32_t reduce, const float* ufeat, int64_t D, int64_t u_stride, const float* dst_scale /* may be NULL */,
@@ -308,9 +311,9 @@ int32_t mgx_gat_fused_bwd(const mgx_csr* csc, const mgx_spmm_plan* csc_plan /* m
  * neighbourhoods (main_dgl_reddit_gat.py on reddit).  `tile_plan`: 4 lanes per row (lanes_log2 = 2), 7 + 1 waves, nacc 3 or 4, with
  * tile_node; `plan`: the tile plan's base plan (its hub tables; workspace = mgx_gat_fused_workspace(plan, 1, F)).  Same arguments,
  * results and statistics as mgx_gat_fused_fwd / _bwd, another fp32 summation order (deterministic for a given plan).  attn_drop:
- * the mask bit of an edge is a function of (seed, destination, source) here -- of (seed, edge id) in the row kernels --, so (i) use
- * the tile form for all three walks of a layer or for none when drop_p > 0, and (ii) parallel edges would share a bit: the caller
- * takes this form with drop_p > 0 only on graphs without parallel edges.  Other shapes: MGX_ERR_UNSUPPORTED. */
+ * the mask bit of an edge is a function of (seed, destination, source, rank among parallel edges) here -- of (seed, edge id) in
+ * the row kernels --: use the tile form for all three walks of a layer or for none when drop_p > 0; it needs lds_stream16 in both
+ * plans.  Sources below 2^24 (the direct stream's ids are masked to 24 bits).  Other shapes: MGX_ERR_UNSUPPORTED. */
 int32_t mgx_gat_tile_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, const mgx_tile_plan* tile_plan, int64_t H, int64_t F,
                          const float* feat, const float* el, const float* er, float negative_slope, float drop_p, uint64_t seed,
                          float* out, float* nstat, void* workspace, void* pack_ws, void* stream);

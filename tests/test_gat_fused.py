@@ -223,34 +223,46 @@ def test_one_head_widening_layer_aggregates_first(k, f, residual, monkeypatch):
     assert widths == [k]
 
 
-def pair_keep(seed, dst, src, p):
-    """The tile walks' attn_drop mask (csrc/gatfused.hip: gat_hash(seed, src, dst)): a 32-bit multiply-xorshift mixer, kept when
-    the hash is >= p * 2^32; restated in int64 arithmetic masked to 32 bits."""
+def pair_keep(seed, dst, src, rank, p):
+    """The tile walks' attn_drop mask (csrc/gatfused.hip gat_hash, csrc/gat_tile.inc gat_pair_keep): a 32-bit multiply-xorshift
+    mixer of (seed, source, destination + rank * 0x9E3779B1), kept when the hash is >= p * 2^32; in int64 arithmetic masked to 32 bits."""
     M = 0xFFFFFFFF
     x = (src ^ (seed & M)) & M
     x = x ^ (x >> 16)
     x = (x * 0x7feb352d) & M
     x = x ^ (x >> 15)
-    x = x ^ ((dst + ((seed >> 32) & M)) & M)
+    x = x ^ ((dst + rank * 0x9E3779B1 + ((seed >> 32) & M)) & M)
     x = (x * 0x846ca68b) & M
     x = x ^ (x >> 16)
     return x >= min(int(p * 4294967296.0), 4294967295)
+
+
+def rank_among_parallel_edges(src, dst, n):
+    """rank[e] = how many edges with a smaller id join the same (source, destination) pair."""
+    key = dst * n + src
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    first = np.concatenate([[True], ks[1:] != ks[:-1]])
+    run0 = np.maximum.accumulate(np.where(first, np.arange(ks.shape[0]), 0))
+    rank = np.empty_like(key)
+    rank[order] = np.arange(ks.shape[0]) - run0
+    return rank
 
 
 @pytest.mark.parametrize("Fd,p", [(16, 0.0), (16, 0.3), (8, 0.0), (4, 0.25), (12, 0.4)])
 def test_tile_walks_match_the_row_kernels(Fd, p, monkeypatch):
     """One head of up to 16 columns on a graph with dense neighbourhoods (main_dgl_reddit_gat.py on reddit): the three walks run
     as LDS-staged tile kernels (csrc/gat_tile.inc) -- same outputs and gradients (1e-4 relative) as the row kernels at p = 0, and
-    with attn_drop as the unfused operators with the tile walks' mask (one bit per (seed, destination, source)) applied to the
-    attention; hub rows split by the tile plan included."""
+    with attn_drop as the unfused operators with the tile walks' mask (one bit per (seed, destination, source, rank among parallel
+    edges)) applied to the attention.  A MULTIGRAPH (up to ~10 parallel edges per pair) with hub rows split by the plan on both sides."""
     n = 2500
     src, dst = random_graph(n, n, 600000, seed=31)
     rng = np.random.default_rng(5)
     hub_in, hub_out = rng.integers(0, n, 21000), rng.integers(0, n, 9000)   # > 2,048 edges: split work items on both sides
     src = np.concatenate([src, hub_in, np.full(9000, 17)]).astype(np.int64)
     dst = np.concatenate([dst, np.full(21000, 23), hub_out]).astype(np.int64)
-    pairs = np.unique(dst * n + src)                                        # attn_drop on a tile plan: no parallel edges
-    src, dst = pairs % n, pairs // n
+    rank = rank_among_parallel_edges(src, dst, n)
+    assert 2 <= rank.max() < 128
     feat0 = torch.randn(n, 1, Fd, device=DEV)
     el0, er0 = torch.randn(n, 1, 1, device=DEV), torch.randn(n, 1, 1, device=DEV)
     w = torch.randn(n, 1, Fd, device=DEV)
@@ -265,14 +277,15 @@ def test_tile_walks_match_the_row_kernels(Fd, p, monkeypatch):
         if mode == "1" or p == 0.0:
             out = ops.gat_fused(g, feat, el, er, 0.2, p, True)
         else:  # the reference under attn_drop: unfused operators, the mask applied to the attention
-            keep = pair_keep(7, T(dst), T(src), p).float().view(-1, 1, 1) / (1.0 - p)
+            keep = pair_keep(7, T(dst), T(src), T(rank), p).float().view(-1, 1, 1) / (1.0 - p)
             out = ops.gspmm(g, "mul", "sum", feat, unfused_attention(g, el, er, 0.2) * keep)
         held = g._index.csc()._tile_plan
         assert (isinstance(held, dict) and "gat" in held) == (mode == "1"), "the tile walk was %staken" % ("not " if mode == "1" else "")
         (out * w).sum().backward()
         res[mode] = [out.detach(), feat.grad, el.grad, er.grad]
         if mode == "1":
-            assert held["gat"].stats["parallel_edges"] is False and held["gat"].base.num_slots > 0
+            st = held["gat"].stats
+            assert st["parallel_edges"] is True and st["max_pair_rank"] == int(rank.max()) and held["gat"].base.num_slots > 0
             ops.GATFused._calls = 0
             again = ops.gat_fused(g, feat0, el0, er0, 0.2, p, True)
             assert torch.equal(again, out.detach())  # no atomics: bitwise reruns
@@ -280,23 +293,38 @@ def test_tile_walks_match_the_row_kernels(Fd, p, monkeypatch):
         assert float((a_ - b_).abs().max()) < RTOL * float(b_.abs().max()) + 1e-6, (name, float((a_ - b_).abs().max()), float(b_.abs().max()))
 
 
-def test_tile_walks_leave_attn_drop_on_a_multigraph_to_the_row_kernels(monkeypatch):
-    """Parallel edges would share a mask bit in the tile walks (keyed by endpoint pair): with attn_drop > 0 such a graph keeps the
-    row kernels (edge-id keys) for all three walks; without dropout it takes the tile walks."""
+def test_tile_walks_with_more_than_128_parallel_edges_on_a_pair(monkeypatch):
+    """The rank field of a tile plan's entries is 7 bits: a pair with 200 parallel edges re-uses mask keys (rank mod 128).  Both
+    CSRs see the same multiset of bits for the pair, so forward and backward stay consistent: the same numbers as the unfused
+    operators with that mask, at 1e-4."""
     n = 2000
-    src, dst = random_graph(n, n, 500000, seed=37)  # sampled with replacement: a few thousand repeated pairs
-    assert np.unique(dst * n + src).shape[0] < src.shape[0]
+    src, dst = random_graph(n, n, 500000, seed=37)
+    src = np.concatenate([src, np.full(200, 3)]).astype(np.int64)   # 200 parallel edges 3 -> 5
+    dst = np.concatenate([dst, np.full(200, 5)]).astype(np.int64)
+    rank = rank_among_parallel_edges(src, dst, n)
+    assert rank.max() >= 199
     monkeypatch.setenv("MGX_TILE", "1")
     monkeypatch.setenv("MGX_GAT_TILE", "1")
     g = mk(n, n, src, dst)
-    feat = torch.randn(n, 1, 16, device=DEV, requires_grad=True)
+    p = 0.35
     el, er = torch.randn(n, 1, 1, device=DEV), torch.randn(n, 1, 1, device=DEV)
-    be = __import__("mi355x_graph").sparse.backend_for(feat)
-    csc, csr = g._index.csc(), g._index.csr()
-    assert be._gat_tile_plans(csc, csr, 1, 16, 0.0) is not None and csc.gat_tile_plan(16).stats["parallel_edges"] is True
-    assert be._gat_tile_plans(csc, csr, 1, 16, 0.3) is None
-    ops.gat_fused(g, feat, el, er, 0.2, 0.3, True).sum().backward()  # row kernels: runs, finite
-    assert bool(torch.isfinite(feat.grad).all())
+    w = torch.randn(n, 1, 16, device=DEV)
+    res = []
+    for tile in (True, False):
+        feat = torch.randn(n, 1, 16, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3)).requires_grad_(True)
+        elg, erg = el.clone().requires_grad_(True), er.clone().requires_grad_(True)
+        torch.manual_seed(11)
+        ops.GATFused._calls = 0
+        if tile:
+            out = ops.gat_fused(g, feat, elg, erg, 0.2, p, True)
+            assert g._index.csc()._tile_plan["gat"].stats["max_pair_rank"] >= 199
+        else:
+            keep = pair_keep(11, T(dst), T(src), T(rank % 128), p).float().view(-1, 1, 1) / (1.0 - p)
+            out = ops.gspmm(g, "mul", "sum", feat, unfused_attention(g, elg, erg, 0.2) * keep)
+        (out * w).sum().backward()
+        res.append([out.detach(), feat.grad, elg.grad, erg.grad])
+    for name, a_, b_ in zip(("out", "d_feat", "d_el", "d_er"), *res):
+        assert float((a_ - b_).abs().max()) < RTOL * float(b_.abs().max()) + 1e-6, (name, float((a_ - b_).abs().max()), float(b_.abs().max()))
 
 
 def test_fused_rejects_mismatched_rows():
