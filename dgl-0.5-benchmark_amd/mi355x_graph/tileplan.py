@@ -223,12 +223,11 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         o1 = torch.sort(eid)[1]
         pk, o2 = torch.sort((node[e_item] * n_src + e_src)[o1], stable=True)
         order = o1[o2]
-        start = torch.ones(E, dtype=torch.bool, device=dev)
-        start[1:] = pk[1:] != pk[:-1]
-        run0 = torch.cummax(torch.where(start, torch.arange(E, device=dev), torch.zeros(E, dtype=torch.int64, device=dev)), 0)[0]
+        runs = torch.unique_consecutive(pk, return_counts=True)[1]  # (torch.cummax over 115 M elements takes 0.36 s on this stack)
+        run0 = torch.repeat_interleave(_excl_cumsum(runs)[:-1], runs)
         e_rank = torch.empty(E, dtype=torch.int64, device=dev)
         e_rank[order] = torch.arange(E, device=dev) - run0
-        del pk, o1, o2, order, start, run0, node, eid, e_csr
+        del pk, o1, o2, order, runs, run0, node, eid, e_csr
     e_tile, e_pos = it_tile[e_item], pos[e_item]
     del e_item, first
     # ---- sources gathered >= tau times inside a tile are staged; per tile they are ordered by multiplicity (dense chunks first)
