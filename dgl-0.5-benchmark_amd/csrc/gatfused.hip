@@ -46,6 +46,25 @@ __device__ __forceinline__ uint32_t gat_hash(uint64_t seed, uint32_t klo, uint32
   return x;
 }
 
+// Sum over the LPH lanes of a head (LPH a power of two, the lanes aligned to LPH): the xor butterfly of __shfl_xor, with its first
+// four steps as DPP moves instead of ds_bpermute -- swap neighbours, swap pairs (quad_perm), then mirror a half row and a row
+// (every lane of a quad / half row already holds the same partial sum, so the mirrored partner's value IS the xor partner's).
+// Bitwise the same sums; no LDS-pipe instruction for heads of up to 16 lanes.
+template <int CTRL>
+__device__ __forceinline__ float gat_dpp(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+template <int LPH>
+__device__ __forceinline__ float head_sum(float x) {
+  if (LPH >= 2) x += gat_dpp<0xB1>(x);    // quad_perm [1, 0, 3, 2]
+  if (LPH >= 4) x += gat_dpp<0x4E>(x);    // quad_perm [2, 3, 0, 1]
+  if (LPH >= 8) x += gat_dpp<0x141>(x);   // row_half_mirror
+  if (LPH >= 16) x += gat_dpp<0x140>(x);  // row_mirror
+#pragma unroll
+  for (int off = 16; off < LPH; off <<= 1) x += __shfl_xor(x, off, kWave);
+  return x;
+}
+
 struct GatArgs {
   const int32_t* indptr;
   const int32_t* indices;
@@ -180,10 +199,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
   v4f al = (v4f)(0.f);
   if (ELK && fact) al = *reinterpret_cast<const v4f*>(a.attn + f);  // attn_l[head, (l % LPH) * 4 ..]: flat index = this lane's column
   auto head_dot = [&](const v4f& v) -> float {  // <row[h,:], attn_l[h,:]> over the LPH lanes of this lane's head
-    float e = v.x * al.x + v.y * al.y + v.z * al.z + v.w * al.w;
-#pragma unroll
-    for (int off = 1; off < LPH; off <<= 1) e += __shfl_xor(e, off, kWave);
-    return e;
+    return head_sum<LPH>(v.x * al.x + v.y * al.y + v.z * al.z + v.w * al.w);
   };
   const uint32_t hbytes = (uint32_t)a.small_ld * 4u;  // per-node stride of the small per-head array (el: H floats, nstat: 4H; packed: the row stride)
   const uint32_t h4 = (uint32_t)head * (MODE == GAT_BWD_SRC ? 16u : 4u);
@@ -225,9 +241,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
         ra = clip((v4f)*reinterpret_cast<const V4*>(a.rowa + row * D + fw));  // d out[v]
         ov = (v4f)*reinterpret_cast<const V4*>(a.rowb + row * D + fw);        // out[v]
       }
-      float t = ra.x * ov.x + ra.y * ov.y + ra.z * ov.z + ra.w * ov.w;  // idle lanes take part with zeros
-#pragma unroll
-      for (int off = 1; off < LPH; off <<= 1) t += __shfl_xor(t, off, kWave);
+      const float t = head_sum<LPH>(ra.x * ov.x + ra.y * ov.y + ra.z * ov.z + ra.w * ov.w);  // idle lanes take part with zeros
       c_t = t;
       // every chunk of a hub row writes the same value
       if (fact && (l % LPH) == 0 && sub == 0) a.nstat_w[(row * H + head) * 4 + 3] = t;
@@ -290,9 +304,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
             const float tt = MODE == GAT_BWD_DST ? c_t : sm[u].w;
             const float z = t > 0.f ? t : t * a.slope;
             const float av = __expf(z - mm) * is;
-            float dot = val[u].x * ra.x + val[u].y * ra.y + val[u].z * ra.z + val[u].w * ra.w;
-#pragma unroll
-            for (int off = 1; off < LPH; off <<= 1) dot += __shfl_xor(dot, off, kWave);
+            const float dot = head_sum<LPH>(val[u].x * ra.x + val[u].y * ra.y + val[u].z * ra.z + val[u].w * ra.w);
             float de = av * (dot * keep - tt) * (t > 0.f ? 1.f : a.slope);
             de = live ? de : 0.f;
             hacc += de;
