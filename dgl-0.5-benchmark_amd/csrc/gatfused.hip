@@ -176,6 +176,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
   constexpr int NB = kWave / G;
   constexpr int U = GatUnroll<G>::value;
   constexpr int STEP = NB * U;
+  constexpr bool QUAD = LPH == 4 && U == 4 && !RAGGED && G >= 4;  // e.g. the 8 x 16 and 4 x 16 layers (reddit-small config, arxiv)
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int sub = lane / G, l = lane % G;
@@ -266,6 +267,71 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
       }
       const int cnt = (end - cbase) < kWave ? (end - cbase) : kWave;
       for (int k = 0; k < cnt; k += STEP) {
+        if (QUAD) {
+          // Heads of four lanes with four edges in flight per lane group: the head's lanes are one DPP quad, and lane q does the
+          // SCALAR work of edge q alone -- its logit, its exp, its mask bit, the gather of its record -- instead of every lane
+          // doing all four; maxima / sums travel by quad_perm swaps, the four weights by quad_perm broadcasts into fused
+          // multiply-adds (as gat_tile.inc).
+          const int qv = l & 3;
+          v4f val[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int jdx = k + u * NB + sub;
+            const int bi = (jdx < cnt ? jdx : 0) * 4;
+            val[u] = (v4f)*reinterpret_cast<const V4*>(gatb + (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)goff) + f4);
+          }
+          const int jown = k + qv * NB + sub;
+          const bool live = jown < cnt;
+          const int bown = (live ? jown : 0) * 4;
+          v4f smo = (v4f)(0.f);
+          if (MODE == GAT_BWD_SRC) smo = *reinterpret_cast<const v4f*>(smallb + (uint32_t)__builtin_amdgcn_ds_bpermute(bown, (int)soff) + h4);
+          else if (!ELK) smo.x = *reinterpret_cast<const float*>(smallb + (uint32_t)__builtin_amdgcn_ds_bpermute(bown, (int)soff) + h4);
+          float keep = 1.f;
+          if (DROP) keep = gat_hash(a.seed, (uint32_t)__builtin_amdgcn_ds_bpermute(bown, eid), (uint32_t)head) >= a.drop_below ? a.keep_scale : 0.f;
+          if (ELK && MODE != GAT_BWD_SRC) {
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e[u] = head_dot(val[u]);
+            smo.x = qv == 0 ? e[0] : (qv == 1 ? e[1] : (qv == 2 ? e[2] : e[3]));
+          }
+          const float t = MODE == GAT_BWD_SRC ? c_el + smo.x : smo.x + c_er;
+          const float z = t > 0.f ? t : t * a.slope;
+          if (MODE == GAT_FWD) {
+            float m4 = live ? z : -INFINITY;
+            m4 = fmaxf(m4, gat_dpp<0xB1>(m4));
+            m4 = fmaxf(m4, gat_dpp<0x4E>(m4));
+            const float mn = fmaxf(run_m, m4);
+            const float rescale = run_m > -INFINITY ? __expf(run_m - mn) : 0.f;
+            const float pe = live ? __expf(z - mn) : 0.f;
+            const float pw = pe * keep;
+            v4f pa = val[0] * gat_dpp<0x00>(pw);
+            pa = __builtin_elementwise_fma(val[1], (v4f)(gat_dpp<0x55>(pw)), pa);
+            pa = __builtin_elementwise_fma(val[2], (v4f)(gat_dpp<0xAA>(pw)), pa);
+            pa = __builtin_elementwise_fma(val[3], (v4f)(gat_dpp<0xFF>(pw)), pa);
+            run_s = __builtin_fmaf(run_s, rescale, head_sum<4>(pe));
+            acc = __builtin_elementwise_fma(acc, (v4f)(rescale), pa);
+            run_m = mn;
+          } else {
+            const float mm = MODE == GAT_BWD_DST ? c_m : smo.y;
+            const float is = MODE == GAT_BWD_DST ? c_is : smo.z;
+            const float tt = MODE == GAT_BWD_DST ? c_t : smo.w;
+            const float av = live ? __expf(z - mm) * is : 0.f;
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              d[u] = head_sum<4>(__builtin_fmaf(val[u].w, ra.w, __builtin_fmaf(val[u].z, ra.z, __builtin_fmaf(val[u].y, ra.y, val[u].x * ra.x))));
+            const float dot = qv == 0 ? d[0] : (qv == 1 ? d[1] : (qv == 2 ? d[2] : d[3]));
+            hacc += av * (dot * keep - tt) * (t > 0.f ? 1.f : a.slope);  // this lane's edge only: summed over the quad below
+            if (MODE == GAT_BWD_SRC) {
+              const float w = av * keep;
+              acc = __builtin_elementwise_fma(val[0], (v4f)(gat_dpp<0x00>(w)), acc);
+              acc = __builtin_elementwise_fma(val[1], (v4f)(gat_dpp<0x55>(w)), acc);
+              acc = __builtin_elementwise_fma(val[2], (v4f)(gat_dpp<0xAA>(w)), acc);
+              acc = __builtin_elementwise_fma(val[3], (v4f)(gat_dpp<0xFF>(w)), acc);
+            }
+          }
+          continue;
+        }
         v4f val[U];
         v4f sm[U];
         int32_t ee[U];
@@ -349,6 +415,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
       for (int off = G; off < kWave; off <<= 1) acc += vec_shfl_xor<4>(acc, off);
     }
     if (MODE != GAT_FWD) {
+      if (QUAD) hacc = head_sum<4>(hacc);  // every lane of the head accumulated its own edges' terms
 #pragma unroll
       for (int off = G; off < kWave; off <<= 1) hacc += __shfl_xor(hacc, off, kWave);
     }
