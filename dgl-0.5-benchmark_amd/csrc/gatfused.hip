@@ -176,7 +176,8 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
   constexpr int NB = kWave / G;
   constexpr int U = GatUnroll<G>::value;
   constexpr int STEP = NB * U;
-  constexpr bool QUAD = LPH == 4 && U == 4 && !RAGGED && G >= 4;  // e.g. the 8 x 16 and 4 x 16 layers (reddit-small config, arxiv)
+  // heads of >= 4 lanes, four edges per batch: 8 x 16, 4 x 16, 4 x 64, the 41-column layer (whose destination walk measured slower this way)
+  constexpr bool QUAD = LPH >= 4 && U == 4 && (LPH == 4 || MODE != GAT_BWD_DST);
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int sub = lane / G, l = lane % G;
@@ -228,13 +229,15 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
     // ---- row constants
     v4f ra = (v4f)(0.f);
     float c_er = 0.f, c_m = 0.f, c_is = 0.f, c_t = 0.f, c_el = 0.f;
+    // (QUAD: an idle feature lane of a ragged row shares its quad with active lanes and does the scalar work of one of the quad's
+    // four edges, so it needs the row's constants too -- head 0's, a valid address)
     if (MODE == GAT_BWD_DST) {
-      if (fact) {
+      if (fact || QUAD) {
         const v4f st = *reinterpret_cast<const v4f*>(a.nstat + (row * H + head) * 4);
         c_er = st.x; c_m = st.y; c_is = st.z;
       }
     }
-    if (MODE == GAT_FWD && fact) c_er = a.er[row * H + head];
+    if (MODE == GAT_FWD && (fact || QUAD)) c_er = a.er[row * H + head];
     float run_m = -INFINITY, run_s = 0.f;  // FWD: online softmax state of this lane's head (per lane group)
     if (MODE == GAT_BWD_DST) {
       v4f ov = (v4f)(0.f);
@@ -247,10 +250,8 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
       // every chunk of a hub row writes the same value
       if (fact && (l % LPH) == 0 && sub == 0) a.nstat_w[(row * H + head) * 4 + 3] = t;
     }
-    if (MODE == GAT_BWD_SRC && fact) {
-      ra = clip((v4f)*reinterpret_cast<const V4*>(a.rowa + row * D + fw));  // feat[u]
-      if (!ELK) c_el = a.el[row * H + head];
-    }
+    if (MODE == GAT_BWD_SRC && fact) ra = clip((v4f)*reinterpret_cast<const V4*>(a.rowa + row * D + fw));  // feat[u]
+    if (MODE == GAT_BWD_SRC && !ELK && (fact || QUAD)) c_el = a.el[row * H + head];
     if (MODE == GAT_BWD_SRC && ELK) c_el = head_dot(ra);  // every lane takes part in the swaps (idle lanes hold zeros)
     v4f acc = (v4f)(0.f);
     float hacc = 0.f;  // d er (BWD_DST) / d el (BWD_SRC) of this lane's head
@@ -268,10 +269,10 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
       const int cnt = (end - cbase) < kWave ? (end - cbase) : kWave;
       for (int k = 0; k < cnt; k += STEP) {
         if (QUAD) {
-          // Heads of four lanes with four edges in flight per lane group: the head's lanes are one DPP quad, and lane q does the
-          // SCALAR work of edge q alone -- its logit, its exp, its mask bit, the gather of its record -- instead of every lane
-          // doing all four; maxima / sums travel by quad_perm swaps, the four weights by quad_perm broadcasts into fused
-          // multiply-adds (as gat_tile.inc).
+          // Heads of four or more lanes with four edges in flight per lane group: lane q of every DPP quad does the SCALAR work of
+          // edge q alone -- its logit, its exp, its mask bit, the gather of its record -- instead of every lane doing all four
+          // (the quads of a wider head each do the same four); maxima / sums travel by quad_perm swaps, the four weights by
+          // quad_perm broadcasts into fused multiply-adds (as gat_tile.inc).
           const int qv = l & 3;
           v4f val[4];
 #pragma unroll
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void gat_fused_kernel(const GatArgs a) {
             float d[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              d[u] = head_sum<4>(__builtin_fmaf(val[u].w, ra.w, __builtin_fmaf(val[u].z, ra.z, __builtin_fmaf(val[u].y, ra.y, val[u].x * ra.x))));
+              d[u] = head_sum<LPH>(__builtin_fmaf(val[u].w, ra.w, __builtin_fmaf(val[u].z, ra.z, __builtin_fmaf(val[u].y, ra.y, val[u].x * ra.x))));
             const float dot = qv == 0 ? d[0] : (qv == 1 ? d[1] : (qv == 2 ? d[2] : d[3]));
             hacc += av * (dot * keep - tt) * (t > 0.f ? 1.f : a.slope);  // this lane's edge only: summed over the quad below
             if (MODE == GAT_BWD_SRC) {

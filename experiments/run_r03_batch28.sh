@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 export TMPDIR=/tmp PYTHONPATH=dgl-0.5-benchmark_amd
-timeout 900 python -m pytest tests/test_gat_fused.py tests/test_models_gpu.py -q -m gpu -x --tb=short 2>&1 | tail -3
+timeout 900 python -m pytest tests/test_gat_fused.py tests/test_models_gpu.py tests/test_gpu_parity.py -q -m gpu -x --tb=short 2>&1 | tail -3
 timeout 600 python dgl-0.5-benchmark_amd/full_graph.py --model gat --dataset reddit-small --heads 8 --num-layers 2 --epochs 20 2>&1 | tail -1
 timeout 600 python dgl-0.5-benchmark_amd/full_graph.py --model gat --dataset arxiv --epochs 20 2>&1 | tail -1
 timeout 600 python dgl-0.5-benchmark_amd/full_graph.py --model gat --dataset cora --epochs 30 2>&1 | tail -1
