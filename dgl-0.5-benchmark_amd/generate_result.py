@@ -35,6 +35,7 @@ RUNS = [  # name, launcher, arguments (reference script each one stands for)
     ("gcn_molhiv", "graph_classification.py", ["--epochs", "3"]),                                         # main_dgl_molhiv_gcn.py
     ("gcn_molhiv_hipgraph", "graph_classification.py", ["--epochs", "4", "--hipgraph"]),                  # same loop, one captured HIP graph
     ("gin_molhiv", "graph_classification.py", ["--model", "gin", "--epochs", "3"]),                       # BASELINE config 5 wording
+    ("gin_molhiv_hipgraph", "graph_classification.py", ["--model", "gin", "--epochs", "4", "--hipgraph"]),  # same loop, one captured HIP graph
     ("ns_sage_reddit", "sampling_sage.py", ["--num-epochs", "8"]),                                        # reddit/ns-sage-dgl.py
     ("gcmc_ml-1m", "link_prediction.py", ["--data_name", "ml-1m", "--train_max_iter", "30"]),             # gcmc_dgl/train.py
 ]
