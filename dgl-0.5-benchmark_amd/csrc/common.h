@@ -119,4 +119,22 @@ template <> __device__ __forceinline__ v4f vec_shfl_xor<4>(v4f v, int mask) {
   return r;
 }
 
+// ---- cross-lane sums without the LDS pipe ------------------------------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute_b32 on gfx950 (an LDS-pipe instruction, ~100 cycles of latency in a dependent chain).  Inside a
+// 16-lane DPP row the same sums are VALU moves: quad_perm swaps for distances 1 and 2, half-row / row mirrors for 4 and 8.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// x summed over the aligned group of L consecutive lanes (L a power of two), in every lane of the group
+template <int L>
+__device__ __forceinline__ float lanes_sum(float x) {
+  if (L >= 2) x += dpp_mov<0xB1>(x);    // quad_perm [1, 0, 3, 2]
+  if (L >= 4) x += dpp_mov<0x4E>(x);    // quad_perm [2, 3, 0, 1]
+  if (L >= 8) x += dpp_mov<0x141>(x);   // row_half_mirror: every lane of a quad holds the quad's sum, the mirrored lane is in the other quad
+  if (L >= 16) x += dpp_mov<0x140>(x);  // row_mirror: ... in the other half row
+#pragma unroll
+  for (int off = 16; off < L; off <<= 1) x += __shfl_xor(x, off, kWave);
+  return x;
+}
 }  // namespace mgx

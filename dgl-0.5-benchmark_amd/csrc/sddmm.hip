@@ -135,10 +135,7 @@ __device__ __forceinline__ void sddmm_dot_edges(const SddmmArgs<Idx>& a, const i
       }
     }
 #pragma unroll
-    for (int off = 1; off < G; off <<= 1) {
-#pragma unroll
-      for (int i = 0; i < kUn; ++i) acc[i] += __shfl_xor(acc[i], off, kWave);
-    }
+    for (int i = 0; i < kUn; ++i) acc[i] = lanes_sum<G>(acc[i]);
 #pragma unroll
     for (int i = 0; i < kUn; ++i)
       if (e[i] >= 0 && l == 0) a.out[e[i] * a.out_len + k] = acc[i];
@@ -404,9 +401,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_csr_headdot_kernel(const SddmmAr
         }
 #pragma unroll
         for (int i = 0; i < kUn; ++i) {
-          float p = x[i].x * rv.x + x[i].y * rv.y + x[i].z * rv.z + x[i].w * rv.w;
-#pragma unroll
-          for (int off = 1; off < LPH; off <<= 1) p += __shfl_xor(p, off, kWave);
+          const float p = lanes_sum<LPH>(x[i].x * rv.x + x[i].y * rv.y + x[i].z * rv.z + x[i].w * rv.w);
           if (writer && k + i * NB + sub < cnt) a.out[(int64_t)ee[i] * H + head] = p;
         }
       }
