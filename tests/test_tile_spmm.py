@@ -192,3 +192,69 @@ def test_product_path_fuzz_over_graph_shapes_and_widths(oracle, monkeypatch):
                 assert rel(got.cpu().numpy(), want) < RTOL + 1e-8 * float(deg.max()), (trial, n_src, n_dst, src.shape[0], D, reduce)
         if src.shape[0]:
             assert g._index.csc()._tile_plan, "the tile path was not taken"
+
+
+def test_gat_tile_plan_carries_nodes_and_ranks_among_parallel_edges(monkeypatch):
+    """The plans behind the tile forms of the fused GAT walks (csrc/gat_tile.inc): every position knows its NODE (hub chunks:
+    their row), and every entry the rank of its edge among the parallel edges of its (row, source) pair, mod 128 -- in the second
+    byte of the 16-bit staged stream and in bits 24-30 of a direct id.  Per pair the ranks are 0 .. m - 1: a key per edge."""
+    monkeypatch.setenv("MGX_PLAN_BUILDER", "host")
+    n = 400
+    src, dst, hub = hub_graph(n, 30000, 5000, seed=13)       # multigraph: the hub row repeats its sources ~12 times
+    src = np.concatenate([src, np.full(300, 7)])             # and one pair with 300 parallel edges (ranks wrap at 128)
+    dst = np.concatenate([dst, np.full(300, 9)])
+    csr = host_csr(n, src, dst)
+    base = schedule.build_plan(csr, torch.randperm(n, generator=torch.Generator().manual_seed(2)), split=2048, order_kind="cluster")
+    tp = tileplan.build_tile_plan(csr, base, 7, 3, 1, 2, lanes_log2=2, pair_rank=True)
+    assert tileplan.validate(tp, csr)
+    st = tp.stats
+    assert st["parallel_edges"] is True and st["max_pair_rank"] >= 299 and st["pair_rank_streams"] is True
+    # positions -> nodes
+    item, node = tp.tile_item.numpy(), tp.tile_node.numpy()
+    live = item != tileplan.NO_ITEM
+    whole = live & (item >= 0)
+    assert np.array_equal(node[whole], item[whole])           # a whole row: the item IS the node
+    hub_row = base.hub_row.numpy()
+    slot_hub = np.repeat(np.arange(base.num_hubs), np.diff(base.hub_slot_ptr.numpy()))
+    part = live & (item < 0)
+    assert part.any() and np.array_equal(node[part], hub_row[slot_hub[-(item[part] + 1)]])
+    # staged entries: same slots as the byte stream, ranks beside them
+    e16 = tp.lds_stream16.view(torch.int16).numpy().astype(np.int64) & 0xFFFF
+    assert np.array_equal(e16 & 0xFF, tp.lds_stream.view(torch.uint8).numpy())
+    # walk the plan as the kernel does and collect (row, source, rank) of every entry
+    G, CS, NC, NACC, R = tp.groups, tp.chunk_slots, tp.consumers, tp.nacc, tp.rows_per_tile
+    ids = tp.chunk_ids.numpy().reshape(-1, CS)
+    tcp, lds_off, dir_off = tp.tile_chunk_ptr.numpy(), tp.lds_off.numpy(), tp.dir_off.numpy()
+    lds_cnt = tp.lds_cnt.numpy().astype(np.uint16).reshape(-1, tileplan.CNT_STRIDE)
+    dir_cnt = tp.dir_cnt.numpy().reshape(-1, tileplan.CNT_STRIDE)
+    s16 = e16.reshape(-1, G, 4)
+    dstream = tp.dir_stream.numpy().reshape(-1, G, 4)
+    seen = {}
+    for t in range(tp.num_tiles):
+        for cw in range(NC):
+            ss = lds_off[t * NC + cw]
+            for c in range(tcp[t], tcp[t + 1]):
+                for j in range(NACC):
+                    for _ in range(int(lds_cnt[c * NC + cw, j])):
+                        for g in range(G):
+                            nd = node[t * R + (cw * NACC + j) * G + g]
+                            for u in range(4):
+                                e = s16[ss, g, u]
+                                if (e & 0xFF) != CS - 1:
+                                    seen.setdefault((int(nd), int(ids[c, e & 0xFF])), []).append(int(e >> 8))
+                        ss += 1
+            ss = dir_off[t * NC + cw]
+            for j in range(NACC):
+                for _ in range(int(dir_cnt[t * NC + cw, j])):
+                    for g in range(G):
+                        nd = node[t * R + (cw * NACC + j) * G + g]
+                        for u in range(4):
+                            e = int(dstream[ss, g, u])
+                            if e >= 0:
+                                seen.setdefault((int(nd), e & 0xFFFFFF), []).append((e >> 24) & 0x7F)
+                    ss += 1
+    pairs, counts = np.unique(dst.astype(np.int64) * n + src, return_counts=True)
+    assert len(seen) == pairs.shape[0]
+    for key, m in zip(pairs.tolist(), counts.tolist()):
+        got = sorted(seen[(key // n, key % n)])
+        assert got == sorted(r % 128 for r in range(m)), (key // n, key % n, m)
