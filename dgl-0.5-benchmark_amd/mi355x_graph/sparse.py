@@ -95,6 +95,13 @@ class CsrView(object):
             self._plan = schedule.plan_for(self) if self.indptr.is_cuda else None
         return self._plan
 
+    def _tile_base_plan(self):
+        """The work items every tile plan of this CSR is cut from (hub rows split at tileplan.TILE_SPLIT edges): built once."""
+        from . import schedule, tileplan
+        if "base" not in self._tile_plan:
+            self._tile_plan["base"] = schedule.plan_for(self, split=tileplan.TILE_SPLIT)
+        return self._tile_plan["base"]
+
     def gat_tile_plan(self, F):
         """Tile plan for the fused GAT walks over this CSR (one head of 4 .. 16 columns, dense neighbourhoods: gat_tile.inc), else None.
         Its own plan: 4 lanes per row with the node of every position and every entry's rank among parallel edges (attn_drop keys)."""
@@ -109,7 +116,7 @@ class CsrView(object):
             from . import schedule
             self.plan()
             nc, nacc, nl, tau = tileplan.gat_config()
-            base = schedule.plan_for(self, split=tileplan.TILE_SPLIT)
+            base = self._tile_base_plan()
             held = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=2, pair_rank=True)
             tileplan.validate(held, self)
             self._tile_plan["gat"] = held
@@ -128,7 +135,7 @@ class CsrView(object):
             from . import schedule
             self.plan()  # computes (and caches) the locality row order first
             nc, nacc, nl, tau = tileplan.config(lg)
-            base = schedule.plan_for(self, split=tileplan.TILE_SPLIT)
+            base = self._tile_base_plan()
             tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=lg)
             tileplan.validate(tp, self)
             self._tile_plan[lg] = tp
