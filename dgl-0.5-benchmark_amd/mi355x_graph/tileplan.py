@@ -105,7 +105,7 @@ def _excl_cumsum(x):
     return out
 
 
-def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None, groups=GROUPS):
+def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None, groups=GROUPS, bank_classes=0):
     """Edges with segment key (seg * 4 + g), seg = a (unit, cw, j) row of the stream -> (superstep counts per seg, first superstep
     of each seg, stream).  A row has max_g(count) steps rounded up to whole SUPERSTEPS (4 steps); layout
     [superstep][lane group g][step u]: one payload per entry, `pad` where a group has run out.  `seg_order`: the order in which
@@ -125,7 +125,15 @@ def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None, groups=GROUPS):
         base[seg_order] = laid[:-1]
     stream = torch.full(((total + STREAM_TAIL) * groups * 4,), pad, dtype=dtype, device=dev)
     if seg_key.numel():
-        order = torch.sort(seg_key, stable=True)[1]
+        if bank_classes and os.environ.get("MGX_TILE_BANK_ORDER", "1") == "1":
+            # narrow rows: a 16-lane pass of ds_read_b128 reads 16 / lanes-per-row rows, and two of them conflict when their slots
+            # are equal mod `bank_classes` (a 64-byte row is one bank quarter, a 128-byte row one half).  Inside a group's list the
+            # order is free (a sum): every group walks its entries class by class, starting from a class of its own, so that the
+            # groups of a pass are mostly in different classes at the same step.
+            cls = ((payload.long() & 0xFF) + (seg_key % groups)) % bank_classes
+            order = torch.sort(seg_key * bank_classes + cls, stable=True)[1]
+        else:
+            order = torch.sort(seg_key, stable=True)[1]
         sk = seg_key[order]
         seg_start = _excl_cumsum(cnt4)
         rank = torch.arange(sk.shape[0], device=dev) - seg_start[sk]
@@ -269,13 +277,14 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     chunk_tile = torch.repeat_interleave(torch.arange(T, device=dev), tile_chunk_ptr[1:] - tile_chunk_ptr[:-1])
     seg_unit = (chunk_tile[seg_chunk] * NC + seg_cw) if NCH else seg
     seg_order = torch.sort(seg_unit, stable=True)[1]  # stable: (chunk, j) order kept inside a (tile, cw)
-    lds_cnt, lds_base, lds_total, lds_bytes = _streams(sk, nseg, e_slot[staged], ZERO_SLOT, torch.uint8, seg_order, GROUPS)
+    bank_classes = {16: 4, 8: 2}.get(GROUPS, 0)  # 4 lanes per row: 64-byte rows; 8 lanes: 128-byte rows; 16 lanes: whole rows, no conflicts
+    lds_cnt, lds_base, lds_total, lds_bytes = _streams(sk, nseg, e_slot[staged], ZERO_SLOT, torch.uint8, seg_order, GROUPS, bank_classes)
     lds_off = _excl_cumsum(torch.bincount(seg_unit, weights=lds_cnt.double(), minlength=T * NC).long()) if NCH else \
         torch.zeros(T * NC + 1, dtype=torch.int64, device=dev)
     lds16 = None
     max_rank = int(e_rank.max()) if e_rank is not None and E else 0
     if e_rank is not None:  # the same stream with 16-bit entries: slot | (rank mod 128) << 8
-        lds16 = _streams(sk, nseg, e_slot[staged] + ((e_rank[staged] & 127) << 8), ZERO_SLOT, torch.int16, seg_order, GROUPS)[3]
+        lds16 = _streams(sk, nseg, e_slot[staged] + ((e_rank[staged] & 127) << 8), ZERO_SLOT, torch.int16, seg_order, GROUPS, bank_classes)[3]
     # ---- direct streams: one per (tile, consumer wave)
     direct = ~staged
     dk = e_tile[direct] * per_unit + e_pos[direct]
