@@ -21,6 +21,7 @@ The JSON line also carries
                 `traffic` = FETCH_SIZE*2 + WRITE_SIZE per launch from rocprofv3 --pmc child passes of the same kernel on
                 the same graph, run after the timed region (N = 1; --no-pmc skips them -> null);
                 `controls` = the same kernel on control graphs of the same size (dgl-0.5-benchmark_amd/kernel_controls.py);
+  epoch_ms_last_layer_backward_on_loss_rows   the default model with MGX_SAGE_SPARSE_LAST=1 (exact; not the headline)
   epoch_ms_plain_model   the same epoch with the reference's exact module graph (torch.nn.Linear, F.relu, nn.Dropout,
                 separate add, log_softmax over all nodes then [train_idx], F.nll_loss) -- only update_all() is this
                 package's -- timed right after the headline loop.  The headline (default) model computes the same function
@@ -484,6 +485,23 @@ def main():
                                "value_edges_per_s": agg_edges / (pel / psteps)}
         del pm, popt
         torch.cuda.empty_cache()
+        # ---- the default model again with the backward of the LAST layer formed on the loss rows only (ops.SageMeanCatRowsFn,
+        # MGX_SAGE_SPARSE_LAST=1): same forward, same gradients -- the output gradient is zero outside the 8 % training rows, so the
+        # dense gradients are taken on those rows and the reversed aggregation skips the rows that are zero by construction.  Off in
+        # the headline (value / ms_per_step) so that every one of its five aggregations gathers every source row; reported beside it.
+        if os.environ.get("MGX_SAGE_SPARSE_LAST", "0") != "1":
+            os.environ["MGX_SAGE_SPARSE_LAST"] = "1"
+            try:
+                sm = make_model()
+                sopt = torch.optim.Adam(sm.parameters(), lr=cfg["lr"])
+                sel_, sloss, _ = timed(make_step(sm, sopt, None), psteps, min(args.warmup, 3), False)
+                line["epoch_ms_last_layer_backward_on_loss_rows"] = round(sel_ / psteps * 1e3, 3)
+                line["last_layer_backward_on_loss_rows"] = {"switch": "MGX_SAGE_SPARSE_LAST=1", "steps": psteps, "final_loss": sloss,
+                                                            "value_edges_per_s": agg_edges / (sel_ / psteps)}
+                del sm, sopt
+            finally:
+                os.environ["MGX_SAGE_SPARSE_LAST"] = "0"
+            torch.cuda.empty_cache()
 
     head = next((k for k in kernels if k["D"] == D), kernels[0] if kernels else None)
     roofline = dict(head) if head else None

@@ -139,6 +139,13 @@ class GraphSAGE(nn.Module):
                 x = ops.relu_dropout(x, self.dropout.p, self.training, out=None if cat is None else cat.left)
                 if cat is not None and not cat.holds(x):
                     cat = None
+        last = self.layers[-1]
+        if rows is not None and self.rows_are_distinct and not self.plain and last.fc_self.bias is None:
+            # opt-in (MGX_SAGE_SPARSE_LAST=1): the last layer and the row selection as one node whose backward knows that the
+            # output gradient is zero outside the loss rows
+            y = ops.sage_mean_layer_rows(g, x, last.fc_self.weight, last.fc_neigh.weight, last.fc_neigh.bias, cat, rows)
+            if y is not None:
+                return y.log_softmax(dim=-1)
         x = self.layers[-1](g, x, cat=cat) if not self.plain else self.layers[-1](g, x)
         if rows is not None:
             x = ops.select_distinct_rows(x, rows) if self.rows_are_distinct else x[rows]

@@ -763,6 +763,78 @@ class SageMeanCatFn(torch.autograd.Function):
         return None, None, dh, dws, dwn, db
 
 
+_ROW_BITS = {}  # (rows.data_ptr(), len, N) -> (rows, bitmap): the loss rows of a training run are one tensor, reused every step
+
+
+def _row_bits(rows, n, be):
+    key = (rows.data_ptr(), int(rows.shape[0]), int(n))
+    held = _ROW_BITS.get(key)
+    if held is None or held[0] is not rows:
+        flag = torch.zeros((n, 4), dtype=torch.float32, device=rows.device)
+        flag[rows] = 1.0
+        if len(_ROW_BITS) > 8:
+            _ROW_BITS.clear()
+        held = _ROW_BITS[key] = (rows, be.row_nonzero_bits(flag))
+    return held[1]
+
+
+class SageMeanCatRowsFn(torch.autograd.Function):
+    """SageMeanCatFn followed by the selection of DISTINCT output rows -- the loss rows, `model(g, feats)[train_idx]` at
+    main_dgl_product_sage.py:105 -- as one node (MGX_SAGE_SPARSE_LAST=1; off by default).  The forward is the whole layer, every row
+    aggregated and projected as the reference does; the backward uses what the selection implies: d y is zero outside `rows` (92 % of
+    the rows of ogbn-products), so the dense gradients are formed on those rows only and the reversed aggregation skips the gathers
+    of rows that are zero by construction (mgx_spmm_copy_u_masked with a bitmap of `rows`; they are never even written).  Exact."""
+
+    @staticmethod
+    def forward(ctx, gidx, cat, h, w_self, w_neigh, bias, rows):
+        csc = gidx.csc()
+        be = sparse.backend_for(h)
+        if not cat.holds(h):
+            cat.left.copy_(h)
+            cat.static_key = None
+        cat.generation += 1
+        be.spmm_copy_u_strided(csc, "mean", cat.left, cat.right)
+        ctx.gidx, ctx.cat, ctx.generation, ctx.rows = gidx, cat, cat.generation, rows
+        ctx.save_for_backward(w_self, w_neigh)
+        y = torch.nn.functional.linear(cat.buf, torch.cat([w_self, w_neigh], dim=1), bias)
+        return y.index_select(0, rows)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dyr):
+        w_self, w_neigh = ctx.saved_tensors
+        cat, rows = ctx.cat, ctx.rows
+        if cat.generation != ctx.generation:
+            raise DGLError("SAGEConv: a later forward pass overwrote the [h | neigh] buffer this backward pass needs")
+        dyr = dyr.contiguous()
+        need = ctx.needs_input_grad
+        be = sparse.backend_for(dyr)
+        K, n = cat.K, cat.buf.shape[0]
+        dh = None
+        if need[2]:
+            dcat = dyr @ torch.cat([w_self, w_neigh], dim=1)                     # [R, 2K]: d[h | neigh] on the loss rows
+            dn = torch.empty((n, K), dtype=dyr.dtype, device=dyr.device)          # rows outside `rows` stay unwritten: never gathered
+            dn.index_copy_(0, rows, dcat[:, K:] * ctx.gidx.csc().inv_degrees()[rows].view(-1, 1))
+            dh = be.spmm_copy_u_masked(ctx.gidx.csr(), "sum", dn, _row_bits(rows, n, be))
+            dh.index_add_(0, rows, dcat[:, :K])
+        dws = dwn = None
+        if need[3] or need[4]:
+            dw = _weight_grad(dyr, cat.buf.index_select(0, rows))                  # [out, 2K]
+            dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
+        db = be.column_sum(dyr) if need[5] else None
+        return None, None, dh, dws, dwn, db, None
+
+
+def sage_mean_layer_rows(g, h, w_self, w_neigh, bias, cat, rows):
+    """The last SAGE layer of a model whose loss reads `rows` only (distinct): SageMeanCatRowsFn when it applies, else None."""
+    if (os.environ.get("MGX_SAGE_SPARSE_LAST", "0") != "1" or cat is None or hasattr(g, "sage_mean_layer") or rows is None
+            or sage_mean_layer.__globals__["_cat_eligible"](g, h, cat) is False or type(g) is not DGLGraph or not h.is_cuda
+            or not torch.is_grad_enabled() or h.dtype != torch.float32 or g.idtype != torch.int32 or _torch_ops() is not None
+            or (bias is not None and w_self.shape[0] > sparse.backend_for(h).COLUMN_SUM_MAX)):
+        return None
+    return SageMeanCatRowsFn.apply(g._index, cat, h, w_self, w_neigh, bias, rows)
+
+
 class SageMeanProjectFirstFn(torch.autograd.Function):
     """y = h W_self^T + mean_{u->v}(h[u] W_neigh^T) + b: the projection BEFORE the aggregation -- mean and the linear map commute,
     so this is SAGEConv's `fc_self(h) + fc_neigh(mean_agg(h))` (main_dgl_reddit_sage.py:73-80) with the aggregation running at

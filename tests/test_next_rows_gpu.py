@@ -314,6 +314,42 @@ def test_one_gemm_layers_over_cat_buffers_match_the_two_gemm_form(monkeypatch, b
             assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-7
 
 
+def test_last_layer_backward_on_the_loss_rows_only_changes_nothing(monkeypatch):
+    """MGX_SAGE_SPARSE_LAST=1: the last SAGE layer + the selection of the loss rows as one node whose backward forms the dense
+    gradients on those rows only and lets the reversed aggregation skip the rows whose gradient is zero by construction
+    (ops.SageMeanCatRowsFn): same loss and the same parameter gradients as the default model, over two training steps."""
+    sys.path.insert(0, PKG)
+    import full_graph
+    n = 70000
+    src, dst = random_graph(n, n, 14 * n, seed=12, skew=True)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().formats(["csr", "csc"]).to(DEV)
+    torch.manual_seed(0)
+    x = torch.randn(n, 100, device=DEV)
+    y = torch.randint(0, 47, (n,), device=DEV)
+    idx = torch.nonzero(torch.rand(n, device=DEV) < 0.08).flatten()   # 8 % of the nodes, as ogbn-products trains
+    runs = []
+    for sparse_last in ("1", "0"):
+        monkeypatch.setenv("MGX_SAGE_SPARSE_LAST", sparse_last)
+        torch.manual_seed(77)
+        ops.ReluDropout._calls = 0
+        m = full_graph.GraphSAGE(100, 64, 47, 3, 0.5).to(DEV)
+        m.rows_are_distinct = True
+        m.train()
+        out = []
+        for step in range(2):
+            m.zero_grad()
+            logp = m(g, x, rows=idx)
+            assert ("SageMeanCatRowsFn" in type(logp.grad_fn.next_functions[0][0]).__name__) == (sparse_last == "1")
+            loss = ops.nll_sum(logp, y[idx]) / idx.shape[0]
+            loss.backward()
+            out.append((float(loss), [p.grad.clone() for p in m.parameters()]))
+        runs.append(out)
+    for (l1, g1), (l2, g2) in zip(*runs):
+        assert abs(l1 - l2) < 1e-5 * abs(l2)
+        for a_, b_ in zip(g1, g2):
+            assert float((a_ - b_).abs().max()) < 2e-4 * float(b_.abs().max()) + 1e-7
+
+
 def test_strided_copy_u_and_relu_dropout_match_the_dense_calls(oracle):
     n, D = 3000, 64
     src, dst = random_graph(n, n, 40000, seed=2, skew=True)
