@@ -327,6 +327,34 @@ def test_tile_walks_with_more_than_128_parallel_edges_on_a_pair(monkeypatch):
         assert float((a_ - b_).abs().max()) < RTOL * float(b_.abs().max()) + 1e-6, (name, float((a_ - b_).abs().max()), float(b_.abs().max()))
 
 
+@pytest.mark.parametrize("mixed", [False, True])
+def test_tile_walks_on_a_bipartite_block_and_mixed_with_the_row_kernels(mixed, monkeypatch):
+    """A dense bipartite block (3,000 sources -> 1,000 destinations): the tile walks against the unfused operators; `mixed`: the
+    out-CSR has no tile plan (as on a graph whose out-degrees fall below the tile rule), so the forward is a tile walk and the
+    backward the row kernels -- they share the per-node statistics."""
+    n_src, n_dst = 3000, 1000
+    src, dst = random_graph(n_src, n_dst, 400000, seed=41)
+    monkeypatch.setenv("MGX_TILE", "1")
+    monkeypatch.setenv("MGX_GAT_TILE", "1")
+    g = mk(n_src, n_dst, src, dst)
+    if mixed:
+        csr = g._index.csr()
+        orig = type(csr).gat_tile_plan
+        monkeypatch.setattr(type(csr), "gat_tile_plan", lambda self, F: None if self is csr else orig(self, F))
+    feat = torch.randn(n_src, 1, 16, device=DEV)
+    el, er = torch.randn(n_src, 1, 1, device=DEV), torch.randn(n_dst, 1, 1, device=DEV)
+    w = torch.randn(n_dst, 1, 16, device=DEV)
+    res = []
+    for fused in (True, False):
+        f_, l_, r_ = (t.clone().requires_grad_(True) for t in (feat, el, er))
+        out = ops.gat_fused(g, f_, l_, r_, 0.2, 0.0, True) if fused else unfused(g, f_, l_, r_, 0.2)
+        (out * w).sum().backward()
+        res.append([out.detach(), f_.grad, l_.grad, r_.grad])
+    assert "gat" in g._index.csc()._tile_plan
+    for name, a_, b_ in zip(("out", "d_feat", "d_el", "d_er"), *res):
+        assert float((a_ - b_).abs().max()) < RTOL * float(b_.abs().max()) + 1e-6, (name, float((a_ - b_).abs().max()), float(b_.abs().max()))
+
+
 def test_fused_rejects_mismatched_rows():
     n = 100
     src, dst = random_graph(n, n, 1000, seed=1)
