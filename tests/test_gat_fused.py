@@ -355,6 +355,57 @@ def test_tile_walks_on_a_bipartite_block_and_mixed_with_the_row_kernels(mixed, m
         assert float((a_ - b_).abs().max()) < RTOL * float(b_.abs().max()) + 1e-6, (name, float((a_ - b_).abs().max()), float(b_.abs().max()))
 
 
+def test_tile_walks_fuzz_over_graph_shapes(monkeypatch):
+    """The tile forms of the three walks forced onto 14 random graphs -- a handful of nodes to a few thousand, bipartite, sparse to
+    dense, hub rows and hub sources, rows without in-edges, parallel edges -- for F in {4, 8, 12, 16}, with and without attn_drop:
+    outputs and all gradients against the unfused operators (with the walks' mask applied under dropout)."""
+    monkeypatch.setenv("MGX_TILE", "1")
+    monkeypatch.setenv("MGX_GAT_TILE", "1")
+    rng = np.random.default_rng(77)
+    for trial in range(14):
+        n_src = int(rng.choice([5, 40, 300, 2000, 3500]))
+        n_dst = n_src if trial % 3 else int(rng.choice([7, 120, 900]))
+        nnz = int(rng.choice([1, 60, 5000, 60000, 300000]))
+        src = rng.integers(0, n_src, nnz)
+        dst = rng.integers(0, max(1, n_dst - n_dst // 5), nnz)            # the last fifth of the rows receives nothing
+        if trial % 4 == 2:
+            src = np.concatenate([src, rng.integers(0, n_src, 4000), np.full(2500, n_src - 1)])
+            dst = np.concatenate([dst, np.full(4000, 1 % n_dst), rng.integers(0, n_dst, 2500)])
+        src, dst = src.astype(np.int64), dst.astype(np.int64)
+        Fd = int(rng.choice([4, 8, 12, 16]))
+        p = float(rng.choice([0.0, 0.35]))
+        g = mk(n_src, n_dst, src, dst)
+        feat = torch.randn(n_src, 1, Fd, device=DEV)
+        el, er = torch.randn(n_src, 1, 1, device=DEV), torch.randn(n_dst, 1, 1, device=DEV)
+        w = torch.randn(n_dst, 1, Fd, device=DEV)
+        rank = np.zeros_like(src)
+        if p > 0.0:  # rank among parallel edges, keyed on (destination, source): any multiple of n_src as the row stride
+            key = dst * n_src + src
+            order = np.argsort(key, kind="stable")
+            ks = key[order]
+            first = np.concatenate([[True], ks[1:] != ks[:-1]])
+            run0 = np.maximum.accumulate(np.where(first, np.arange(ks.shape[0]), 0))
+            rank[order] = np.arange(ks.shape[0]) - run0
+        res = []
+        for tile in (True, False):
+            f_, l_, r_ = (t.clone().requires_grad_(True) for t in (feat, el, er))
+            torch.manual_seed(5)
+            ops.GATFused._calls = 0
+            if tile:
+                out = ops.gat_fused(g, f_, l_, r_, 0.2, p, True)
+                assert "gat" in g._index.csc()._tile_plan, (trial, "tile walk not taken")
+            else:
+                a = unfused_attention(g, l_, r_, 0.2)
+                if p > 0.0:
+                    a = a * (pair_keep(5, T(dst), T(src), T(rank % 128), p).float().view(-1, 1, 1) / (1.0 - p))
+                out = ops.gspmm(g, "mul", "sum", f_, a)
+            (out * w).sum().backward()
+            res.append([out.detach(), f_.grad, l_.grad, r_.grad])
+        for name, a_, b_ in zip(("out", "d_feat", "d_el", "d_er"), *res):
+            tol = RTOL * float(b_.abs().max()) + 1e-6
+            assert float((a_ - b_).abs().max()) < tol, (trial, n_src, n_dst, src.shape[0], Fd, p, name, float((a_ - b_).abs().max()), float(b_.abs().max()))
+
+
 def test_fused_rejects_mismatched_rows():
     n = 100
     src, dst = random_graph(n, n, 1000, seed=1)
