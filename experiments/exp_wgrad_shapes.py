@@ -24,7 +24,7 @@ def timeit(fn, reps=10):
 dev = torch.device("cuda")
 be = sparse.backend_for(torch.zeros(1, device=dev))
 for n, M, K in ((232965, 128, 602), (232965, 41, 128), (169343, 256, 512), (169343, 256, 256), (169343, 40, 512),
-                (2449029, 64, 128), (2449029, 64, 200), (300000, 64, 128), (7680, 256, 256), (7680, 256, 512), (16128, 256, 256),
+                (2449029, 64, 128), (2449029, 64, 200), (2449029, 47, 128), (300000, 64, 128), (7680, 256, 256), (7680, 256, 512), (16128, 256, 256),
                 (30000, 256, 256)):
     dy, x = torch.randn(n, M, device=dev), torch.randn(n, K, device=dev)
     t_x = timeit(lambda: be.xty(dy, x))
