@@ -157,7 +157,8 @@ def profile_avg_us(tag=None):
         return {}
     out = {}
     for ln in open(files[-1]):
-        m = re.match(r"void mgx::spmm_(?:rowwave32|tile)\w*_kernel<(\d+), (\d+),.*?\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s*$", ln)
+        # the row kernel only: spmm_tile*_kernel<W, NL, ...> carries other template arguments
+        m = re.match(r"void mgx::spmm_rowwave32_kernel<(\d+), (\d+),.*?\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s*$", ln)
         if m:
             vec, g, calls, _total, avg = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4), float(m.group(5))
             for width in (64, 100):  # lane-group width G covers D = 4 G columns (D = 100: G = 32 with idle lanes)
@@ -231,7 +232,17 @@ def main():
     p.add_argument("--no-controls", action="store_true", help="skip the control graphs (roofline.controls)")
     p.add_argument("--no-plain", action="store_true", help="skip the plain-torch-module epoch (epoch_ms_plain_model)")
     p.add_argument("--dropout", type=float, default=None, help="override the model's dropout (tests compare N = 1 and N > 1 at 0)")
+    p.add_argument("--emulate-ranks", default=None, metavar="P[,P...]",
+                   help="N = 1 only: run every rank of a P-way partition of the same graph one at a time on this GPU (mi355x_graph/"
+                        "emulate.py) and put the scaling model into config.partition.predicted; given explicitly it also skips the "
+                        "plain-model / controls / counter / CPU legs.  Default for a plain N = 1 run: 2,4,8")
+    p.add_argument("--no-scale-model", action="store_true", help="skip the emulated-ranks scaling model")
+    p.add_argument("--report", default=None, help="with --emulate-ranks: also write the human-readable table to this file")
     args = p.parse_args()
+    if args.emulate_ranks is not None:
+        args.no_plain = args.no_controls = args.no_pmc = args.no_cpu_baseline = True
+    elif not args.no_scale_model and args.gpus == 1:
+        args.emulate_ranks = "2,4,8"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)  # does not return
@@ -349,7 +360,8 @@ def main():
                           "halo_bytes_per_exchange_D%d" % D_hid: r[1] * D_hid * 4} for r in allr],
             "max_halo_bytes_per_exchange": max(r[1] for r in allr) * D_hid * 4,
             "exchanges_per_epoch": "2 forward (the layer-1 input halo is resident) + 2 backward, D=%d each" % D_hid})
-    del src, dst
+    if world > 1 or not args.emulate_ranks:
+        del src, dst
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
 
     def make_step(model, opt, bucket):
@@ -424,7 +436,10 @@ def main():
         algo = spmm_algorithmic_bytes(r0["n_rows"], r0["n_cols"], r0["nnz"], width)
         algo_rmw = sum(spmm_algorithmic_bytes(r["n_rows"], r["n_cols"], r["nnz"], width, r.get("accumulate", False)) for r in sel) / len(sel)
         achieved = algo / avg / 1e9
-        kernels.append({"bound": "hbm", "kernel": "g-SpMM copy_u/sum|mean, D=%d (mgx_spmm_csr)" % width, "D": width,
+        variants = sorted({r.get("variant", "row") for r in sel})
+        entry = "mgx_spmm_tile_copy_u" if variants == ["tile"] else "mgx_spmm_csr / mgx_spmm_copy_u_strided"
+        kernels.append({"bound": "hbm", "kernel": "g-SpMM copy_u/sum|mean, D=%d (%s; %s kernel)" % (width, entry, "+".join(variants)),
+                        "D": width,
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                         "algorithmic_bytes_per_launch": int(algo),
@@ -451,12 +466,17 @@ def main():
 
     epoch = elapsed / args.steps
     agg_edges = full_graph.spmm_edges_per_epoch(cfg["num_layers"], num_edges)
+    # like for like with cpu_baseline (which times the five aggregations alone): the same five aggregations' DEVICE time, hub
+    # fix-up launches included (the events bracket the whole mgx_spmm_* call), per epoch
+    spmm_ms_per_epoch = sum(r["start"].elapsed_time(r["end"]) for r in records + sparse_recs) / max(args.steps, 1)
     line = {
         "metric": "aggregated edges/s, full-graph 3-layer GraphSAGE (hidden 64) on an ogbn-products-shaped graph; "
                   "epoch time in ms_per_step",
         "value": agg_edges / epoch, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": epoch * 1e3, "epoch_time_s": epoch, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_spmm_only_edges_per_s": (agg_edges / (spmm_ms_per_epoch * 1e-3)) if spmm_ms_per_epoch > 0 and world == 1 else None,
+        "spmm_ms_per_epoch": round(spmm_ms_per_epoch, 4) if world == 1 else None,
         "config": {"workload": "configs[3]: 3-layer GraphSAGE full-graph on ogbn-products shape "
                                "(N=%d, E=%d directed, D=%d->%d->%d->%d), %s" %
                                (n, num_edges, spec["feat"], cfg["hidden"], cfg["hidden"], spec["classes"],
@@ -502,6 +522,59 @@ def main():
             finally:
                 os.environ["MGX_SAGE_SPARSE_LAST"] = "0"
             torch.cuda.empty_cache()
+        # ---- the default model with layer 1 projected BEFORE its aggregation (ops.SageMeanStaticInputProjectFn,
+        # MGX_SAGE_L1_PROJECT_FIRST=1): mean_agg(x) W^T = mean_agg(x W^T), so the layer-1 aggregation runs at 64 columns instead of
+        # 100; its weight gradient is taken against the constant mean_agg(x), aggregated once and kept.  Same loss and gradients
+        # (test); still five aggregations over every edge per epoch.  NOT the headline: the headline keeps the reference's widths.
+        if os.environ.get("MGX_SAGE_L1_PROJECT_FIRST", "0") != "1":
+            os.environ["MGX_SAGE_L1_PROJECT_FIRST"] = "1"
+            try:
+                lm = make_model()
+                lopt = torch.optim.Adam(lm.parameters(), lr=cfg["lr"])
+                lel, lloss, _ = timed(make_step(lm, lopt, None), psteps, min(args.warmup, 3), False)
+                line["epoch_ms_layer1_projected_first"] = round(lel / psteps * 1e3, 3)
+                line["layer1_projected_first"] = {"switch": "MGX_SAGE_L1_PROJECT_FIRST=1", "steps": psteps, "final_loss": lloss,
+                                                  "value_edges_per_s": agg_edges / (lel / psteps),
+                                                  "aggregation_widths": [cfg["hidden"]] * (2 * cfg["num_layers"] - 1)}
+                del lm, lopt
+            finally:
+                os.environ["MGX_SAGE_L1_PROJECT_FIRST"] = "0"
+            torch.cuda.empty_cache()
+
+    # ---- the 2 / 4 / 8-GPU curve as a MODEL measured on this one GPU: every rank of the partitioned program run here, one at a
+    # time, exchanges priced per xGMI link (scale_model.py; never a measured multi-GPU number, and labelled so)
+    if rank == 0 and world == 1 and args.emulate_ranks:
+        import scale_model
+        model = opt = None  # (the plain-model leg above may already have dropped them)
+        torch.cuda.empty_cache()
+        models = []
+        for P in [int(t) for t in args.emulate_ranks.split(",") if t.strip()]:
+            try:
+                models.append(scale_model.run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P,
+                                              steps=min(args.steps, 5), warmup=min(args.warmup, 2), dropout=args.dropout,
+                                              progress=lambda msg: print("[scale model] " + msg, file=sys.stderr, flush=True)))
+            except Exception as err:  # the model must not lose the bench line
+                models.append({"ranks": P, "error": "%s: %s" % (type(err).__name__, str(err)[:300])})
+            torch.cuda.empty_cache()
+        pred = {"kind": "MODEL, not a multi-GPU measurement: every rank's device time measured on this GPU (mi355x_graph/emulate.py), "
+                        "exchanges priced per xGMI link (scale_model.py)",
+                "epoch_ms_1gpu_measured": round(epoch * 1e3, 3)}
+        for m in models:
+            if "error" in m:
+                pred["P=%d" % m["ranks"]] = m
+                continue
+            keep = {k: m[k] for k in ("edge_cut_pct", "exchanges_per_epoch", "imbalance", "compute_ms_max", "compute_ms_mean",
+                                      "max_pair_bytes_per_exchange", "max_recv_bytes_per_exchange", "final_loss", "predicted")}
+            keep["per_rank"] = [{k: p[k] for k in ("owned_rows", "halo_rows", "local_edges", "halo_edges", "compute_ms",
+                                                   "overlap_window_ms_per_exchange")} for p in m["per_rank"]]
+            pred["P=%d" % m["ranks"]] = keep
+        line["config"]["partition"] = {"predicted": pred}
+        if args.report:
+            good = [m for m in models if "error" not in m]
+            with open(args.report, "w") as fh:
+                fh.write(scale_model.report(good, epoch * 1e3, header="Scaling model of %s\n(bench.py --emulate-ranks %s --steps %d)"
+                                            % (line["config"]["workload"], args.emulate_ranks, args.steps)))
+        del src, dst
 
     head = next((k for k in kernels if k["D"] == D), kernels[0] if kernels else None)
     roofline = dict(head) if head else None

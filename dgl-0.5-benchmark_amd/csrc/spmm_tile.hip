@@ -129,6 +129,10 @@ __device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, int w
     o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = MGX_STAMP() - t_begin; o[4] = n;
   }
 #endif
+  // the consumers' (n + 1)-th barrier (before the direct part reuses the ring): the loaders take part in it, as in gat_tile.inc,
+  // instead of relying on exited waves being dropped from the workgroup's barrier count
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
 }
 
 // ---- consumer waves -------------------------------------------------------------------------------------------------------
@@ -241,7 +245,7 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int
 
   // ---- direct part: sources used once in this tile, gathered from global memory.  Stream layout [superstep][lane group][4 ids]
   // = 64 bytes per superstep; its windows (1 KiB = 16 supersteps) live where the chunk ring was: every consumer has left the
-  // staged part (barrier; the loader waves have exited and no longer count).
+  // staged part (barrier, which the loader waves join before they exit).
   auto direct_part = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef MGX_TILE_STAMPS
@@ -482,6 +486,8 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
       o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = MGX_STAMP() - t_begin; o[4] = n;
     }
 #endif
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();  // the consumers' barrier before the direct part (see tile_loader)
     return;
   }
 

@@ -63,7 +63,9 @@ class SAGEConv(nn.Module):
             # the whole layer as one autograd node (ops.SageMeanLayerFn / SageMeanCatFn): same aggregation kernel, the two
             # gradients of `feat` meet inside the reversed aggregation instead of in a separate add pass
             # in_feats >> out_feats (reddit: 602 -> 16): project first, aggregate at the output width (dgl.nn.SAGEConv's lin_before_mp)
-            y = ops.sage_project_first(graph, feat, self.fc_self.weight, self.fc_neigh.weight, self.fc_neigh.bias)
+            y = ops.sage_static_input_project(graph, feat, self.fc_self.weight, self.fc_neigh.weight, self.fc_neigh.bias, cat)
+            if y is None:
+                y = ops.sage_project_first(graph, feat, self.fc_self.weight, self.fc_neigh.weight, self.fc_neigh.bias)
             if y is None:
                 y = ops.sage_mean_layer(graph, feat, self.fc_self.weight, self.fc_neigh.weight, self.fc_neigh.bias, cat=cat)
             if y is not None:

@@ -23,7 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from ._lib import DGLError
-from . import core, ops, schedule, sparse
+from . import core, emulate, ops, schedule, sparse
 from . import function as fn
 from .graph import DGLGraph, Frame, GraphIndex
 
@@ -284,8 +284,17 @@ class _Comm(object):
         self.group = group
         self.n_exchanges = 0
 
+    def mark(self, label):
+        """Names the stretch of work that starts here -- recorded only by an emulated rank (emulate.EmuRank.mark)."""
+        emu = emulate.current()
+        if emu is not None:
+            emu.mark(label)
+
     def all_to_all(self, out, inp, out_splits, in_splits):
         self.n_exchanges += 1
+        emu = emulate.current()
+        if emu is not None:  # P ranks in one process (emulate.py): in-process row copies
+            return emu.all_to_all(out, inp, out_splits, in_splits)
         if dist.get_backend(self.group) == "gloo":  # tests: pairwise isend/irecv staged through host memory
             world, rank = dist.get_world_size(self.group), dist.get_rank(self.group)
             outs = list(out.split(out_splits, 0))
@@ -311,6 +320,10 @@ class _Comm(object):
     def all_to_all_async(self, out, inp, out_splits, in_splits):
         """Returns a handle whose wait() orders the CURRENT stream after the exchange (RCCL runs it on the
         process group's own stream, so kernels launched in between overlap with it)."""
+        emu = emulate.current()
+        if emu is not None:
+            self.n_exchanges += 1
+            return emu.all_to_all_async(out, inp, out_splits, in_splits)
         if dist.get_backend(self.group) == "gloo":
             self.all_to_all(out, inp, out_splits, in_splits)
             return _Done()
@@ -393,6 +406,7 @@ class DistSageMeanCatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, comm, cat, h, w_self, w_neigh, bias, static_cache):
         be = sparse.backend_for(h)
+        comm.mark("pack")
         if static_cache is not None and static_cache.get("recv") is not None and static_cache.get("version") == h._version:
             recv, work = static_cache["recv"], _Done()
         else:
@@ -407,12 +421,15 @@ class DistSageMeanCatFn(torch.autograd.Function):
                 cat.left.copy_(h)
                 cat.static_key = None if h.requires_grad else (h, h._version)
         cat.generation += 1
+        comm.mark("owned-source aggregation")
         be.spmm_copy_u_strided(plan.loc.csc(), "sum", cat.left, cat.right, dst_scale=plan.inv_deg)
         work.wait()
+        comm.mark("halo-source aggregation")
         if plan.n_halo:
             be.spmm_copy_u_strided(plan.halo.csc(), "sum", recv, cat.right, accumulate=True, dst_scale=plan.inv_deg)
         ctx.plan, ctx.comm, ctx.cat, ctx.generation = plan, comm, cat, cat.generation
         ctx.save_for_backward(w_self, w_neigh)
+        comm.mark("dense")
         return torch.nn.functional.linear(cat.buf, torch.cat([w_self, w_neigh], dim=1), bias)
 
     @staticmethod
@@ -434,14 +451,18 @@ class DistSageMeanCatFn(torch.autograd.Function):
             dn.mul_(plan.inv_deg.view(-1, 1))  # d(sum / deg)
             back = torch.empty((plan.send_idx.shape[0], K), dtype=dy.dtype, device=dy.device)
             g_halo = torch.empty((plan.n_halo, K), dtype=dy.dtype, device=dy.device)
+            comm.mark("halo-row gradients")
             if plan.n_halo:
                 be.spmm_copy_u_strided(plan.halo.csr(), "sum", dn, g_halo)
             work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
+            comm.mark("owned-row reversed aggregation")
             be.spmm_copy_u_strided(plan.loc.csr(), "sum", dn, dcat[:, :K], accumulate=True)
             work.wait()
+            comm.mark("return-add")
             if back.shape[0]:  # row v += the returned rows whose owner is v: copy_u over (owned row -> position in `back`)
                 be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dcat[:, :K], accumulate=True)
             dh = dcat[:, :K]
+            comm.mark("dense")
         dws = dwn = None
         if need[4] or need[5]:
             dw = ops._weight_grad(dy, cat.buf)
@@ -593,10 +614,24 @@ class DistGraph(DGLGraph):
 # ----------------------------------------------------------------------------- training helpers
 def _staged(group):
     """gloo (tests / single-GPU smoke runs) moves device tensors through host memory."""
-    return dist.get_backend(group) == "gloo"
+    return emulate.current() is None and dist.get_backend(group) == "gloo"
+
+
+_EMU_OPS = {dist.ReduceOp.SUM: "sum", dist.ReduceOp.MAX: "max", dist.ReduceOp.MIN: "min"}
+
+
+def world_size(group=None):
+    """Ranks of the running job: the emulated world's, else the process group's, else 1."""
+    emu = emulate.current()
+    if emu is not None:
+        return emu.size
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
 def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
+    emu = emulate.current()
+    if emu is not None:
+        return emu.all_reduce(t, _EMU_OPS[op])
     if _staged(group) and t.is_cuda:
         h = t.cpu()
         dist.all_reduce(h, op=op, group=group)
@@ -607,6 +642,9 @@ def all_reduce(t, op=dist.ReduceOp.SUM, group=None):
 
 
 def broadcast(t, src=0, group=None):
+    emu = emulate.current()
+    if emu is not None:
+        return emu.broadcast(t, src)
     if _staged(group) and t.is_cuda:
         h = t.cpu()
         dist.broadcast(h, src, group=group)
@@ -775,7 +813,7 @@ class GlobalBatchNorm1d(nn.BatchNorm1d):
 
     def forward(self, x):
         use_batch = self.training or not self.track_running_stats
-        if not use_batch or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.process_group) == 1:
+        if not use_batch or world_size(self.process_group) == 1:
             return super(GlobalBatchNorm1d, self).forward(x)
         if x.dim() != 2:
             raise DGLError("GlobalBatchNorm1d expects (rows, channels) input")

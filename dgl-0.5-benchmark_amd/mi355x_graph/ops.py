@@ -297,21 +297,21 @@ class GATFused(torch.autograd.Function):
             GATFused._calls += 1
         be = sparse.backend_for(feat)
         if p > 0.0 and be.name == "hip":  # training with attn_drop: the backward needs the out-CSR anyway; the forward's choice of kernel too
-            out, nstat = be.gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed, attn_l, csr=gidx.csr())
+            out, nstat, form = be.gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed, attn_l, csr=gidx.csr())
         else:
-            out, nstat = be.gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed, attn_l)
-        ctx.backward_cache = gidx, float(slope), float(p), seed, el.shape, er.shape, attn_l
+            out, nstat, form = be.gat_fused_fwd(csc, feat, el2, er2, float(slope), float(p), seed, attn_l)
+        ctx.backward_cache = gidx, float(slope), float(p), seed, el.shape, er.shape, attn_l, form
         ctx.save_for_backward(feat, el2, out, nstat)
         return out
 
     @staticmethod
     @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, d_out):
-        gidx, slope, p, seed, el_shape, er_shape, attn_l = ctx.backward_cache
+        gidx, slope, p, seed, el_shape, er_shape, attn_l, form = ctx.backward_cache
         feat, el2, out, nstat = ctx.saved_tensors
         need_src = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         d_feat, d_el, d_er = sparse.backend_for(feat).gat_fused_bwd(gidx.csc(), gidx.csr(), feat, el2, slope, p, seed, out,
-                                                                     d_out.contiguous(), nstat, need_src, attn_l)
+                                                                     d_out.contiguous(), nstat, need_src, attn_l, form=form)
         return (None, d_feat if ctx.needs_input_grad[1] else None,
                 d_el.view(el_shape) if (d_el is not None and ctx.needs_input_grad[2]) else None,
                 d_er.view(er_shape) if ctx.needs_input_grad[3] else None, None, None, None)
@@ -682,13 +682,14 @@ class CatBuffer(object):
     """An [N, 2 K] matrix whose left half holds a layer's input h and whose right half receives mean_{u->v} h[u]: the operand of
     the ONE GEMM `[h | neigh] [W_self | W_neigh]^T` that replaces SAGEConv's two.  `generation` counts the forward passes
     that wrote the right half; a backward pass checks that no later forward overwrote what it saved."""
-    __slots__ = ("buf", "K", "generation", "static_key")
+    __slots__ = ("buf", "K", "generation", "static_key", "static_agg")
 
     def __init__(self, n, K, device):
         self.buf = torch.empty((n, 2 * K), dtype=torch.float32, device=device)
         self.K = K
         self.generation = 0
         self.static_key = None
+        self.static_agg = None  # the static_key whose aggregation the right half holds (SageMeanStaticInputProjectFn)
 
     @property
     def left(self):
@@ -874,6 +875,69 @@ class SageMeanProjectFirstFn(torch.autograd.Function):
             dws, dwn = dw[:K], dw[K:]
         db = be.column_sum(dy.contiguous()) if need[4] else None
         return None, dh, dws, dwn, db
+
+
+class SageMeanStaticInputProjectFn(torch.autograd.Function):
+    """The FIRST SAGE layer of a full-graph model, whose input x is a constant (the node features: no gradient), with the
+    projection before the aggregation (MGX_SAGE_L1_PROJECT_FIRST=1; off by default, reported beside the headline):
+
+        y = x W_self^T + mean_agg(x W_neigh^T) + b        ==  fc_self(x) + fc_neigh(mean_agg(x))   (main_dgl_product_sage.py:61-64)
+
+    so the products layer aggregates 64 columns instead of 100 (whole 256-byte rows instead of 400-byte rows that straddle 4.125
+    cache lines).  SageMeanProjectFirstFn pays for that with a second aggregation in the backward (dz = A_mean^T dy) because its
+    weight gradient is [dy | dz]^T h; here x is constant, so  dW_neigh = dy^T (A_mean x)  is taken against a CONSTANT matrix that is
+    aggregated once and kept in the right half of the layer's CatBuffer for as long as the left half holds the same unmodified
+    tensor object (identity + version counter, exactly like the resident copy of x itself) -- the forward aggregation still runs
+    every pass, over every edge, and no aggregation is added to the backward."""
+
+    @staticmethod
+    def forward(ctx, gidx, cat, x, w_self, w_neigh, bias):
+        be = sparse.backend_for(x)
+        K = w_self.shape[0]
+        same = cat.static_key is not None and cat.static_key[0] is x and cat.static_key[1] == x._version
+        if not same or cat.static_agg is not cat.static_key:
+            cat.left.copy_(x)
+            cat.static_key = (x, x._version)
+            be.spmm_copy_u_strided(gidx.csc(), "mean", cat.left, cat.right)      # A_mean x: once per (tensor, version)
+            cat.static_agg = cat.static_key
+            cat.generation += 1
+        w = torch.cat([w_self, w_neigh], dim=0)                                   # [2K, in]
+        b2 = None if bias is None else torch.cat([bias, torch.zeros_like(bias)])
+        sz = torch.nn.functional.linear(x, w, b2)                                 # [N, 2K] = [x W_self^T + b | x W_neigh^T]
+        be.spmm_copy_u_strided(gidx.csc(), "mean", sz[:, K:], sz[:, :K], accumulate=True)
+        ctx.cat, ctx.generation = cat, cat.generation
+        return sz[:, :K]                                                           # row-strided view: relu_dropout reads it in place
+
+    @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
+    def backward(ctx, dy):
+        cat = ctx.cat
+        if cat.generation != ctx.generation:
+            raise DGLError("SAGEConv: the cached [x | mean_agg(x)] buffer was rewritten before this backward pass")
+        need = ctx.needs_input_grad
+        be = sparse.backend_for(dy)
+        if dy.stride(1) != 1:
+            dy = dy.contiguous()
+        D = cat.K
+        dws = dwn = None
+        if need[3] or need[4]:
+            dw = _weight_grad(dy, cat.buf)                                        # [K, 2 in] = dy^T [x | A_mean x]
+            dws, dwn = dw[:, :D].contiguous(), dw[:, D:].contiguous()
+        db = be.column_sum(dy if dy.is_contiguous() else dy.contiguous()) if need[5] else None
+        return None, None, None, dws, dwn, db
+
+
+def sage_static_input_project(g, x, w_self, w_neigh, bias, cat):
+    """SageMeanStaticInputProjectFn when it applies (opt-in switch, constant input, out_feats < in_feats), else None."""
+    K, D = w_self.shape
+    if (os.environ.get("MGX_SAGE_L1_PROJECT_FIRST", "0") != "1" or cat is None or x.requires_grad or type(g) is not DGLGraph
+            or g.is_block or x.dim() != 2 or x.dtype != torch.float32 or not x.is_cuda or x.device.type not in sparse._BACKENDS
+            or not torch.is_grad_enabled() or g.idtype != torch.int32 or cat.K != D or cat.buf.shape[0] != x.shape[0]
+            or g.number_of_src_nodes() != g.number_of_dst_nodes() or x.shape[0] != g.number_of_src_nodes()
+            or K % 4 or D % 4 or K >= D or _torch_ops() is not None or not _cat_eligible(g, x, cat)
+            or (bias is not None and K > sparse.backend_for(x).COLUMN_SUM_MAX) or x.shape[0] * 2 * K * 4 >= (1 << 32)):
+        return None
+    return SageMeanStaticInputProjectFn.apply(g._index, cat, x, w_self, w_neigh, bias)
 
 
 def sage_project_first(g, h, w_self, w_neigh, bias=None):

@@ -18,6 +18,9 @@ from . import _lib
 from ._lib import DGLError, MgxCsr, OP, REDUCE, TARGET
 
 
+# Every tile plan is bounds-checked once when it is built (the kernels follow its tables blindly: a wrong entry would be an
+# out-of-bounds access on the device).  A dozen reductions with host syncs per plan; MGX_TILE_VALIDATE=0 skips them.
+_VALIDATE_TILE_PLANS = os.environ.get("MGX_TILE_VALIDATE", "1") != "0"
 PROFILE = None  # set to a list by bench.py to collect per-launch HIP-event timings of mgx_spmm_csr
 TILE_MIN_WIDTH = int(os.environ.get("MGX_TILE_MIN_WIDTH", 4))  # rows of 4 .. 20 columns take the 16-column tile pass, 24 .. 44 the 32-column one, wider the 64-column one
 
@@ -118,7 +121,8 @@ class CsrView(object):
             nc, nacc, nl, tau = tileplan.gat_config()
             base = self._tile_base_plan()
             held = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=2, pair_rank=True)
-            tileplan.validate(held, self)
+            if _VALIDATE_TILE_PLANS:
+                tileplan.validate(held, self)
             self._tile_plan["gat"] = held
         return self._tile_plan["gat"]
 
@@ -137,7 +141,8 @@ class CsrView(object):
             nc, nacc, nl, tau = tileplan.config(lg)
             base = self._tile_base_plan()
             tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=lg)
-            tileplan.validate(tp, self)
+            if _VALIDATE_TILE_PLANS:
+                tileplan.validate(tp, self)
             self._tile_plan[lg] = tp
         return self._tile_plan[lg]
 
@@ -525,8 +530,9 @@ class HipBackend(object):
         return t_dst, t_src
 
     def gat_fused_fwd(self, csc, feat3d, el2d, er2d, slope, p, seed, attn_l=None, csr=None):
-        """feat3d [n_src, H, F], el2d [n_src, H], er2d [n_dst, H] -> (out [n_dst, H, F], nstat [n_dst, H, 4]).
-        csr: the out-CSR, needed to choose the tile form when p > 0 (see _gat_tile_plans)."""
+        """feat3d [n_src, H, F], el2d [n_src, H], er2d [n_dst, H] -> (out [n_dst, H, F], nstat [n_dst, H, 4], form).
+        csr: the out-CSR, needed to choose the tile form when p > 0 (see _gat_tile_plans).  `form` ("tile" | "row") is the
+        kernel family that ran: with p > 0 it fixes how the dropout mask is keyed, and the backward must be given it back."""
         dev = self._check_dev(csc.indptr, feat3d, el2d, er2d)
         H, F = int(feat3d.shape[1]), int(feat3d.shape[2])
         out = torch.empty((csc.num_rows, H, F), dtype=torch.float32, device=dev)
@@ -540,7 +546,7 @@ class HipBackend(object):
                 _lib.check(_lib.lib().mgx_gat_tile_fwd(ctypes.byref(csc.c_struct()), self._plan_ptr(tp.base), ctypes.byref(tp.c_struct()),
                                                        H, F, _ptr(feat3d), _ptr(el2d), _ptr(er2d), ctypes.c_float(slope), ctypes.c_float(p),
                                                        ctypes.c_uint64(seed), _ptr(out), _ptr(nstat), _ptr(ws), _ptr(pack), _stream(dev)))
-            return out, nstat
+            return out, nstat, "tile"
         plan = csc.plan()
         ws = self._gat_ws([plan], H, F, dev)
         pack = self._gat_pack_ws(csc, H, F, dev)
@@ -548,21 +554,29 @@ class HipBackend(object):
             _lib.check(_lib.lib().mgx_gat_fused_fwd(ctypes.byref(csc.c_struct()), self._plan_ptr(plan), H, F, _ptr(feat3d), _ptr(el2d),
                                                     _ptr(attn_l), _ptr(er2d), ctypes.c_float(slope), ctypes.c_float(p), ctypes.c_uint64(seed),
                                                     _ptr(out), _ptr(nstat), _ptr(ws), _ptr(pack), _stream(dev)))
-        return out, nstat
+        return out, nstat, "row"
 
     @staticmethod
     def _gat_pack_ws(csc, H, F, dev):
         need = _lib.lib().mgx_gat_fused_pack_workspace(csc.num_cols, csc.num_rows, H, F)
         return torch.empty(need // 4, dtype=torch.float32, device=dev) if need else None
 
-    def gat_fused_bwd(self, csc, csr, feat3d, el2d, slope, p, seed, out3d, d_out3d, nstat, need_src, attn_l=None):
-        """-> (d_feat | None, d_el | None, d_er); nstat[..., 3] is overwritten with <out, d_out> per head."""
+    def gat_fused_bwd(self, csc, csr, feat3d, el2d, slope, p, seed, out3d, d_out3d, nstat, need_src, attn_l=None, form=None):
+        """-> (d_feat | None, d_el | None, d_er); nstat[..., 3] is overwritten with <out, d_out> per head.
+        `form`: what gat_fused_fwd returned.  With p > 0 the backward runs that same kernel family or raises -- the two families
+        key the dropout mask differently (edge id / (destination, source, rank)), so re-deriving the choice here (an environment
+        switch flipped, a plan that failed to build in between) would silently apply another mask."""
         dev = self._check_dev(csc.indptr, csr.indptr, feat3d, el2d, out3d, d_out3d, nstat)
         H, F = int(feat3d.shape[1]), int(feat3d.shape[2])
         d_er = torch.empty((csc.num_rows, H), dtype=torch.float32, device=dev)
         d_feat = torch.empty_like(feat3d) if need_src else None
         d_el = torch.empty((csc.num_cols, H), dtype=torch.float32, device=dev) if need_src else None
         tiles = self._gat_tile_plans(csc, csr, H, F, p)
+        if p > 0.0 and form == "row":
+            tiles = None
+        elif p > 0.0 and form == "tile" and (tiles is None or tiles[1] is None):
+            raise DGLError("gat_fused backward: the forward pass drew its dropout mask with the tile kernels, but their plans are not "
+                           "available any more (MGX_GAT_TILE / MGX_TILE changed between forward and backward?)")
         if tiles is not None and tiles[1] is not None:
             t_dst, t_src = tiles
             if not need_src:  # the kernel's source walk is skipped when both are NULL

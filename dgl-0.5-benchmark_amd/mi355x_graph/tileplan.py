@@ -222,7 +222,9 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     # ---- edges: (tile, position in tile, source)
     e_item = torch.repeat_interleave(torch.arange(I, device=dev), lens)
     first = _excl_cumsum(lens)[:-1]
-    e_src = csr.indices[beg[e_item] + (torch.arange(E, device=dev) - first[e_item])].long()
+    # E-sized temporaries are kept as narrow as their range allows and freed as soon as their last reader is past (reddit has
+    # 115 M edges and up to five plans per graph: a dozen live int64 arrays were > 10 GB of transient memory)
+    e_src = csr.indices[beg[e_item] + (torch.arange(E, device=dev) - first[e_item])]  # the CSR's own index type
     e_rank = None
     if pair_rank:  # rank of every edge among the edges of its (row, source) pair, by edge id
         node = (base.item_node if base is not None and base.item_node is not None else item_row).long()
@@ -233,13 +235,14 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         order = o1[o2]
         runs = torch.unique_consecutive(pk, return_counts=True)[1]  # (torch.cummax over 115 M elements takes 0.36 s on this stack)
         run0 = torch.repeat_interleave(_excl_cumsum(runs)[:-1], runs)
-        e_rank = torch.empty(E, dtype=torch.int64, device=dev)
-        e_rank[order] = torch.arange(E, device=dev) - run0
+        e_rank = torch.empty(E, dtype=torch.int32, device=dev)
+        e_rank[order] = (torch.arange(E, device=dev) - run0).to(torch.int32)
         del pk, o1, o2, order, runs, run0, node, eid, e_csr
-    e_tile, e_pos = it_tile[e_item], pos[e_item]
+    e_tile, e_pos = it_tile[e_item], pos[e_item].to(torch.int32)
     del e_item, first
+    tile_edges = torch.bincount(e_tile, minlength=T) if os.environ.get("MGX_TILE_LPT", "0") == "1" else None
     # ---- sources gathered >= tau times inside a tile are staged; per tile they are ordered by multiplicity (dense chunks first)
-    skey, perm = torch.sort(e_tile * n_src + e_src)
+    skey, perm = torch.sort(e_tile * n_src + e_src.long())
     uniq, inv, counts = torch.unique_consecutive(skey, return_inverse=True, return_counts=True)
     del skey
     g_tile, g_src = uniq // n_src, uniq % n_src
@@ -263,14 +266,15 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     grp_chunk[sel], grp_slot[sel] = s_chunk, s_slot
     # back to storage order of the edges (so that the streams keep it inside every lane group)
     e_chunk = torch.empty(E, dtype=torch.int64, device=dev)
-    e_slot = torch.empty(E, dtype=torch.int64, device=dev)
-    e_chunk[perm], e_slot[perm] = grp_chunk[inv], grp_slot[inv]
-    del perm, inv, grp_chunk, grp_slot, uniq
+    e_slot = torch.empty(E, dtype=torch.int16, device=dev)   # < 256 LDS slots per chunk
+    e_chunk[perm], e_slot[perm] = grp_chunk[inv], grp_slot[inv].to(torch.int16)
+    del perm, inv, grp_chunk, grp_slot, uniq, g_tile
     staged = e_chunk >= 0
     # ---- LDS streams: rows (chunk, cw, j), laid out per (tile, consumer wave) -- contiguous over the chunks of the tile, so the
     # kernel's prefetch of the next supersteps runs through chunk boundaries
     per_unit = NC * NACC * GROUPS
     sk = e_chunk[staged] * per_unit + e_pos[staged]
+    del e_chunk
     nseg = NCH * NC * NACC
     seg = torch.arange(nseg, device=dev)
     seg_chunk, seg_cw = seg // (NC * NACC), (seg // NACC) % NC
@@ -284,13 +288,16 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     lds16 = None
     max_rank = int(e_rank.max()) if e_rank is not None and E else 0
     if e_rank is not None:  # the same stream with 16-bit entries: slot | (rank mod 128) << 8
-        lds16 = _streams(sk, nseg, e_slot[staged] + ((e_rank[staged] & 127) << 8), ZERO_SLOT, torch.int16, seg_order, GROUPS, bank_classes)[3]
+        lds16 = _streams(sk, nseg, e_slot[staged].long() + ((e_rank[staged].long() & 127) << 8), ZERO_SLOT, torch.int16, seg_order,
+                         GROUPS, bank_classes)[3]
+    del sk, e_slot
     # ---- direct streams: one per (tile, consumer wave)
     direct = ~staged
     dk = e_tile[direct] * per_unit + e_pos[direct]
-    dir_payload = e_src[direct]
+    dir_payload = e_src[direct].to(torch.int32)
     if e_rank is not None and n_src < (1 << 24):
         dir_payload = dir_payload | ((e_rank[direct] & 127) << 24)
+    del e_tile, e_pos, e_src, direct
     dir_cnt, dir_base, dir_total, dir_stream = _streams(dk, T * NC * NACC, dir_payload, -1, torch.int32, None, GROUPS)
     dir_off = torch.cat([dir_base.view(-1)[::NACC], torch.tensor([dir_total], device=dev)])
     if int(lds_cnt.max() if lds_cnt.numel() else 0) > 65535:
@@ -325,7 +332,7 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         "zero_row": torch.zeros(64, dtype=torch.float32, device=dev),
         "tile_node": tile_node,
         "lds_stream16": None if lds16 is None else lds16.view(torch.int32),  # [lds_supersteps * groups * 2] words: 4 x (slot | rank << 8)
-        "tile_order": _longest_first(torch.bincount(e_tile, minlength=T), T) if os.environ.get("MGX_TILE_LPT", "0") == "1" else None,
+        "tile_order": _longest_first(tile_edges, T) if tile_edges is not None else None,
     }
     if lds_total * 4 >= 2 ** 31 or dir_total * 16 >= 2 ** 31:
         raise ValueError("tile plan: stream offsets exceed 31 bits")

@@ -350,6 +350,69 @@ def test_last_layer_backward_on_the_loss_rows_only_changes_nothing(monkeypatch):
             assert float((a_ - b_).abs().max()) < 2e-4 * float(b_.abs().max()) + 1e-7
 
 
+def test_first_layer_projected_before_its_aggregation_changes_nothing(monkeypatch):
+    """MGX_SAGE_L1_PROJECT_FIRST=1: layer 1 of the products model as x W_self^T + mean_agg(x W_neigh^T) -- the
+    aggregation at 64 columns instead of 100 -- with dW_neigh taken against the cached constant mean_agg(x)
+    (ops.SageMeanStaticInputProjectFn): same loss and the same parameter gradients as the default model over three steps with
+    dropout on, every epoch still running its five aggregations, and a changed input is noticed."""
+    sys.path.insert(0, PKG)
+    import full_graph
+    from mi355x_graph import sparse
+    n = 70000
+    src, dst = random_graph(n, n, 14 * n, seed=13, skew=True)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().formats(["csr", "csc"]).to(DEV)
+    torch.manual_seed(0)
+    x = torch.rand(n, 100, device=DEV)
+    y = torch.randint(0, 47, (n,), device=DEV)
+    idx = torch.nonzero(torch.rand(n, device=DEV) < 0.08).flatten()
+    runs, launches = [], []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MGX_SAGE_L1_PROJECT_FIRST", flag)
+        torch.manual_seed(77)
+        ops.ReluDropout._calls = 0
+        m = full_graph.GraphSAGE(100, 64, 47, 3, 0.5).to(DEV)
+        m.rows_are_distinct = True
+        m.train()
+        opt = torch.optim.SGD(m.parameters(), lr=0.05)
+        out = []
+        for step in range(3):
+            opt.zero_grad()
+            sparse.PROFILE = []
+            loss = ops.nll_sum(m(g, x, rows=idx), y[idx]) / idx.shape[0]
+            loss.backward()
+            recs, sparse.PROFILE = sparse.PROFILE, None
+            launches.append((flag, step, sorted(r["out_len"] for r in recs)))
+            out.append((float(loss), [p.grad.clone() for p in m.parameters()]))
+            opt.step()
+        runs.append(out)
+    for (l1, g1), (l2, g2) in zip(*runs):
+        assert abs(l1 - l2) < 1e-5 * abs(l2)
+        for a_, b_ in zip(g1, g2):
+            assert float((a_ - b_).abs().max()) < 2e-4 * float(b_.abs().max()) + 1e-7
+    # five aggregations per epoch either way; the switch turns the 100-column one into a 64-column one (+ the one-off constant)
+    assert [w for f, s_, w in launches if f == "0"] == [[64, 64, 64, 64, 100]] * 3
+    assert [w for f, s_, w in launches if f == "1"] == [[64, 64, 64, 64, 64, 100]] + [[64, 64, 64, 64, 64]] * 2
+    # an in-place change of the features is noticed (version counter): the constant is aggregated again
+    monkeypatch.setenv("MGX_SAGE_L1_PROJECT_FIRST", "1")
+    x.mul_(0.5)
+    sparse.PROFILE = []
+    loss2 = ops.nll_sum(m(g, x, rows=idx), y[idx]) / idx.shape[0]
+    loss2.backward()
+    recs, sparse.PROFILE = sparse.PROFILE, None
+    assert sorted(r["out_len"] for r in recs) == [64, 64, 64, 64, 64, 100]
+    monkeypatch.setenv("MGX_SAGE_L1_PROJECT_FIRST", "0")
+    m0 = full_graph.GraphSAGE(100, 64, 47, 3, 0.0).to(DEV)
+    m0.load_state_dict(m.state_dict())
+    m.eval(), m0.eval()
+    monkeypatch.setenv("MGX_SAGE_L1_PROJECT_FIRST", "1")
+    with torch.no_grad():
+        a = m(g, x)
+    monkeypatch.setenv("MGX_SAGE_L1_PROJECT_FIRST", "0")
+    with torch.no_grad():
+        b = m0(g, x)
+    assert float((a - b).abs().max()) < 1e-4 * max(1.0, float(b.abs().max()))
+
+
 def test_strided_copy_u_and_relu_dropout_match_the_dense_calls(oracle):
     n, D = 3000, 64
     src, dst = random_graph(n, n, 40000, seed=2, skew=True)
