@@ -457,17 +457,21 @@ class DistSageMeanCatFn(torch.autograd.Function):
             work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
             comm.mark("owned-row reversed aggregation")
             be.spmm_copy_u_strided(plan.loc.csr(), "sum", dn, dcat[:, :K], accumulate=True)
-            work.wait()
-            comm.mark("return-add")
-            if back.shape[0]:  # row v += the returned rows whose owner is v: copy_u over (owned row -> position in `back`)
-                be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dcat[:, :K], accumulate=True)
-            dh = dcat[:, :K]
-            comm.mark("dense")
+        # the parameter gradients need nothing from the peers: formed while the halo-row gradients travel (the scaling model,
+        # profiles/r04_scale_model.txt, has the exchange at 2x the reversed aggregation it used to hide behind at P = 8)
+        comm.mark("dense (inside the exchange window)")
         dws = dwn = None
         if need[4] or need[5]:
             dw = ops._weight_grad(dy, cat.buf)
             dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
         db = be.column_sum(dy) if need[6] else None
+        if need[3]:
+            work.wait()
+            comm.mark("return-add")
+            if back.shape[0]:  # row v += the returned rows whose owner is v: copy_u over (owned row -> position in `back`)
+                be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dcat[:, :K], accumulate=True)
+            dh = dcat[:, :K]
+        comm.mark("dense")
         return None, None, None, dh, dws, dwn, db, None
 
 

@@ -278,9 +278,10 @@ def _ms(a, b):
     return a.elapsed_time(b) if hasattr(a, "elapsed_time") else (b - a) * 1e3
 
 
-def mean_epoch(traces):
+def typical_epoch(traces):
     """One rank's traces of K identical epochs (start_trace() ... stop_trace() around each; device synchronised since) ->
-    the mean epoch as stages in program order, one per collective plus the tail:
+    the typical epoch -- per stretch the MEDIAN over the K epochs, so that one host stall (an allocator refill, a lazily built
+    table) in one epoch does not pass for device work -- as stages in program order, one per collective plus the tail:
         {"kind", "info", "pre": {label: ms}, "window": {label: ms}}     work before the post / between post and wait
         {"kind": None, "pre": {label: ms}}                               what follows the last collective
     Posts and waits must nest one at a time (post k, work, wait k) -- what dist.py issues."""
@@ -292,11 +293,11 @@ def mean_epoch(traces):
                 cur[it[1]] = cur.get(it[1], 0.0) + _ms(it[2], it[3])
             elif it[0] == "post":
                 if open_post is not None:
-                    raise EmuError("mean_epoch: collective #%d posted while #%d is still open" % (it[2], open_post[2]))
+                    raise EmuError("typical_epoch: collective #%d posted while #%d is still open" % (it[2], open_post[2]))
                 open_post, pre, cur = it, cur, {}
             else:
                 if open_post is None or open_post[2] != it[2]:
-                    raise EmuError("mean_epoch: wait on #%d without its post" % (it[2],))
+                    raise EmuError("typical_epoch: wait on #%d without its post" % (it[2],))
                 stages.append({"kind": open_post[1], "info": open_post[3], "pre": pre, "window": cur})
                 open_post, cur = None, {}
         stages.append({"kind": None, "pre": cur})
@@ -304,8 +305,12 @@ def mean_epoch(traces):
     shape = [s["kind"] for s in epochs[0]]
     for e in epochs[1:]:
         if [s["kind"] for s in e] != shape:
-            raise EmuError("mean_epoch: the epochs of one rank issue different collectives")
-    K = float(len(epochs))
+            raise EmuError("typical_epoch: the epochs of one rank issue different collectives")
+    def median(vals):
+        v = sorted(vals)
+        h = len(v) // 2
+        return v[h] if len(v) % 2 else 0.5 * (v[h - 1] + v[h])
+
     out = []
     for i, st in enumerate(epochs[0]):
         m = {"kind": st["kind"], "info": st.get("info")}
@@ -314,13 +319,13 @@ def mean_epoch(traces):
                 labels = []
                 for e in epochs:
                     labels += [l for l in e[i][part] if l not in labels]
-                m[part] = {l: sum(e[i][part].get(l, 0.0) for e in epochs) / K for l in labels}
+                m[part] = {l: median([e[i][part].get(l, 0.0) for e in epochs]) for l in labels}
         out.append(m)
     return out
 
 
 def price_epoch(ranks, link_gbps, latency_us=10.0, allreduce_us=40.0, overlap=True):
-    """Lock-step replay of every rank's mean epoch with the collectives PRICED instead of emulated.
+    """Lock-step replay of every rank's typical epoch with the collectives PRICED instead of emulated.
 
     all_to_all: the slice q -> r rides its own xGMI link (MI355X: every pair of the 8 GPUs is linked, full duplex): it starts
     once BOTH ranks have posted, takes latency + bytes / link rate, and a rank's collective is complete when everything it

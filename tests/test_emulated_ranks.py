@@ -105,7 +105,7 @@ def test_trace_and_priced_epoch():
     ser = emulate.price_epoch(ranks, 1.0, latency_us=0.0, allreduce_us=0.0, overlap=False)
     assert abs(ser["epoch_ms"] - (0.1 + 0.5 + 0.512 + 1.0 + 0.3)) < 1e-9
 
-    # a real trace on the CPU clock: structure and labels survive mean_epoch
+    # a real trace on the CPU clock: structure and labels survive typical_epoch
     def body(rank):
         ctx = emulate.current()
         traces = []
@@ -120,7 +120,7 @@ def test_trace_and_priced_epoch():
             comm.mark("after")
             mdist.all_reduce(torch.ones(1))
             traces.append(ctx.stop_trace())
-        return emulate.mean_epoch(traces)
+        return emulate.typical_epoch(traces)
 
     tl = emulate.EmuWorld(2).run(body)
     assert [s["kind"] for s in tl[0]] == ["all_to_all", "all_reduce", None]
