@@ -15,6 +15,7 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with its own 4 MiB L2
 
 void set_error(const char* fmt, ...);
+void note_spmm_kernel(const char* name);  // mgx_last_spmm_kernel(): which kernel family a g-SpMM call was routed to
 
 #define MGX_CHECK_ARG(cond, ...)                    \
   do {                                              \

@@ -69,7 +69,13 @@ static void coo_to_csr_host_impl(int64_t n_rows, int64_t nnz, const Idx* row, co
 
 extern "C" const char* mgx_last_error(void) { return mgx::g_err; }
 
-extern "C" int32_t mgx_abi_version(void) { return 21; }
+extern "C" int32_t mgx_abi_version(void) { return 22; }
+
+namespace mgx {
+static thread_local const char* g_last_spmm_kernel = "";
+void note_spmm_kernel(const char* name) { g_last_spmm_kernel = name; }
+}  // namespace mgx
+extern "C" const char* mgx_last_spmm_kernel(void) { return mgx::g_last_spmm_kernel; }
 
 extern "C" int32_t mgx_device_info(int32_t* num_cus, int32_t* lds_bytes_per_cu, char* arch_name, int32_t arch_name_len) {
   using namespace mgx;

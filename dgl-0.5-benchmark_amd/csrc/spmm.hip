@@ -535,6 +535,149 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// spmm_rowgroup32_kernel (round 4): SHORT rows -- one work item per LANE GROUP, 64 / G items per wave at a time.
+// The row-per-wave kernel above spends one dependent chain (item -> ids -> gathers -> store, ~6 us from beyond L2) per row
+// whatever its length up to 16 edges; the CSRs of a partition's halo (mi355x_graph/dist.py: 3.4 edges per row backward, 11
+// forward, profiles/r04_scale_model.txt), of arxiv-shaped graphs (6.9) and of batched molecules (2.2) are all of that kind and
+// run latency-bound on it.  Here a lane group of G lanes owns an item: its lanes load the item's first G ids with one
+// coalesced access, the ids travel inside the group through ds_bpermute, and the group gathers its row's neighbours U at a
+// time with 16-byte lanes along the feature dimension -- 64 / G chains per wave instead of one, and no cross-group reduction
+// at the end.  Terms are added in storage order (exactly the CPU oracle's order for rows that are not split).
+// COPY_LHS / COPY_RHS, sum / mean, dst_scale, accumulate, row strides, plan items with partial slots; int32 ids, gathered
+// matrix below 4 GiB, D % 4 == 0.  The next batch's bounds and ids are requested before the current batch's gathers.
+template <int VEC, int G, int MODE, bool LANEMASK>
+__global__ __launch_bounds__(kBlock) void spmm_rowgroup32_kernel(const SpmmFastArgs<int32_t> a) {
+  typedef typename VecT<VEC>::type V;
+  constexpr int NB = kWave / G;
+  constexpr int U = 4;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int sub = lane / G;
+  const int l = lane % G;
+  const int f = (blockIdx.y * G + l) * VEC;
+  const bool factive = LANEMASK ? (f < a.D) : true;
+  int64_t item_base, item_stop;
+  xcd_stretch(a.xcd, item_base, item_stop);
+  item_base += (int64_t)(blockIdx.x / kXcds) * a.rpb;
+  const uint32_t rowbytes = (uint32_t)a.lds * 4u;
+  const uint32_t f4 = factive ? (uint32_t)f * 4u : (uint32_t)(blockIdx.y * G * VEC) * 4u;  // idle lanes re-read column 0 of the pass
+  const char* __restrict__ srcb = reinterpret_cast<const char*>(a.src);
+  const int gbase = sub * G;
+
+  auto load_meta = [&](int r, bool& ok, int64_t& row, int32_t& beg, int32_t& end) {
+    const int64_t item = item_base + r;
+    ok = r < a.rpb && item < item_stop;
+    row = 0; beg = 0; end = 0;
+    if (ok) {
+      if (a.item_row) {
+        row = (int64_t)a.item_row[item];
+        beg = a.item_beg[item];
+        end = a.item_end[item];
+      } else {
+        row = item;
+        beg = a.indptr[item];
+        end = a.indptr[item + 1];
+      }
+    }
+  };
+  auto load_ids = [&](int32_t base, int32_t end) -> uint32_t {  // lane l of the group: byte offset of neighbour base + l
+    const int32_t q = base + l;
+    uint32_t goff = 0;
+    if (q < end) {
+      int32_t gid;
+      if (MODE == MODE_COPY_RHS) gid = a.eids ? __builtin_nontemporal_load(&a.eids[q]) : q;
+      else gid = __builtin_nontemporal_load(&a.indices[q]);
+      goff = (uint32_t)gid * rowbytes;
+    }
+    return goff;
+  };
+
+  int r = wave * NB + sub;  // this group's item inside the workgroup's stretch; batches of kWavesPerBlock * NB items
+  bool ok;
+  int64_t row;
+  int32_t beg, end;
+  load_meta(r, ok, row, beg, end);
+  uint32_t goff = load_ids(beg, end);
+  for (;;) {
+    const int rn = r + kWavesPerBlock * NB;
+    const bool more = __builtin_amdgcn_readfirstlane(rn - sub) < a.rpb && item_base + (rn - sub) < item_stop;  // wave-uniform
+    bool nok = false;
+    int64_t nrow = 0;
+    int32_t nbeg = 0, nend = 0;
+    uint32_t ngoff = 0;
+    if (more) {
+      load_meta(rn, nok, nrow, nbeg, nend);
+      ngoff = load_ids(nbeg, nend);
+    }
+    V acc = (V)(0.f);
+    int32_t cbase = beg;
+    for (;;) {  // chunks of G edges; wave-uniform trip count (the longest item of the batch), per-group predicates inside
+      const int cnt = (end - cbase) < G ? (end - cbase) : G;
+      for (int k = 0; k < G; k += U) {
+        if (__builtin_amdgcn_ballot_w64(k < cnt) == 0) break;
+        V val[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool live = k + u < cnt;
+          const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + (live ? k + u : 0)) * 4, (int)goff) + f4;
+          val[u] = (V)(0.f);
+          if (live) val[u] = *reinterpret_cast<const V*>(srcb + off);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += val[u];
+      }
+      cbase += G;
+      if (__builtin_amdgcn_ballot_w64(cbase < end) == 0) break;
+      goff = load_ids(cbase, end);
+    }
+    if (ok && factive) {
+      if (row >= 0) {
+        if (a.mean) {
+          const int deg = end - beg;
+          acc = acc / (float)(deg > 1 ? deg : 1);
+        }
+        if (a.dst_scale) acc = acc * a.dst_scale[row];
+        float* op = a.out + row * (int64_t)a.ldo + f;
+        if (a.accum) acc += *reinterpret_cast<const V*>(op);
+        __builtin_nontemporal_store(acc, reinterpret_cast<V*>(op));
+      } else {
+        *reinterpret_cast<V*>(a.partial + (-(row + 1)) * (int64_t)a.D + f) = acc;
+      }
+    }
+    if (!more) break;
+    r = rn;
+    ok = nok; row = nrow; beg = nbeg; end = nend; goff = ngoff;
+  }
+}
+
+template <int VEC, int G, int MODE>
+static bool launch_rowgroup32(SpmmFastArgs<int32_t> a, int64_t nnz, hipStream_t s) {
+  // MGX_ROWGROUP: 0 = never, 1 = whenever eligible (A/B runs: experiments/exp_rowgroup.py); default: work items shorter on
+  // average than 3 edges per lane group of the wave, at most 16 -- measured on MI355X (profiles/r04_rowgroup.txt, uniform random
+  // sources): 3.4 edges per row D = 64 0.39 -> 0.19 ms, D = 16 0.27 -> 0.08 ms; 6.9 per row (arxiv shape) D = 64 69 -> 55 us,
+  // D = 16 56 -> 26 us, but D = 100 / 128 (two groups per wave) 100 -> 102 us; 11 per row: equal at D = 64 (both at the fabric's
+  // random-gather rate), better below; from 20 per row on the row-per-wave kernel wins at every width.
+  static const int env = getenv("MGX_ROWGROUP") ? atoi(getenv("MGX_ROWGROUP")) : -1;
+  constexpr int NB = kWave / G;
+  const double max_avg = NB >= 8 ? 16.0 : 3.0 * NB;
+  if constexpr (NB < 2 || VEC != 4 || MODE == MODE_MUL_EDGE) {
+    return false;
+  } else {
+    if (env == 0 || a.ragged || a.src_scale || a.src_bits || a.D % 4 != 0) return false;
+    if (a.src_rows * (int64_t)a.lds * 4 >= (int64_t(1) << 32) || getenv("MGX_SPMM_V1") != nullptr) return false;
+    if (env != 1 && (a.n_items == 0 || (double)nnz / (double)a.n_items >= max_avg)) return false;
+    note_spmm_kernel("rowgroup32");
+    a.rpb = 2 * kWavesPerBlock * NB;  // two batches per wave: the second's ids travel under the first's gathers
+    const dim3 grid((unsigned)xcd_ranges(a.plan, a.n_items, a.rpb, a.xcd), (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
+    if (a.D % (G * VEC) != 0) hipLaunchKernelGGL((spmm_rowgroup32_kernel<VEC, G, MODE, true>), grid, dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((spmm_rowgroup32_kernel<VEC, G, MODE, false>), grid, dim3(kBlock), 0, s, a);
+    return true;
+  }
+}
+template <int VEC, int G, int MODE>
+static bool launch_rowgroup32(SpmmFastArgs<int64_t>, int64_t, hipStream_t) { return false; }
+
 // Sums the partial slots of every split (hub) row in slot order -- deterministic -- and applies
 // the mean / dst_scale epilogue.  One wave per hub row, lanes along the feature dimension.
 template <typename Idx>
@@ -684,18 +827,20 @@ template <int VEC, int G, int MODE>
 static bool launch_rowwave32(const SpmmFastArgs<int64_t>&, int64_t, dim3, hipStream_t) { return false; }
 
 template <typename Idx, int VEC, int G, int MODE>
-static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, hipStream_t s) {
+static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, int64_t nnz, hipStream_t s) {
   constexpr int NB = kWave / G;
   if (a.ragged) split = true;  // only the lean row-per-wave kernel implements the ragged 16-byte tail window
   if (a.lds != a.D || a.ldo != a.D) split = true;  // ... and row strides (spmm_fast_kernel ignores lds / ldo; MGX_SPLIT_FACTOR A/B runs)
+  if (launch_rowgroup32<VEC, G, MODE>(a, nnz, s)) return;  // short rows: one item per lane group (lean, int32)
   a.rpb = rows_per_block_setting();
   if (!split && a.rpb < kWavesPerBlock * NB) a.rpb = kWavesPerBlock * NB;  // one item per lane group
   a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);
   dim3 grid((unsigned)a.nblocks, (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
   {  // lean kernel: per-XCD stretches of the schedule
     const dim3 lgrid((unsigned)xcd_ranges(a.plan, a.n_items, a.rpb, a.xcd), grid.y);
-    if (split && launch_rowwave32<VEC, G, MODE>(a, a.src_rows, lgrid, s)) return;
+    if (split && launch_rowwave32<VEC, G, MODE>(a, a.src_rows, lgrid, s)) { note_spmm_kernel("rowwave32"); return; }
   }
+  note_spmm_kernel(split ? "rowwave" : "fast");
   if (split) hipLaunchKernelGGL((spmm_rowwave_kernel<Idx, VEC, G, MODE>), grid, dim3(kBlock), 0, s, a);
   else hipLaunchKernelGGL((spmm_fast_kernel<Idx, VEC, G, MODE, false>), grid, dim3(kBlock), 0, s, a);
 }
@@ -728,13 +873,13 @@ static void launch_fast_v(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s
   const double split_factor = env_factor >= 0.0 ? env_factor : (lean ? 0.0 : 2.0);
   const bool split = (NB == 1) || (avg_deg >= split_factor * NB);
   switch (G) {
-    case 1: launch_fast_g<Idx, VEC, 1, MODE>(a, split, s); break;
-    case 2: launch_fast_g<Idx, VEC, 2, MODE>(a, split, s); break;
-    case 4: launch_fast_g<Idx, VEC, 4, MODE>(a, split, s); break;
-    case 8: launch_fast_g<Idx, VEC, 8, MODE>(a, split, s); break;
-    case 16: launch_fast_g<Idx, VEC, 16, MODE>(a, split, s); break;
-    case 32: launch_fast_g<Idx, VEC, 32, MODE>(a, split, s); break;
-    default: launch_fast_g<Idx, VEC, 64, MODE>(a, split, s); break;
+    case 1: launch_fast_g<Idx, VEC, 1, MODE>(a, split, nnz, s); break;
+    case 2: launch_fast_g<Idx, VEC, 2, MODE>(a, split, nnz, s); break;
+    case 4: launch_fast_g<Idx, VEC, 4, MODE>(a, split, nnz, s); break;
+    case 8: launch_fast_g<Idx, VEC, 8, MODE>(a, split, nnz, s); break;
+    case 16: launch_fast_g<Idx, VEC, 16, MODE>(a, split, nnz, s); break;
+    case 32: launch_fast_g<Idx, VEC, 32, MODE>(a, split, nnz, s); break;
+    default: launch_fast_g<Idx, VEC, 64, MODE>(a, split, nnz, s); break;
   }
 }
 
@@ -864,6 +1009,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
   g.u_off = u_off; g.e_off = e_off; g.src_scale = src_scale; g.dst_scale = dst_scale; g.out = out;
   g.arg_u = (Idx*)arg_u; g.arg_e = (Idx*)arg_e; g.n_rows = n_rows; g.nblocks = nblocks;
   g.u_len = u_len; g.e_len = e_len; g.out_len = out_len; g.op = op; g.reduce = reduce; g.accum = accumulate;
+  note_spmm_kernel("generic");
   hipLaunchKernelGGL((spmm_generic_kernel<Idx>), dim3((unsigned)nblocks), dim3(kBlock), 0, s, g);
   MGX_CHECK_LAUNCH();
   return MGX_OK;

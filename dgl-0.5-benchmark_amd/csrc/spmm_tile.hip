@@ -788,6 +788,7 @@ extern "C" int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan*
                     tp->loaders, tp->nacc);
   }
   MGX_CHECK_LAUNCH();
+  note_spmm_kernel("tile");
   if (hubs) return spmm_hub_fixup_launch(csr, plan, partial_ws, dst_scale, out, a.D, a.mean, a.accum, a.ldo, s);
   return MGX_OK;
 }

@@ -40,6 +40,7 @@ _csr_p = ctypes.POINTER(MgxCsr)
 SIGNATURES = {
     "mgx_last_error": (ctypes.c_char_p, []),
     "mgx_abi_version": (_i32, []),
+    "mgx_last_spmm_kernel": (ctypes.c_char_p, []),
     "mgx_device_info": (_i32, [ctypes.POINTER(_i32), ctypes.POINTER(_i32), ctypes.c_char_p, _i32]),
     "mgx_spmm_plan_workspace": (_i64, [_i64]),
     "mgx_spmm_plan_count": (_i32, [_csr_p, _i64, _vp, _vp, _vp, _i64, _vp]),

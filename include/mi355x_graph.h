@@ -122,6 +122,9 @@ int32_t mgx_spmm_plan_fill(const mgx_csr* csr, int64_t split, const void* row_or
 const char* mgx_last_error(void);
 /* ABI version, bumped on any signature change. */
 int32_t mgx_abi_version(void);
+/* Name of the kernel family the calling thread's last g-SpMM entry point launched ("rowwave32", "rowgroup32", "rowwave", "fast",
+ * "generic", "tile"; "" before the first call): which of the schedules a CSR / width was routed to -- for tests and tuning. */
+const char* mgx_last_spmm_kernel(void);
 /* Fills *num_cus / *lds_bytes of the current HIP device; MGX_ERR_HIP when no GPU is usable. */
 int32_t mgx_device_info(int32_t* num_cus, int32_t* lds_bytes_per_cu, char* arch_name, int32_t arch_name_len);
 

@@ -1,0 +1,129 @@
+"""GPU suite: the short-row g-SpMM (spmm_rowgroup32_kernel, csrc/spmm.hip, round 4) -- one work item per lane group.
+
+Chosen by the library for CSRs whose work items average fewer than 14 edges: the halo CSRs of a partition (dist.py), arxiv-
+shaped graphs (kernel/dgl-new.py:61), batched molecules (main_dgl_molhiv_gcn.py:46).  Against the CPU oracle through the C ABI;
+rows that are not split are summed in storage order, i.e. BIT-EXACT against the oracle's sequential fp32 sum."""
+import numpy as np
+import pytest
+import torch
+
+import mi355x_graph as mg
+from mi355x_graph import _lib, ops, sparse
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def last_kernel():
+    return _lib.lib().mgx_last_spmm_kernel().decode()
+
+
+def expected_kernel(D, nnz, n_items):
+    """The library's policy (csrc/spmm.hip launch_rowgroup32): items shorter on average than 3 edges per lane group, at most 16."""
+    lanes, G = (D + 3) // 4, 1
+    while G < lanes and G < 64:
+        G *= 2
+    nb = 64 // G
+    return "rowgroup32" if nb >= 2 and nnz / max(n_items, 1) < (16.0 if nb >= 8 else 3.0 * nb) else "rowwave32"
+
+
+def short_row_graph(n_src, n_dst, avg, seed, hubs=2):
+    """Mostly short rows (Poisson around `avg`, many empty), a few hub rows beyond the split threshold, duplicates."""
+    rng = np.random.default_rng(seed)
+    deg = rng.poisson(avg, n_dst)
+    deg[rng.integers(0, n_dst, max(1, n_dst // 10))] = 0
+    for h in rng.integers(0, n_dst, hubs):
+        deg[h] = int(rng.integers(300, 900))
+    dst = np.repeat(np.arange(n_dst), deg)
+    src = rng.integers(0, n_src, dst.shape[0])
+    perm = rng.permutation(dst.shape[0])          # edge ids are not in CSR order
+    return src[perm].astype(np.int64), dst[perm].astype(np.int64), deg
+
+
+@pytest.mark.parametrize("D", [4, 8, 16, 32, 64, 100, 128])
+@pytest.mark.parametrize("avg", [1.5, 3.4, 11.0])
+def test_short_rows_copy_u_against_the_oracle(oracle, D, avg):
+    n_src, n_dst = 5000, 7000
+    src, dst, deg = short_row_graph(n_src, n_dst, avg, seed=int(D * 10 + avg))
+    g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=torch.int32, device=DEV)
+    rng = np.random.default_rng(D)
+    X = rng.standard_normal((n_src, D)).astype(np.float32)
+    ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
+    x = torch.from_numpy(X).to(DEV)
+    small = deg <= 256                              # rows that are one work item: summed in storage order
+    pl = g._index.csc().plan()
+    n_items = pl.num_items if pl is not None else n_dst
+    want_kernel = expected_kernel(D, src.shape[0], n_items)
+    assert want_kernel == "rowgroup32" or (avg > 6 and D > 64)
+    for red in ("sum", "mean"):
+        out = ops.gspmm(g, "copy_lhs", red, x, None).cpu().numpy()
+        assert last_kernel() == want_kernel, (last_kernel(), want_kernel)
+        ref = oracle.spmm(ip, ix, ei, "copy_lhs", red, X, None)
+        if want_kernel == "rowgroup32":
+            assert np.array_equal(out[small], ref[small]), (D, avg, red)
+        scale = oracle.spmm(ip, ix, ei, "copy_lhs", red, np.abs(X), None)
+        assert bool((np.abs(out - ref) <= 1e-4 * scale + 1e-30).all())
+        assert float(np.abs(out[deg == 0]).sum()) == 0.0
+    # accumulate + dst_scale + bitwise rerun
+    csc = g._index.csc()
+    base = torch.from_numpy(rng.standard_normal((n_dst, D)).astype(np.float32)).to(DEV)
+    sc = torch.from_numpy(rng.random(n_dst).astype(np.float32) + 0.5).to(DEV)
+    acc = base.clone()
+    sparse.gspmm_raw(csc, "copy_lhs", "sum", x, None, dst_scale=sc, accumulate_into=acc)
+    assert last_kernel() == want_kernel
+    want = base.cpu().numpy() + oracle.spmm(ip, ix, ei, "copy_lhs", "sum", X, None) * sc.cpu().numpy()[:, None]
+    assert float(np.abs(acc.cpu().numpy() - want).max()) <= 1e-4 * max(1.0, float(np.abs(want).max()))
+    acc2 = base.clone()
+    sparse.gspmm_raw(csc, "copy_lhs", "sum", x, None, dst_scale=sc, accumulate_into=acc2)
+    assert torch.equal(acc, acc2)
+
+
+def test_short_rows_strided_operands_and_copy_e(oracle):
+    n_src, n_dst, D = 6000, 9000, 64
+    src, dst, deg = short_row_graph(n_src, n_dst, 3.4, seed=5)
+    g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=torch.int32, device=DEV)
+    csc = g._index.csc()
+    be = sparse.backend_for(csc.indptr)
+    rng = np.random.default_rng(1)
+    wide_in = torch.from_numpy(rng.standard_normal((n_src, 2 * D + 8)).astype(np.float32)).to(DEV)
+    wide_out = torch.zeros(n_dst, 3 * D, device=DEV)
+    be.spmm_copy_u_strided(csc, "mean", wide_in[:, D:2 * D], wide_out[:, D:2 * D])
+    assert last_kernel() == "rowgroup32"
+    ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
+    ref = oracle.spmm(ip, ix, ei, "copy_lhs", "mean", wide_in[:, D:2 * D].contiguous().cpu().numpy(), None)
+    got = wide_out.cpu().numpy()
+    assert np.array_equal(got[:, D:2 * D][deg <= 256], ref[deg <= 256])
+    assert float(np.abs(got[:, :D]).sum()) == 0.0 and float(np.abs(got[:, 2 * D:]).sum()) == 0.0   # nothing written beside the block
+    be.spmm_copy_u_strided(csc, "sum", wide_in[:, D:2 * D], wide_out[:, D:2 * D], accumulate=True)
+    ref2 = ref + oracle.spmm(ip, ix, ei, "copy_lhs", "sum", wide_in[:, D:2 * D].contiguous().cpu().numpy(), None)
+    assert float(np.abs(wide_out[:, D:2 * D].cpu().numpy() - ref2).max()) <= 1e-4 * float(np.abs(ref2).max())
+    # copy_e / sum: rows of an edge matrix addressed by edge id (main_dgl_molhiv_gcn.py:46 after the UDF message)
+    E = rng.standard_normal((src.shape[0], 32)).astype(np.float32)
+    out = ops.gspmm(g, "copy_rhs", "sum", None, torch.from_numpy(E).to(DEV)).cpu().numpy()
+    assert last_kernel() == "rowgroup32"
+    ref_e = oracle.spmm(ip, ix, ei, "copy_rhs", "sum", None, E)
+    assert np.array_equal(out[deg <= 256], ref_e[deg <= 256])
+    assert float(np.abs(out - ref_e).max()) <= 1e-4 * float(np.abs(ref_e).max())
+
+
+def test_policy_long_rows_keep_the_row_per_wave_kernel_and_grads_flow(oracle):
+    n = 4000
+    rng = np.random.default_rng(3)
+    src, dst = rng.integers(0, n, 40 * n), rng.integers(0, n, 40 * n)          # 40 edges per row: row-per-wave
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().to(DEV)
+    x = torch.rand(n, 64, device=DEV)
+    ops.gspmm(g, "copy_lhs", "sum", x, None)
+    assert last_kernel() == "rowwave32"
+    src2, dst2 = rng.integers(0, n, 5 * n), rng.integers(0, n, 5 * n)          # 5 edges per row, both directions short
+    g2 = mg.graph((torch.from_numpy(src2), torch.from_numpy(dst2)), num_nodes=n).int().to(DEV)
+    xr = x.clone().requires_grad_(True)
+    out = ops.gspmm(g2, "copy_lhs", "mean", xr, None)
+    assert last_kernel() == "rowgroup32"
+    w = torch.rand(n, 64, device=DEV)
+    (out * w).sum().backward()
+    assert last_kernel() == "rowgroup32"                                         # the reversed graph is short-rowed too
+    rp, rx, re_ = oracle.coo_to_csr(n, src2, dst2)
+    ip = oracle.coo_to_csr(n, dst2, src2)[0]
+    inv = (1.0 / np.maximum(np.diff(ip), 1)).astype(np.float32)
+    want = oracle.spmm(rp, rx, re_, "copy_lhs", "sum", w.cpu().numpy() * inv[:, None], None)
+    assert float(np.abs(xr.grad.cpu().numpy() - want).max()) <= 1e-4 * float(np.abs(want).max())
