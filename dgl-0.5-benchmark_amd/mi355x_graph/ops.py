@@ -35,8 +35,7 @@ def _raw_gspmm(csr, op, reduce_op, X, Y, want_arg=False):
     t = _torch_ops()
     if t is None or not (X if X is not None else Y).is_cuda:
         return sparse.gspmm_raw(csr, op, reduce_op, X, Y, want_arg=want_arg)
-    out, au, ae = torch.ops.mi355x_graph.gspmm(*t.csr_args(csr), op, reduce_op, X, Y)
-    return out, (au if au.numel() else None), (ae if ae.numel() else None)
+    return t.raw_gspmm(csr, op, reduce_op, X, Y, want_arg)
 
 
 def _gidx(g):

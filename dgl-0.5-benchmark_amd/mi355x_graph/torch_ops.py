@@ -14,14 +14,21 @@ kernel/dgl-new.py:20,39) is exposed here as dispatcher ops over plain tensors,
     torch.ops.mi355x_graph.in_degrees(indptr) -> deg
 
 each with a fake (meta) implementation, so FakeTensor / torch.compile can trace programs that call them, and each a thin
-call into the same C ABI (csrc/libmi355x_graph.so through sparse.HipBackend) that the ctypes path uses -- the kernels
-do not change.  The CSR travels as its tensors; the execution schedule (mgx_spmm_plan) that belongs to a CSR is found
-again through a weak registry keyed by the tensors' storage, so a registered graph keeps its cached plan.
+call into the same C ABI that the ctypes path uses -- the kernels do not change.
 
-The autograd Functions of ops.py call these ops instead of the direct ctypes wrappers when MGX_TORCH_OPS=1; the default
-stays the direct path because a Python-registered custom op costs more host time per call than ctypes (measured by
-experiments/exp_host_overhead.py, numbers in DESIGN.md) and the small-graph loops are host-bound.
+Round 4: the ops are DEFINED AND IMPLEMENTED IN C++ (csrc/torch_bind.cpp: TORCH_LIBRARY(mi355x_graph) + TORCH_LIBRARY_IMPL(...,
+CUDA, ...) in libmi355x_graph_torch.so, a host translation unit linked against libmi355x_graph.so; the C header stays free of
+torch types).  This module loads that library and adds what belongs to Python: the fake implementations and the autograd
+formula of edge_softmax.  Every op takes a trailing `plan: int = 0` -- the address of the CSR's live mgx_spmm_plan
+(`plan_handle(csr)`), 0 = natural row order.  Without the library (MGX_TORCH_OPS_NATIVE=0, or a tree where it was not built)
+the same schemas are registered from Python over sparse.HipBackend, where a CSR finds its cached schedule again through a
+weak registry keyed by its tensors' storage.
+
+The autograd Functions of ops.py call these ops instead of the direct ctypes wrappers when MGX_TORCH_OPS=1 (per-call host
+time of the three routes: experiments/exp_host_overhead.py, numbers in DESIGN.md).
 """
+import ctypes
+import os
 import weakref
 from typing import Optional, Tuple
 
@@ -29,10 +36,40 @@ import torch
 from torch import Tensor
 
 from . import sparse
-from ._lib import DGLError
+from ._lib import CSRC_DIR, DGLError
 
 NS = "mi355x_graph"
 _views = weakref.WeakValueDictionary()
+
+EXT_PATH = os.path.join(CSRC_DIR, "libmi355x_graph_torch.so")
+NATIVE = False
+if os.environ.get("MGX_TORCH_OPS_NATIVE", "1") == "1" and os.path.exists(EXT_PATH):
+    torch.ops.load_library(EXT_PATH)  # TORCH_LIBRARY(mi355x_graph): schemas + HIP implementations
+    NATIVE = True
+
+
+def _op(name, fn):
+    """Register `fn` (type-annotated, the op's Python implementation) as mi355x_graph::<name> -- unless the C++ library already
+    defines and implements it; returns an object with .register_fake / .register_autograd either way."""
+    if not NATIVE:
+        return torch.library.custom_op(NS + "::" + name, mutates_args=())(fn)
+
+    class _Native(object):
+        @staticmethod
+        def register_fake(f):
+            return torch.library.register_fake(NS + "::" + name)(f)
+
+        @staticmethod
+        def register_autograd(backward, setup_context=None):
+            torch.library.register_autograd(NS + "::" + name, backward, setup_context=setup_context)
+
+    return _Native
+
+
+def plan_handle(csr):
+    """Address of the CSR's mgx_spmm_plan struct (kept alive by the CsrView), 0 when it has none."""
+    plan = csr.plan() if csr.indptr.is_cuda else None
+    return 0 if plan is None else ctypes.addressof(plan.c_struct())
 
 
 def _key(indptr, indices):
@@ -73,9 +110,8 @@ def _feat_shape(U, E):
 
 
 # ----------------------------------------------------------------------------- gspmm
-@torch.library.custom_op(NS + "::gspmm", mutates_args=())
-def gspmm(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int, op: str, reduce: str,
-          ufeat: Optional[Tensor], efeat: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+def _gspmm_py(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int, op: str, reduce: str,
+              ufeat: Optional[Tensor], efeat: Optional[Tensor], plan: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
     csr = _view(indptr, indices, eids, num_cols)
     want_arg = reduce in ("max", "min")
     out, arg_u, arg_e = sparse.gspmm_raw(csr, op, reduce, ufeat, efeat, want_arg=want_arg)
@@ -83,8 +119,11 @@ def gspmm(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int
     return out, (arg_u if arg_u is not None else indptr.new_empty(0)), (arg_e if arg_e is not None else indptr.new_empty(0))
 
 
+gspmm = _op("gspmm", _gspmm_py)
+
+
 @gspmm.register_fake
-def _(indptr, indices, eids, num_cols, op, reduce, ufeat, efeat):
+def _(indptr, indices, eids, num_cols, op, reduce, ufeat, efeat, plan=0):
     U = None if op == "copy_rhs" else ufeat
     E = None if op == "copy_lhs" else efeat
     ref = U if U is not None else E
@@ -114,15 +153,17 @@ class _IndexOverCsr(object):
         return self._csc
 
 
-@torch.library.custom_op(NS + "::gsddmm", mutates_args=())
-def gsddmm(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int, op: str, lhs: Optional[Tensor],
-           rhs: Optional[Tensor], lhs_target: str, rhs_target: str) -> Tensor:
+def _gsddmm_py(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int, op: str, lhs: Optional[Tensor],
+               rhs: Optional[Tensor], lhs_target: str, rhs_target: str, plan: int = 0) -> Tensor:
     """out[e] = op(lhs[t_l(e)], rhs[t_r(e)]) by edge id, walking the in-CSR (indptr over destination nodes)."""
     return sparse.gsddmm_raw(_IndexOverCsr(_view(indptr, indices, eids, num_cols)), op, lhs, rhs, lhs_target, rhs_target)
 
 
+gsddmm = _op("gsddmm", _gsddmm_py)
+
+
 @gsddmm.register_fake
-def _(indptr, indices, eids, num_cols, op, lhs, rhs, lhs_target, rhs_target):
+def _(indptr, indices, eids, num_cols, op, lhs, rhs, lhs_target, rhs_target, plan=0):
     L = None if op == "copy_rhs" else lhs
     R = None if op == "copy_lhs" else rhs
     ref = L if L is not None else R
@@ -135,45 +176,52 @@ def _(indptr, indices, eids, num_cols, op, lhs, rhs, lhs_target, rhs_target):
 
 
 # ----------------------------------------------------------------------------- edge softmax
-@torch.library.custom_op(NS + "::edge_softmax_fwd", mutates_args=())
-def edge_softmax_fwd(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int, z: Tensor) -> Tensor:
+def _edge_softmax_fwd_py(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int, z: Tensor, plan: int = 0) -> Tensor:
     return sparse.edge_softmax_fwd_raw(_view(indptr, indices, eids, num_cols), z)
 
 
+edge_softmax_fwd = _op("edge_softmax_fwd", _edge_softmax_fwd_py)
+
+
 @edge_softmax_fwd.register_fake
-def _(indptr, indices, eids, num_cols, z):
-    return torch.empty_like(z)
+def _(indptr, indices, eids, num_cols, z, plan=0):
+    return torch.empty_like(z, memory_format=torch.contiguous_format)
 
 
-@torch.library.custom_op(NS + "::edge_softmax_bwd", mutates_args=())
-def edge_softmax_bwd(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int, a: Tensor, da: Tensor) -> Tensor:
+def _edge_softmax_bwd_py(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int, a: Tensor, da: Tensor,
+                         plan: int = 0) -> Tensor:
     return sparse.edge_softmax_bwd_raw(_view(indptr, indices, eids, num_cols), a, da.contiguous())
 
 
+edge_softmax_bwd = _op("edge_softmax_bwd", _edge_softmax_bwd_py)
+
+
 @edge_softmax_bwd.register_fake
-def _(indptr, indices, eids, num_cols, a, da):
-    return torch.empty_like(a)
+def _(indptr, indices, eids, num_cols, a, da, plan=0):
+    return torch.empty_like(a, memory_format=torch.contiguous_format)
 
 
 def _softmax_setup(ctx, inputs, output):
-    indptr, indices, eids, num_cols, z = inputs
+    indptr, indices, eids, num_cols, z, plan = inputs
     ctx.save_for_backward(indptr, indices, eids, output)
-    ctx.num_cols = num_cols
+    ctx.num_cols, ctx.plan = num_cols, plan
 
 
 def _softmax_backward(ctx, grad):
     indptr, indices, eids, a = ctx.saved_tensors
-    return None, None, None, None, torch.ops.mi355x_graph.edge_softmax_bwd(indptr, indices, eids, ctx.num_cols, a, grad)
+    return None, None, None, None, torch.ops.mi355x_graph.edge_softmax_bwd(indptr, indices, eids, ctx.num_cols, a, grad, ctx.plan), None
 
 
 edge_softmax_fwd.register_autograd(_softmax_backward, setup_context=_softmax_setup)
 
 
 # ----------------------------------------------------------------------------- segment reduce
-@torch.library.custom_op(NS + "::segment_reduce", mutates_args=())
-def segment_reduce(offsets: Tensor, x: Tensor, reduce: str) -> Tensor:
+def _segment_reduce_py(offsets: Tensor, x: Tensor, reduce: str) -> Tensor:
     out, _ = sparse.segment_reduce_raw(offsets, x, reduce, want_arg=False, total=int(x.shape[0]))
     return out
+
+
+segment_reduce = _op("segment_reduce", _segment_reduce_py)
 
 
 @segment_reduce.register_fake
@@ -182,11 +230,13 @@ def _(offsets, x, reduce):
 
 
 # ----------------------------------------------------------------------------- formats (integer work)
-@torch.library.custom_op(NS + "::coo_to_csr", mutates_args=())
-def coo_to_csr(row: Tensor, col: Tensor, num_rows: int, num_cols: int) -> Tuple[Tensor, Tensor, Tensor]:
+def _coo_to_csr_py(row: Tensor, col: Tensor, num_rows: int, num_cols: int) -> Tuple[Tensor, Tensor, Tensor]:
     """Stable COO -> CSR: (indptr [num_rows + 1], indices = col sorted by row, eids = original positions)."""
     v = sparse.coo_to_csr(num_rows, num_cols, row, col)
     return v.indptr, v.indices, v.eids
+
+
+coo_to_csr = _op("coo_to_csr", _coo_to_csr_py)
 
 
 @coo_to_csr.register_fake
@@ -194,12 +244,14 @@ def _(row, col, num_rows, num_cols):
     return row.new_empty(num_rows + 1), torch.empty_like(col), torch.empty_like(col)
 
 
-@torch.library.custom_op(NS + "::csr_transpose", mutates_args=())
-def csr_transpose(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int) -> Tuple[Tensor, Tensor, Tensor]:
+def _csr_transpose_py(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int) -> Tuple[Tensor, Tensor, Tensor]:
     src = sparse.CsrView(indptr.shape[0] - 1, num_cols, indptr, indices,
                          eids if eids is not None else torch.arange(indices.shape[0], dtype=indices.dtype, device=indices.device))
     t = sparse.csr_transpose(src)
     return t.indptr, t.indices, t.eids
+
+
+csr_transpose = _op("csr_transpose", _csr_transpose_py)
 
 
 @csr_transpose.register_fake
@@ -207,14 +259,40 @@ def _(indptr, indices, eids, num_cols):
     return indptr.new_empty(num_cols + 1), torch.empty_like(indices), torch.empty_like(indices)
 
 
-@torch.library.custom_op(NS + "::in_degrees", mutates_args=())
-def in_degrees(indptr: Tensor) -> Tensor:
+def _in_degrees_py(indptr: Tensor) -> Tensor:
     if not indptr.is_cuda:
         raise DGLError("mi355x_graph::in_degrees runs on MI355X (HIP) tensors")
     n = indptr.shape[0] - 1
     return sparse.backend_for(indptr).degrees(sparse.CsrView(n, 0, indptr, indptr.new_empty(0), None)).clone()
 
 
+in_degrees = _op("in_degrees", _in_degrees_py)
+
+
 @in_degrees.register_fake
 def _(indptr):
     return indptr.new_empty(indptr.shape[0] - 1)
+
+
+# ----------------------------------------------------------------------------- the route ops.py takes under MGX_TORCH_OPS=1
+def _native_shapes_ok(U, E):
+    """What the C++ op takes without offset tables: equal feature shapes, or one weight per head ((N, H, F) x (E, H, 1))."""
+    if U is None or E is None:
+        return True
+    us, es = tuple(U.shape[1:]), tuple(E.shape[1:])
+    return us == es or (len(us) == len(es) and len(us) >= 1 and us[:-1] == es[:-1] and es[-1] == 1)
+
+
+def raw_gspmm(csr, op, reduce, X, Y, want_arg=False):
+    """sparse.gspmm_raw's contract through torch.ops.mi355x_graph.gspmm.  What only the Python layer knows how to route -- general
+    broadcasting (offset tables), the LDS-tile kernel and the line-padded wide rows of dense graphs -- stays on the direct path."""
+    from . import tileplan
+    ref = X if X is not None else Y
+    width = 1
+    for d in ref.shape[1:]:
+        width *= int(d)
+    if (not _native_shapes_ok(X, Y) or (op == "copy_lhs" and reduce in ("sum", "mean") and tileplan.tile_plan_wanted(csr))
+            or (op == "copy_lhs" and width > 256 and width % 32)):
+        return sparse.gspmm_raw(csr, op, reduce, X, Y, want_arg=want_arg)
+    out, au, ae = torch.ops.mi355x_graph.gspmm(*csr_args(csr), op, reduce, X, Y, plan_handle(csr) if NATIVE else 0)
+    return out, (au if au.numel() else None), (ae if ae.numel() else None)

@@ -55,11 +55,15 @@ pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
 
-# ---- the same raw call through the torch.library registration (torch.ops.mi355x_graph.gspmm)
+# ---- the same raw call through the dispatcher op torch.ops.mi355x_graph.gspmm: C++ (csrc/torch_bind.cpp) unless
+# MGX_TORCH_OPS_NATIVE=0 selects the Python registration
 from mi355x_graph import torch_ops
 args = torch_ops.csr_args(g._index.csc())
-host, total = loop(lambda: torch.ops.mi355x_graph.gspmm(*args, "copy_lhs", "sum", x, None))
-print("%-28s host %6.1f us/call   end-to-end %6.1f us/call" % ("torch.ops gspmm copy_u/sum", host, total))
+ph = torch_ops.plan_handle(g._index.csc()) if torch_ops.NATIVE else 0
+host, total = loop(lambda: torch.ops.mi355x_graph.gspmm(*args, "copy_lhs", "sum", x, None, ph))
+print("%-28s host %6.1f us/call   end-to-end %6.1f us/call" % ("torch.ops gspmm (%s)" % ("C++" if torch_ops.NATIVE else "Python"), host, total))
+host, total = loop(lambda: torch_ops.raw_gspmm(g._index.csc(), "copy_lhs", "sum", x, None))
+print("%-28s host %6.1f us/call   end-to-end %6.1f us/call" % ("torch_ops.raw_gspmm", host, total))
 os.environ["MGX_TORCH_OPS"] = "1"
 host, total = loop(lambda: ops.gspmm(g, "copy_lhs", "sum", x, None))
 print("%-28s host %6.1f us/call   end-to-end %6.1f us/call" % ("ops.gspmm via torch.ops", host, total))
