@@ -6,6 +6,7 @@
 //
 //   mi355x_graph::gspmm(indptr, indices, eids?, num_cols, op, reduce, ufeat?, efeat?, plan=0)  -> (out, arg_u, arg_e)
 //   mi355x_graph::gsddmm(indptr, indices, eids?, num_cols, op, lhs?, rhs?, lhs_target, rhs_target, plan=0) -> out
+//   mi355x_graph::gsddmm_coo(src, dst, num_src, num_dst, op, lhs?, rhs?, lhs_target, rhs_target)            -> out
 //   mi355x_graph::edge_softmax_fwd / _bwd(indptr, indices, eids?, num_cols, ..., plan=0)
 //   mi355x_graph::segment_reduce(offsets, x, reduce) / coo_to_csr / csr_transpose / in_degrees
 //
@@ -218,6 +219,54 @@ Tensor gsddmm(const Tensor& indptr, const Tensor& indices, const optional<Tensor
   return out;
 }
 
+// COO walk (graphs that keep their edge list: src / dst in edge-id order) -- the form batched small graphs take
+// (main_dgl_molhiv_gcn.py:50-52: the gathers behind edges.src[...] of the UDF message)
+Tensor gsddmm_coo(const Tensor& src, const Tensor& dst, int64_t num_src, int64_t num_dst, std::string op, const optional<Tensor>& lhs,
+                  const optional<Tensor>& rhs, std::string lhs_target, std::string rhs_target) {
+  const char* what = "mi355x_graph::gsddmm_coo";
+  TORCH_CHECK(src.is_cuda() && dst.is_cuda() && src.device() == dst.device(), what, ": runs on MI355X (HIP) tensors only");
+  TORCH_CHECK(src.dim() == 1 && src.sizes() == dst.sizes() && src.scalar_type() == dst.scalar_type() && src.is_contiguous() &&
+                  dst.is_contiguous(), what, ": src / dst must be matching contiguous 1-D index tensors");
+  const int bits = idx_bits(src, what);
+  const int64_t nnz = src.numel();
+  const int opc = op_code(op, what);
+  const int lt = target_code(lhs_target, what), rt = target_code(rhs_target, what);
+  auto rows_of = [&](int t) { return t == MGX_TARGET_U ? num_src : (t == MGX_TARGET_V ? num_dst : nnz); };
+  Tensor L, R;
+  if (opc != MGX_OP_COPY_RHS) {
+    TORCH_CHECK(lhs.has_value(), what, ": op '", op, "' needs lhs");
+    L = as_f32(*lhs, src, what);
+    TORCH_CHECK(L.dim() >= 1 && L.size(0) == rows_of(lt), what, ": lhs has ", L.size(0), " rows, its target has ", rows_of(lt));
+  }
+  if (opc != MGX_OP_COPY_LHS) {
+    TORCH_CHECK(rhs.has_value(), what, ": op '", op, "' needs rhs");
+    R = as_f32(*rhs, src, what);
+    TORCH_CHECK(R.dim() >= 1 && R.size(0) == rows_of(rt), what, ": rhs has ", R.size(0), " rows, its target has ", rows_of(rt));
+  }
+  const Tensor& ref = L.defined() ? L : R;
+  std::vector<int64_t> shape{nnz};
+  int64_t l_len = L.defined() ? trailing(L) : 0, r_len = R.defined() ? trailing(R) : 0, out_len = 0, reduce_size = 1;
+  if (opc == MGX_OP_DOT) {
+    TORCH_CHECK(L.dim() >= 2 && L.sizes().slice(1) == R.sizes().slice(1), what, ": dot needs operands of equal feature shape");
+    reduce_size = L.size(L.dim() - 1);
+    for (int64_t d = 1; d + 1 < L.dim(); ++d) shape.push_back(L.size(d));
+    shape.push_back(1);
+    out_len = reduce_size ? l_len / reduce_size : 0;
+  } else {
+    if (L.defined() && R.defined())
+      TORCH_CHECK(L.sizes().slice(1) == R.sizes().slice(1), what, ": operand shapes ", L.sizes(), " and ", R.sizes(),
+                  " need broadcasting; call mi355x_graph.ops.gsddmm (it builds the offset tables)");
+    for (int64_t d = 1; d < ref.dim(); ++d) shape.push_back(ref.size(d));
+    out_len = trailing(ref);
+  }
+  Tensor out = at::empty(shape, ref.options());
+  check_status(mgx_sddmm_coo(num_src, num_dst, nnz, src.data_ptr(), dst.data_ptr(), bits, opc, L.defined() ? L.data_ptr<float>() : nullptr,
+                             R.defined() ? R.data_ptr<float>() : nullptr, lt, rt, l_len, r_len, out_len, reduce_size, nullptr, nullptr,
+                             out.data_ptr<float>(), stream_of(src)),
+               what);
+  return out;
+}
+
 // ----------------------------------------------------------------------------- edge softmax
 Tensor softmax_ws(const mgx_spmm_plan* plan, int64_t H, const Tensor& like) {
   if (!plan || plan->num_slots + plan->num_hubs == 0) return Tensor();
@@ -318,6 +367,8 @@ TORCH_LIBRARY(mi355x_graph, m) {
         "int plan=0) -> (Tensor, Tensor, Tensor)");
   m.def("gsddmm(Tensor indptr, Tensor indices, Tensor? eids, int num_cols, str op, Tensor? lhs, Tensor? rhs, str lhs_target, "
         "str rhs_target, int plan=0) -> Tensor");
+  m.def("gsddmm_coo(Tensor src, Tensor dst, int num_src, int num_dst, str op, Tensor? lhs, Tensor? rhs, str lhs_target, "
+        "str rhs_target) -> Tensor");
   m.def("edge_softmax_fwd(Tensor indptr, Tensor indices, Tensor? eids, int num_cols, Tensor z, int plan=0) -> Tensor");
   m.def("edge_softmax_bwd(Tensor indptr, Tensor indices, Tensor? eids, int num_cols, Tensor a, Tensor da, int plan=0) -> Tensor");
   m.def("segment_reduce(Tensor offsets, Tensor x, str reduce) -> Tensor");
@@ -330,6 +381,7 @@ TORCH_LIBRARY(mi355x_graph, m) {
 TORCH_LIBRARY_IMPL(mi355x_graph, CUDA, m) {
   m.impl("gspmm", &gspmm);
   m.impl("gsddmm", &gsddmm);
+  m.impl("gsddmm_coo", &gsddmm_coo);
   m.impl("edge_softmax_fwd", &edge_softmax_fwd);
   m.impl("edge_softmax_bwd", &edge_softmax_bwd);
   m.impl("segment_reduce", &segment_reduce);

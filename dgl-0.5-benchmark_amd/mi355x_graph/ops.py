@@ -23,19 +23,44 @@ __all__ = ["gspmm", "gsddmm", "edge_softmax", "gat_attention", "gat_fused", "seg
 
 
 def _torch_ops():
-    """MGX_TORCH_OPS=1: the raw primitives go through torch.ops.mi355x_graph.* (torch.library registrations over the same
-    C ABI, mi355x_graph/torch_ops.py) instead of the direct ctypes wrappers."""
-    if os.environ.get("MGX_TORCH_OPS", "0") != "1":
+    """MGX_TORCH_OPS=1 (tests): EVERY raw primitive goes through torch.ops.mi355x_graph.* and the fused layer forms of this module
+    are switched off, so that a model exercises exactly the registered operator surface."""
+    if os.environ.get("MGX_TORCH_OPS", "auto") != "1":
         return None
     from . import torch_ops
     return torch_ops
 
 
+_NATIVE = None
+
+
+def _native_ops():
+    """Default route of the generic operators behind update_all() / apply_edges() on HIP tensors: the C++ dispatcher ops
+    (csrc/torch_bind.cpp, TORCH_LIBRARY(mi355x_graph)) -- 5.6 us of host time per call against 13.2 us through ctypes and 22.8 us
+    for a Python-registered op (experiments/exp_host_overhead.py; eager molhiv epoch 0.92 -> 0.80 s).  MGX_TORCH_OPS=0 restores
+    the ctypes route; a tree without libmi355x_graph_torch.so uses it as well."""
+    global _NATIVE
+    if os.environ.get("MGX_TORCH_OPS", "auto") == "0":
+        return None
+    if _NATIVE is None:
+        from . import torch_ops
+        _NATIVE = torch_ops if torch_ops.NATIVE else False
+    return _NATIVE or _torch_ops()
+
+
 def _raw_gspmm(csr, op, reduce_op, X, Y, want_arg=False):
-    t = _torch_ops()
+    t = _native_ops()
     if t is None or not (X if X is not None else Y).is_cuda:
         return sparse.gspmm_raw(csr, op, reduce_op, X, Y, want_arg=want_arg)
     return t.raw_gspmm(csr, op, reduce_op, X, Y, want_arg)
+
+
+def _raw_gsddmm(gidx, op, X, Y, lhs_target="u", rhs_target="v"):
+    t = _native_ops()
+    ref = X if X is not None else Y
+    if t is None or ref is None or not ref.is_cuda:
+        return sparse.gsddmm_raw(gidx, op, X, Y, lhs_target, rhs_target)
+    return t.raw_gsddmm(gidx, op, X, Y, lhs_target, rhs_target)
 
 
 def _gidx(g):
@@ -106,17 +131,19 @@ class GSpMM(torch.autograd.Function):
                 rev = gidx.csr()  # rows = src: the reversed graph's in-CSR
                 if op == "mul":
                     dX, _, _ = _raw_gspmm(rev, "mul", "sum", dZs, Y)
-                else:  # add, copy_lhs: aggregation of a gradient -- skips its all-zero rows (sparse.gspmm_grad_raw)
-                    dX = sparse.gspmm_grad_raw(rev, dZs) if _torch_ops() is None else _raw_gspmm(rev, "copy_lhs", "sum", dZs, None)[0]
+                elif os.environ.get("MGX_SPARSE_GRAD", "0") == "1" and _torch_ops() is None:
+                    dX = sparse.gspmm_grad_raw(rev, dZs)  # measured variant: flags the gradient's all-zero rows and skips them
+                else:  # add, copy_lhs: aggregation of the gradient over the reversed graph
+                    dX = _raw_gspmm(rev, "copy_lhs", "sum", dZs, None)[0]
                 dX = _reduce_grad(dX, ctx.x_shape)
             if op != "copy_lhs" and ctx.needs_input_grad[4]:
                 if op == "mul":
                     if _need_reduce_last_dim(ctx.x_shape, ctx.y_shape):
-                        dY = sparse.gsddmm_raw(gidx, "dot", X, dZs, "u", "v")
+                        dY = _raw_gsddmm(gidx, "dot", X, dZs, "u", "v")
                     else:
-                        dY = sparse.gsddmm_raw(gidx, "mul", X, dZs, "u", "v")
+                        dY = _raw_gsddmm(gidx, "mul", X, dZs, "u", "v")
                 else:  # add, copy_rhs
-                    dY = sparse.gsddmm_raw(gidx, "copy_rhs", None, dZs, "u", "v")
+                    dY = _raw_gsddmm(gidx, "copy_rhs", None, dZs, "u", "v")
                 dY = _reduce_grad(dY, ctx.y_shape)
         else:  # max / min: route dZ through the arg indices; empty rows (arg = -1) contribute nothing
             if op != "copy_rhs" and ctx.needs_input_grad[3]:
@@ -147,7 +174,7 @@ class GSpMM(torch.autograd.Function):
 class GSDDMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gidx, op, X, Y, lhs_target, rhs_target):
-        out = sparse.gsddmm_raw(gidx, op, X, Y, lhs_target, rhs_target)
+        out = _raw_gsddmm(gidx, op, X, Y, lhs_target, rhs_target)
         ctx.backward_cache = gidx, op, lhs_target, rhs_target
         ctx.x_shape = None if X is None else X.shape
         ctx.y_shape = None if Y is None else Y.shape
@@ -164,7 +191,7 @@ class GSDDMM(torch.autograd.Function):
         if target == "e":
             return edge_grad
         view = gidx.csr() if target == "u" else gidx.csc()
-        out, _, _ = sparse.gspmm_raw(view, "copy_rhs", "sum", None, edge_grad)
+        out, _, _ = _raw_gspmm(view, "copy_rhs", "sum", None, edge_grad)
         return out
 
     @staticmethod
@@ -180,11 +207,11 @@ class GSDDMM(torch.autograd.Function):
             elif op in ("mul", "dot", "div"):
                 if lt == "u" and rt == "v" and op in ("mul", "dot"):
                     # dX[u] = sum_{e: u->v} Y[v] * dZ[e]: a mul-SpMM on the reversed graph
-                    dX, _, _ = sparse.gspmm_raw(gidx.csr(), "mul", "sum", Y, dZ)
+                    dX, _, _ = _raw_gspmm(gidx.csr(), "mul", "sum", Y, dZ)
                 elif lt == "v" and rt == "u" and op in ("mul", "dot"):
-                    dX, _, _ = sparse.gspmm_raw(gidx.csc(), "mul", "sum", Y, dZ)
+                    dX, _, _ = _raw_gspmm(gidx.csc(), "mul", "sum", Y, dZ)
                 else:
-                    y_e = sparse.gsddmm_raw(gidx, "copy_rhs", None, Y, lt, rt) if rt != "e" else Y
+                    y_e = _raw_gsddmm(gidx, "copy_rhs", None, Y, lt, rt) if rt != "e" else Y
                     ge = dZ * y_e if op in ("mul", "dot") else dZ / y_e
                     dX = GSDDMM._to_target(gidx, lt, ge.contiguous())
             dX = _reduce_grad(dX, ctx.x_shape)
@@ -199,11 +226,11 @@ class GSDDMM(torch.autograd.Function):
                 elif lt == "v" and rt == "u":
                     dY, _, _ = sparse.gspmm_raw(gidx.csr(), "mul", "sum", X, dZ)
                 else:
-                    x_e = sparse.gsddmm_raw(gidx, "copy_lhs", X, None, lt, rt) if lt != "e" else X
+                    x_e = _raw_gsddmm(gidx, "copy_lhs", X, None, lt, rt) if lt != "e" else X
                     dY = GSDDMM._to_target(gidx, rt, (dZ * x_e).contiguous())
             else:  # div: d(x/y)/dy = -x / y^2
-                x_e = sparse.gsddmm_raw(gidx, "copy_lhs", X, None, lt, rt) if lt != "e" else X
-                y_e = sparse.gsddmm_raw(gidx, "copy_rhs", None, Y, lt, rt) if rt != "e" else Y
+                x_e = _raw_gsddmm(gidx, "copy_lhs", X, None, lt, rt) if lt != "e" else X
+                y_e = _raw_gsddmm(gidx, "copy_rhs", None, Y, lt, rt) if rt != "e" else Y
                 dY = GSDDMM._to_target(gidx, rt, (-dZ * x_e / (y_e * y_e)).contiguous())
             dY = _reduce_grad(dY, ctx.y_shape)
         return None, None, dX, dY, None, None
@@ -213,10 +240,12 @@ class EdgeSoftmax(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gidx, score, norm_by):
         view = gidx.csc() if norm_by == "dst" else gidx.csr()
-        t = _torch_ops()
+        t = _native_ops()
         if t is not None and score.is_cuda:
+            if score.dtype != torch.float32 or score.shape[0] != view.nnz:
+                raise DGLError("edge_softmax: expected float32 logits with %d rows, got %s %s" % (view.nnz, score.dtype, tuple(score.shape)))
             with torch.no_grad():
-                out = torch.ops.mi355x_graph.edge_softmax_fwd(*t.csr_args(view), score.contiguous())
+                out = torch.ops.mi355x_graph.edge_softmax_fwd(*t.csr_args(view), score.contiguous(), t.softmax_plan_handle(view))
         else:
             out = sparse.edge_softmax_fwd_raw(view, score)
         ctx.backward_cache = view

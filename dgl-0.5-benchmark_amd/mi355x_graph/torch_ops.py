@@ -67,8 +67,17 @@ def _op(name, fn):
 
 
 def plan_handle(csr):
-    """Address of the CSR's mgx_spmm_plan struct (kept alive by the CsrView), 0 when it has none."""
-    plan = csr.plan() if csr.indptr.is_cuda else None
+    """Address of the CSR's mgx_spmm_plan struct (kept alive by the CsrView), 0 when it has none or the ops are Python's."""
+    if not NATIVE or not csr.indptr.is_cuda:
+        return 0
+    plan = csr.plan()
+    return 0 if plan is None else ctypes.addressof(plan.c_struct())
+
+
+def softmax_plan_handle(csr):
+    if not NATIVE or not csr.indptr.is_cuda:
+        return 0
+    plan = csr.softmax_plan()
     return 0 if plan is None else ctypes.addressof(plan.c_struct())
 
 
@@ -97,7 +106,8 @@ _keep = []  # a few views built on the fly stay alive so that their plans are no
 
 
 def csr_args(csr):
-    register_view(csr)
+    if not NATIVE:  # the Python registrations find the CSR's cached schedule again through the registry
+        register_view(csr)
     return csr.indptr, csr.indices, csr.eids, csr.num_cols
 
 
@@ -173,6 +183,28 @@ def _(indptr, indices, eids, num_cols, op, lhs, rhs, lhs_target, rhs_target, pla
     else:
         shape = _feat_shape(L, R)
     return ref.new_empty((nnz,) + shape)
+
+
+def _gsddmm_coo_py(src: Tensor, dst: Tensor, num_src: int, num_dst: int, op: str, lhs: Optional[Tensor], rhs: Optional[Tensor],
+                   lhs_target: str, rhs_target: str) -> Tensor:
+    """The COO walk (src / dst in edge-id order) of the same operator."""
+    from .graph import GraphIndex
+    return sparse.gsddmm_raw(GraphIndex(num_src, num_dst, coo=(src, dst)), op, lhs, rhs, lhs_target, rhs_target)
+
+
+gsddmm_coo = _op("gsddmm_coo", _gsddmm_coo_py)
+
+
+@gsddmm_coo.register_fake
+def _(src, dst, num_src, num_dst, op, lhs, rhs, lhs_target, rhs_target):
+    L = None if op == "copy_rhs" else lhs
+    R = None if op == "copy_lhs" else rhs
+    ref = L if L is not None else R
+    if op == "dot":
+        shape = tuple(torch.broadcast_shapes(tuple(L.shape[1:-1]), tuple(R.shape[1:-1]))) + (1,)
+    else:
+        shape = _feat_shape(L, R)
+    return ref.new_empty((src.shape[0],) + shape)
 
 
 # ----------------------------------------------------------------------------- edge softmax
@@ -286,13 +318,38 @@ def _native_shapes_ok(U, E):
 def raw_gspmm(csr, op, reduce, X, Y, want_arg=False):
     """sparse.gspmm_raw's contract through torch.ops.mi355x_graph.gspmm.  What only the Python layer knows how to route -- general
     broadcasting (offset tables), the LDS-tile kernel and the line-padded wide rows of dense graphs -- stays on the direct path."""
-    from . import tileplan
-    ref = X if X is not None else Y
-    width = 1
-    for d in ref.shape[1:]:
-        width *= int(d)
-    if (not _native_shapes_ok(X, Y) or (op == "copy_lhs" and reduce in ("sum", "mean") and tileplan.tile_plan_wanted(csr))
-            or (op == "copy_lhs" and width > 256 and width % 32)):
+    if X is not None and Y is not None and not _native_shapes_ok(X, Y):
         return sparse.gspmm_raw(csr, op, reduce, X, Y, want_arg=want_arg)
-    out, au, ae = torch.ops.mi355x_graph.gspmm(*csr_args(csr), op, reduce, X, Y, plan_handle(csr) if NATIVE else 0)
+    if op == "copy_lhs" and (reduce == "sum" or reduce == "mean"):
+        if csr._tile_plan is False:  # decided once per CSR, as CsrView.tile_plan() does
+            from . import tileplan
+            csr._tile_plan = {} if tileplan.tile_plan_wanted(csr) else None
+        width = X.numel() // max(int(X.shape[0]), 1)
+        if csr._tile_plan is not None or (width > 256 and width % 32):
+            return sparse.gspmm_raw(csr, op, reduce, X, Y, want_arg=want_arg)
+    if not NATIVE:
+        register_view(csr)
+    try:
+        out, au, ae = torch.ops.mi355x_graph.gspmm(csr.indptr, csr.indices, csr.eids, csr.num_cols, op, reduce, X, Y, plan_handle(csr))
+    except DGLError:
+        raise
+    except RuntimeError as err:  # TORCH_CHECK in csrc/torch_bind.cpp: the operator surface raises DGLError (SURVEY 8b "Errors")
+        raise DGLError(str(err).split("\n")[0]) from None
     return out, (au if au.numel() else None), (ae if ae.numel() else None)
+
+
+def raw_gsddmm(gidx, op, L, R, lhs_target="u", rhs_target="v"):
+    """sparse.gsddmm_raw's contract through the dispatcher ops: the COO walk when the graph keeps its edge list, else the CSR walk;
+    operands that need broadcasting (offset tables) stay on the direct path."""
+    if not NATIVE or (L is not None and R is not None and L.shape[1:] != R.shape[1:]) or (L if L is not None else R).dtype != torch.float32:
+        return sparse.gsddmm_raw(gidx, op, L, R, lhs_target, rhs_target)
+    try:
+        if gidx.has_format("coo") or not gidx.has_format("csc"):  # the same choice HipBackend.sddmm makes
+            src, dst = gidx.coo()
+            return torch.ops.mi355x_graph.gsddmm_coo(src, dst, gidx.num_src, gidx.num_dst, op, L, R, lhs_target, rhs_target)
+        csc = gidx.csc()
+        return torch.ops.mi355x_graph.gsddmm(csc.indptr, csc.indices, csc.eids, csc.num_cols, op, L, R, lhs_target, rhs_target, plan_handle(csc))
+    except DGLError:
+        raise
+    except RuntimeError as err:
+        raise DGLError(str(err).split("\n")[0]) from None

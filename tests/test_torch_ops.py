@@ -49,18 +49,22 @@ def test_registered_ops_match_the_direct_path(oracle):
     g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=torch.int32, device=dev)
     csc = g._index.csc()
     args = torch_ops.csr_args(csc)
+    ph = torch_ops.plan_handle(csc)   # the CSR's execution schedule (hub rows split): same summation order as the direct path
+    assert (ph != 0) == (torch_ops.NATIVE and csc.plan() is not None)
     x = torch.randn(n_src, 4, 8, device=dev)
     w = torch.rand(nnz, 4, 1, device=dev)
-    out, au, ae = torch.ops.mi355x_graph.gspmm(*args, "mul", "sum", x, w)
+    out, au, ae = torch.ops.mi355x_graph.gspmm(*args, "mul", "sum", x, w, ph)
     assert torch.equal(out, ops.gspmm(g, "mul", "sum", x, w)) and au.numel() == 0
+    out0 = torch.ops.mi355x_graph.gspmm(*args, "mul", "sum", x, w)[0]            # plan = 0: natural row order, same sums to rounding
+    assert float((out0 - out).abs().max()) <= 1e-4 * float(out.abs().max())
     out, au, ae = torch.ops.mi355x_graph.gspmm(*args, "copy_lhs", "max", x, None)
     ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
     ref, ru, _ = oracle.spmm(ip, ix, ei, "copy_lhs", "max", x.cpu().numpy(), None, want_arg=True)
     assert np.array_equal(out.cpu().numpy(), ref) and np.array_equal(au.cpu().numpy(), ru)
     y = torch.randn(n_dst, 4, 8, device=dev)
-    assert torch.equal(torch.ops.mi355x_graph.gsddmm(*args, "dot", x, y, "u", "v"), ops.gsddmm(g.formats(["csr", "csc"]), "dot", x, y))
+    assert torch.equal(torch.ops.mi355x_graph.gsddmm(*args, "dot", x, y, "u", "v", ph), ops.gsddmm(g.formats(["csr", "csc"]), "dot", x, y))
     z = torch.randn(nnz, 4, 1, device=dev, requires_grad=True)
-    a = torch.ops.mi355x_graph.edge_softmax_fwd(*args, z)
+    a = torch.ops.mi355x_graph.edge_softmax_fwd(*args, z, ph)
     z2 = z.detach().clone().requires_grad_(True)
     a2 = ops.edge_softmax(g, z2)
     assert torch.equal(a, a2)
