@@ -19,7 +19,8 @@ for d in ("$O/${TAG}_gat8_fetch", "$O/${TAG}_gat8_write", "$O/${TAG}_gat8_l2"):
         c.setdefault(k, {}).update(v)
 lines = ["# fused GAT kernels, reddit-small + self loops (N = 232,965, E = 11.84 M), 2 layers (8 heads x 16, then 1 head x 41): HBM-side",
          "# bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE KiB x 1024 x 2, WRITE_SIZE KiB x 1024) and L2 hit rate",
-         "%-58s %8s %12s %12s %8s" % ("kernel", "launches", "read MB", "write MB", "L2 hit")]
+         "%-58s %8s %12s %12s %8s %10s" % ("kernel", "launches", "read MB", "write MB", "L2 hit", "L2 req/edge")]
+E = 11839883.0
 for k in sorted(c):
     if "mgx::gat_" not in k:
         continue
@@ -28,7 +29,9 @@ for k in sorted(c):
     rd = sum(v.get("FETCH_SIZE", [0])) / max(n, 1) * 2048
     wr = sum(v.get("WRITE_SIZE", [0])) / max(len(v.get("WRITE_SIZE", [1])), 1) * 1024
     hit, miss = sum(v.get("TCC_HIT_sum", [0])), sum(v.get("TCC_MISS_sum", [0]))
-    lines.append("%-58s %8d %12.1f %12.1f %8.3f" % (k.split("(")[0].replace("void ", "")[:58], n, rd / 1e6, wr / 1e6, hit / max(hit + miss, 1)))
+    nl2 = max(len(v.get("TCC_HIT_sum", [1])), 1)
+    lines.append("%-58s %8d %12.1f %12.1f %8.3f %10.2f" % (k.split("(")[0].replace("void ", "")[:58], n, rd / 1e6, wr / 1e6, hit / max(hit + miss, 1),
+                                                            (hit + miss) / nl2 / E))
 open("$O/${TAG}_gat8_pmc.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
