@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -13,6 +14,9 @@ constexpr int kWave = 64;          // CDNA4 wavefront
 constexpr int kBlock = 256;        // 4 waves / workgroup: one per SIMD
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with its own 4 MiB L2
+
+// A/B switches of measured alternatives (README: "A/B toggles") are read ONCE per process, not on every launch.
+#define MGX_ENV_FLAG(name) ([]() -> bool { static const bool v = getenv(name) != nullptr; return v; }())
 
 void set_error(const char* fmt, ...);
 void note_spmm_kernel(const char* name);  // mgx_last_spmm_kernel(): which kernel family a g-SpMM call was routed to

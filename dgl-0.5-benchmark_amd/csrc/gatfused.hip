@@ -497,7 +497,7 @@ static bool gat_launch(const GatArgs& a, bool drop, hipStream_t s) {
 }
 
 static int gat_rows_per_block() {
-  const char* e = getenv("MGX_ROWS_PER_BLOCK");
+  static const char* e = getenv("MGX_ROWS_PER_BLOCK");  // read once per process
   int x = e ? atoi(e) : 16;
   if (x < 4) x = 4;
   if (x > 1024) x = 1024;

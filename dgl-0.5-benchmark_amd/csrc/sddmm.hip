@@ -436,7 +436,7 @@ static bool try_headdot(const SddmmArgs<int32_t>& a, hipStream_t s) {
   const bool ragged = RS % 4 != 0;
   const int64_t lph = RS / 4;
   if (ragged) {
-    if (a.out_len != 1 || D <= 4 || D > 64 || (uintptr_t)a.L % 4 || (uintptr_t)a.R % 4 || getenv("MGX_SPMM_NO_RAGGED")) return false;
+    if (a.out_len != 1 || D <= 4 || D > 64 || (uintptr_t)a.L % 4 || (uintptr_t)a.R % 4 || MGX_ENV_FLAG("MGX_SPMM_NO_RAGGED")) return false;
   } else {
     if ((lph & (lph - 1)) != 0 || lph > 16) return false;
     if ((uintptr_t)a.L % 16 || (uintptr_t)a.R % 16) return false;
@@ -458,13 +458,13 @@ static bool try_headdot(const SddmmArgs<int32_t>& a, hipStream_t s) {
 }
 template <typename Idx> static bool try_headdot_any(const SddmmArgs<Idx>&, hipStream_t) { return false; }
 template <> bool try_headdot_any<int32_t>(const SddmmArgs<int32_t>& a, hipStream_t s) {
-  return getenv("MGX_SDDMM_GENERIC_DOT") == nullptr && try_headdot(a, s);
+  return !MGX_ENV_FLAG("MGX_SDDMM_GENERIC_DOT") && try_headdot(a, s);
 }
 
 // int32 COO graphs with element-wise DIRECT operands on node targets, each addressable with 32-bit byte offsets
 template <int VEC, int G, bool ELIGIBLE>
 static bool launch_coo32(const SddmmArgs<int32_t>& a, dim3 grid, hipStream_t s) {
-  if (!ELIGIBLE || getenv("MGX_SDDMM_V1") != nullptr) return false;  // A/B switch
+  if (!ELIGIBLE || MGX_ENV_FLAG("MGX_SDDMM_V1")) return false;  // A/B switch
   auto rows_of = [&](int t) -> int64_t { return t == MGX_TARGET_U ? a.n_cols : (t == MGX_TARGET_V ? a.n_rows : -1); };
   const int64_t lim = int64_t(1) << 32;
   if (a.L && (rows_of(a.lhs_target) <= 0 || rows_of(a.lhs_target) * a.out_len * 4 >= lim)) return false;

@@ -62,7 +62,7 @@ struct SpmmFastArgs {
 // the rows in flight on one XCD a tight window of the schedule (256 resident groups x rpb rows)
 // and balances skewed rows better; 16 measured best on MI355X (64: +5..50 %, 256: +20..150 %).
 static int rows_per_block_setting() {
-  const char* e = getenv("MGX_ROWS_PER_BLOCK");
+  static const char* e = getenv("MGX_ROWS_PER_BLOCK");  // read once per process
   int x = e ? atoi(e) : 16;
   if (x < 4) x = 4;
   if (x > 1024) x = 1024;
@@ -665,7 +665,7 @@ static bool launch_rowgroup32(SpmmFastArgs<int32_t> a, int64_t nnz, hipStream_t 
     return false;
   } else {
     if (env == 0 || a.ragged || a.src_scale || a.src_bits || a.D % 4 != 0) return false;
-    if (a.src_rows * (int64_t)a.lds * 4 >= (int64_t(1) << 32) || getenv("MGX_SPMM_V1") != nullptr) return false;
+    if (a.src_rows * (int64_t)a.lds * 4 >= (int64_t(1) << 32) || MGX_ENV_FLAG("MGX_SPMM_V1")) return false;
     if (env != 1 && (a.n_items == 0 || (double)nnz / (double)a.n_items >= max_avg)) return false;
     note_spmm_kernel("rowgroup32");
     a.rpb = 2 * kWavesPerBlock * NB;  // two batches per wave: the second's ids travel under the first's gathers
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(kBlock) void spmm_generic_kernel(const SpmmGenericA
 // int32 graphs whose gathered matrix is addressable with 32-bit byte offsets take the lean kernel
 template <int VEC, int G, int MODE>
 static bool launch_rowwave32(const SpmmFastArgs<int32_t>& a, int64_t src_rows, dim3 grid, hipStream_t s) {
-  if (getenv("MGX_SPMM_V1") != nullptr) return false;  // A/B switch
+  if (MGX_ENV_FLAG("MGX_SPMM_V1")) return false;  // A/B switch
   if (src_rows * (int64_t)a.lds * 4 >= (int64_t(1) << 32)) return false;
   if (a.ragged) {  // VEC == 4, D % 4 != 0, one weight per edge at most (launch_fast checked eligibility)
     if (VEC == 4 && MODE != MODE_COPY_RHS) {
@@ -868,7 +868,7 @@ static void launch_fast_v(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s
   // than the row-per-group kernel at every degree measured (arxiv-shaped, avg in-degree 6.9: D = 64 187 -> 108 us, D = 8
   // 148 -> 82 us; cora / pubmed 40-54 -> 22-26 us), so it is always taken when eligible; the 64-bit kernels keep the old
   // rule (rows long enough to feed all NB lane groups).  MGX_SPLIT_FACTOR overrides the factor for A/B runs.
-  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) && getenv("MGX_SPMM_V1") == nullptr;
+  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) && !MGX_ENV_FLAG("MGX_SPMM_V1");
   static const double env_factor = getenv("MGX_SPLIT_FACTOR") ? atof(getenv("MGX_SPLIT_FACTOR")) : -1.0;
   const double split_factor = env_factor >= 0.0 ? env_factor : (lean ? 0.0 : 2.0);
   const bool split = (NB == 1) || (avg_deg >= split_factor * NB);
@@ -890,8 +890,8 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
   // MODE_MUL_EDGE needs every lane's VEC features inside one head: F % VEC == 0.
   const int vec_ok = (MODE == MODE_MUL_EDGE) ? a.F : a.D;
   // odd widths (41 classes): 16-byte gathers with a ragged last lane, lean int32 kernel only, one head
-  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) && getenv("MGX_SPMM_V1") == nullptr;
-  if (lean && MODE != MODE_COPY_RHS && a.D % 4 != 0 && a.D > 4 && (a.D <= 256 || MODE == MODE_COPY_LHS) && a.H == 1 && getenv("MGX_SPMM_NO_RAGGED") == nullptr &&
+  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) && !MGX_ENV_FLAG("MGX_SPMM_V1");
+  if (lean && MODE != MODE_COPY_RHS && a.D % 4 != 0 && a.D > 4 && (a.D <= 256 || MODE == MODE_COPY_LHS) && a.H == 1 && !MGX_ENV_FLAG("MGX_SPMM_NO_RAGGED") &&
       (uintptr_t)a.src % 4 == 0) {
     SpmmFastArgs<Idx> b = a;
     b.ragged = 1;
@@ -956,7 +956,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
       if (a.lds != a.D || a.ldo != a.D) {  // strided rows: the lean row-per-wave kernel with 16-byte lanes only
         const bool ok = sizeof(Idx) == 4 && a.D % 4 == 0 && a.lds % 4 == 0 && a.ldo % 4 == 0 && a.lds >= a.D && a.ldo >= a.D &&
                         (uintptr_t)U % 16 == 0 && (uintptr_t)out % 16 == 0 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) &&
-                        getenv("MGX_SPMM_V1") == nullptr && !src_bits;
+                        !MGX_ENV_FLAG("MGX_SPMM_V1") && !src_bits;
         if (!ok) MGX_UNSUPPORTED("mgx_spmm_copy_u_strided: needs int32 ids, D and both strides multiples of 4, 16-byte aligned "
                                  "pointers and a gathered matrix under 4 GiB");
       }

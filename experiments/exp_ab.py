@@ -1,5 +1,7 @@
 """A/B of kernel variants selected by environment variables (default: 64-bit row-per-wave kernel vs the lean 32-bit one),
 by graph / D / schedule."""
+# NOTE (round 4): the C library reads its A/B switches ONCE per process (common.h MGX_ENV_FLAG): the in-process sweeps below
+# recorded the round-1/2 numbers; to repeat them now, run one process per setting.
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dgl-0.5-benchmark_amd"))
 import torch

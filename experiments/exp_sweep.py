@@ -1,4 +1,6 @@
 """Sweep split threshold x items-per-workgroup for the clustered schedule (products shape)."""
+# NOTE (round 4): the C library reads its A/B switches ONCE per process (common.h MGX_ENV_FLAG): the in-process sweeps below
+# recorded the round-1/2 numbers; to repeat them now, run one process per setting.
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dgl-0.5-benchmark_amd"))
 import torch
