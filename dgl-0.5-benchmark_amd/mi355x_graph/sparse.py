@@ -140,9 +140,21 @@ class CsrView(object):
             self.plan()  # computes (and caches) the locality row order first
             nc, nacc, nl, tau = tileplan.config(lg)
             base = self._tile_base_plan()
-            tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=lg)
+            # MGX_TILE_DIRECT=split (A/B, measured slower: reddit D = 64 1.13 -> 1.42 ms, docs/LOG_r04.md §8): the tile's once-used
+            # sources as a second, accumulating launch of the row kernel instead of the tile kernel's own direct part
+            split = lg == 4 and os.environ.get("MGX_TILE_DIRECT", "kernel") == "split"
+            tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=lg, split_direct=split)
             if _VALIDATE_TILE_PLANS:
                 tileplan.validate(tp, self)
+            tp.direct_csr = None
+            if tp.direct_coo is not None and tp.direct_coo[0].numel():
+                # the tile's once-used sources as a CSR of their own (same rows, same row order) for the row-per-wave kernel
+                dv = coo_to_csr(self.num_rows, self.num_cols, tp.direct_coo[0], tp.direct_coo[1])
+                dv._tile_plan = None
+                dv._row_order = self._row_order
+                dv.dst_is_src_prefix = getattr(self, "dst_is_src_prefix", False)
+                tp.direct_csr = dv
+            tp.direct_coo = None
             self._tile_plan[lg] = tp
         return self._tile_plan[lg]
 
@@ -439,6 +451,13 @@ class HipBackend(object):
             if rec is not None:
                 rec["end"].record(torch.cuda.current_stream(dev))
                 PROFILE.append(rec)
+        dv = getattr(tile_plan, "direct_csr", None)
+        if dv is not None:  # the edges the tile plan left out (sources used once in their tile): row kernel, accumulating
+            scale = dst_scale
+            if reduce == "mean":
+                inv = csr.inv_degrees()
+                scale = inv if dst_scale is None else inv * dst_scale
+            self.spmm_copy_u_strided(dv, "sum", U2d, out2d, accumulate=True, dst_scale=scale)
         return out2d
 
     def sddmm(self, graph_index, op, L, R, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size, l_off, r_off):

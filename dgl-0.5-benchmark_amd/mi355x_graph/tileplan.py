@@ -157,7 +157,7 @@ def _longest_first(tile_edges, T, xcds=8):
     return torch.sort(key, stable=True)[1].to(torch.int32)
 
 
-def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, pair_rank=False):
+def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, pair_rank=False, split_direct=False):
     """csr: CsrView (int32, device or host); base: SpmmPlan over it (items in schedule order; None = natural rows).
     pair_rank (the plans of the fused GAT walks, gat_tile.inc): every entry also carries the RANK k of its edge among the parallel
     edges of its (row, source) pair, in edge-id order -- (destination, source, k) is then a key per edge that both CSRs of a graph
@@ -165,6 +165,10 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     (`lds_stream16`); direct entries: k in bits 24-30 of the source id.  k is kept mod 128: a pair with MORE than 128 parallel
     edges (the heavy-tailed stand-ins have hub pairs with thousands; the datasets have none) re-uses keys, i.e. its edges with
     equal k mod 128 share a mask bit -- both CSRs still see the same multiset of bits per pair, so the three walks stay consistent."""
+    # split_direct (round 4): the edges whose source is used fewer than tau times in their tile -- nothing to re-use -- are NOT walked
+    # by the tile kernel (its direct part stays empty); they are returned as a COO (`tables["direct_coo"]`, destination row / source)
+    # for a second, accumulating launch of the row-per-wave kernel: in the tile kernel that part ran on 14 waves per CU with the
+    # LDS idle and took 40 % of a tile's time for 18 % of the edges (profiles/r03_tile_stamps.txt, reddit D = 64).
     dev = csr.indptr.device
     NC, NACC = int(consumers), int(nacc)
     if NC + int(loaders) not in TILE_WAVES or not 1 <= NACC <= CNT_STRIDE or int(loaders) not in (1, 2, 4):
@@ -239,6 +243,9 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         e_rank[order] = (torch.arange(E, device=dev) - run0).to(torch.int32)
         del pk, o1, o2, order, runs, run0, node, eid, e_csr
     e_tile, e_pos = it_tile[e_item], pos[e_item].to(torch.int32)
+    e_row = None
+    if split_direct:
+        e_row = (base.item_node if base is not None and base.item_node is not None else item_row).to(torch.int32)[e_item]
     del e_item, first
     tile_edges = torch.bincount(e_tile, minlength=T) if os.environ.get("MGX_TILE_LPT", "0") == "1" else None
     # ---- sources gathered >= tau times inside a tile are staged; per tile they are ordered by multiplicity (dense chunks first)
@@ -293,6 +300,11 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     del sk, e_slot
     # ---- direct streams: one per (tile, consumer wave)
     direct = ~staged
+    direct_coo = None
+    if split_direct:
+        direct_coo = (e_row[direct].contiguous(), e_src[direct].to(torch.int32).contiguous())
+        direct = torch.zeros_like(direct)  # the kernel's own direct part stays empty
+        del e_row
     dk = e_tile[direct] * per_unit + e_pos[direct]
     dir_payload = e_src[direct].to(torch.int32)
     if e_rank is not None and n_src < (1 << 24):
@@ -318,7 +330,7 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
              "dir_slot_fill": (E - n_staged) / max(int(dir_stream.shape[0]) - STREAM_TAIL * GROUPS * 4, 1),
              "parallel_edges": None if e_rank is None else max_rank > 0,
              "max_pair_rank": None if e_rank is None else max_rank,
-             "pair_rank_streams": lds16 is not None and n_src < (1 << 24)}
+             "pair_rank_streams": lds16 is not None and n_src < (1 << 24), "direct_split": direct_coo is not None}
     tables = {
         "tile_chunk_ptr": tile_chunk_ptr.to(torch.int32),
         "chunk_ids": chunk_ids,
@@ -333,6 +345,7 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         "tile_node": tile_node,
         "lds_stream16": None if lds16 is None else lds16.view(torch.int32),  # [lds_supersteps * groups * 2] words: 4 x (slot | rank << 8)
         "tile_order": _longest_first(tile_edges, T) if tile_edges is not None else None,
+        "direct_coo": direct_coo,
     }
     if lds_total * 4 >= 2 ** 31 or dir_total * 16 >= 2 ** 31:
         raise ValueError("tile plan: stream offsets exceed 31 bits")
