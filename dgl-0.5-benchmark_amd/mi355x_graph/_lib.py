@@ -92,6 +92,7 @@ SIGNATURES = {
     "mgx_coo_to_csr_host": (_i32, [_i64, _i64, _vp, _vp, _i32, _vp, _vp, _vp]),
     "mgx_sample_neighbors": (_i32, [_csr_p, _i64, _vp, _i32, ctypes.c_uint64, _vp, _vp, _vp, _vp]),
     "mgx_gather_rows": (_i32, [_i64, _vp, _i32, _i64, _fp, _fp, _vp]),
+    "mgx_gather_rows_strided": (_i32, [_i64, _vp, _i32, _i64, _fp, _i64, _fp, _i64, _vp]),
     "mgx_scatter_add_rows": (_i32, [_i64, _vp, _i32, _i64, _fp, _fp, _vp]),
 }
 

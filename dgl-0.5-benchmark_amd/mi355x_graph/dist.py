@@ -410,7 +410,8 @@ class DistSageMeanCatFn(torch.autograd.Function):
         if static_cache is not None and static_cache.get("recv") is not None and static_cache.get("version") == h._version:
             recv, work = static_cache["recv"], _Done()
         else:
-            send = torch.index_select(h, 0, plan.send_idx.long()) if plan.send_idx.numel() else h.new_empty((0, h.shape[1]))
+            # boundary rows packed straight out of the (row-strided) left half of the layer's buffer: mgx_gather_rows_strided
+            send = be.gather_rows(h, plan.send_idx) if plan.send_idx.numel() else h.new_empty((0, h.shape[1]))
             recv = torch.empty((plan.n_halo, h.shape[1]), dtype=h.dtype, device=h.device)
             work = comm.all_to_all_async(recv, send, plan.recv_splits, plan.send_splits)
             if static_cache is not None:

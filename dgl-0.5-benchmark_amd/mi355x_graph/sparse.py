@@ -803,11 +803,19 @@ class HipBackend(object):
         return src, eid, counts
 
     def gather_rows(self, x2d, idx):
+        """out[i] = x2d[idx[i]]; x2d may be a row-strided view (stride(1) == 1) when D and the stride are multiples of 4."""
         dev = self._check_dev(x2d, idx)
-        out = torch.empty((idx.shape[0], x2d.shape[1]), dtype=torch.float32, device=dev)
+        D = int(x2d.shape[1])
+        out = torch.empty((idx.shape[0], D), dtype=torch.float32, device=dev)
+        bits = 32 if idx.dtype == torch.int32 else 64
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_gather_rows(idx.shape[0], _ptr(idx), 32 if idx.dtype == torch.int32 else 64,
-                                                  x2d.shape[1], _ptr(x2d), _ptr(out), _stream(dev)))
+            if (x2d.dim() == 2 and x2d.stride(1) == 1 and D % 4 == 0 and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0 and D > 0
+                    and x2d.stride(0) >= D):
+                _lib.check(_lib.lib().mgx_gather_rows_strided(idx.shape[0], _ptr(idx), bits, D, _ptr(x2d), int(x2d.stride(0)), _ptr(out),
+                                                              D, _stream(dev)))
+            else:
+                x2d = x2d.contiguous()
+                _lib.check(_lib.lib().mgx_gather_rows(idx.shape[0], _ptr(idx), bits, D, _ptr(x2d), _ptr(out), _stream(dev)))
         return out
 
     def scatter_add_rows(self, x2d, idx, rows2d):

@@ -429,6 +429,11 @@ int32_t mgx_coo_to_csr_host(int64_t num_rows, int64_t nnz, const void* row_host,
  *   scatter_add_rows: x[idx[i],:]  += in[i,:]   (idx sorted & unique per call => no atomics) */
 int32_t mgx_gather_rows(int64_t n, const void* idx, int32_t idx_bits, int64_t D,
                         const float* x, float* out, void* stream);
+/* The same gather over row-strided operands (round 4): x rows x_stride floats apart, out rows out_stride floats apart (both >= D,
+ * multiples of 4, 16-byte aligned pointers; else MGX_ERR_UNSUPPORTED) -- packs the boundary rows straight out of a column block of a
+ * wider matrix (the left half of the one-GEMM SAGE layer's [h | neigh] buffer). */
+int32_t mgx_gather_rows_strided(int64_t n, const void* idx, int32_t idx_bits, int64_t D, const float* x, int64_t x_stride,
+                                float* out, int64_t out_stride, void* stream);
 int32_t mgx_scatter_add_rows(int64_t n, const void* idx, int32_t idx_bits, int64_t D,
                              const float* in, float* x, void* stream);
 
