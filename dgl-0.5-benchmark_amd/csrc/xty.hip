@@ -69,6 +69,98 @@ __global__ __launch_bounds__(kBlock) void xty_partial_kernel(int64_t n, int M, i
       for (int r = 0; r < 4; ++r) p[(i * 16 + 4 * q + r) * (KT * 16) + j * 16 + c] = acc[i][j][r];
 }
 
+// Round 4: the same partial kernel with 16-BYTE operand loads.  The MFMA wants lane (c, q) to supply A[row + q][m = c] of a 16-column
+// tile -- a dword per lane, i.e. 256 bytes per load instruction for 16 rows.  But which 16 columns form a "tile" is only a labelling of the
+// OUTPUT: a lane that loads the float4 A[row][4c .. 4c+3] holds one column of FOUR tiles (tile t = component t, its 16 columns are
+// 4c + t), so a 64-column operand arrives in one 16-byte load per lane and row, and the epilogue writes accumulator (tile t, index c) to
+// column 4c + t.  Per operand: VG groups of 64 columns by float4 loads (VG * 4 tiles) + ST tiles of 16 columns by dword loads for the
+// remainder (K = 72 = one group + one tile) or for an operand whose row stride is not a multiple of 4 floats (the 47-column output
+// gradient).  Same accumulators, same partial layout, same finish kernel; fp32 MFMA, sums in another (fixed) order.
+template <int AVG, int AST, int BVG, int BST>
+__global__ __launch_bounds__(kBlock) void xty_partial_v4_kernel(int64_t n, int M, int K, int mt16, int kt16, const float* __restrict__ A,
+                                                                int64_t lda, const float* __restrict__ B, int64_t ldb,
+                                                                float* __restrict__ part) {
+  constexpr int AT = AVG * 4 + AST, BT = BVG * 4 + BST;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t gw = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int c = lane % 16, q = lane / 16;
+  v4f acc[AT][BT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int j = 0; j < BT; ++j) acc[i][j] = (v4f)(0.f);
+  const int64_t stride = (int64_t)gridDim.x * kWavesPerBlock * 16;
+  for (int64_t r0 = gw * 16; r0 < n; r0 += stride) {
+    float a[4][AT > 0 ? AT : 1], b[4][BT > 0 ? BT : 1];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int64_t row = r0 + s * 4 + q;
+      const bool ok = row < n;
+#pragma unroll
+      for (int g = 0; g < AVG; ++g) {
+        const v4f v = (ok && g * 64 + 4 * c + 3 < M) ? *reinterpret_cast<const v4f*>(A + row * lda + g * 64 + 4 * c) : (v4f)(0.f);
+        a[s][g * 4 + 0] = v.x; a[s][g * 4 + 1] = v.y; a[s][g * 4 + 2] = v.z; a[s][g * 4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int i = 0; i < AST; ++i) a[s][AVG * 4 + i] = (ok && AVG * 64 + i * 16 + c < M) ? A[row * lda + AVG * 64 + i * 16 + c] : 0.f;
+#pragma unroll
+      for (int g = 0; g < BVG; ++g) {
+        const v4f v = (ok && g * 64 + 4 * c + 3 < K) ? *reinterpret_cast<const v4f*>(B + row * ldb + g * 64 + 4 * c) : (v4f)(0.f);
+        b[s][g * 4 + 0] = v.x; b[s][g * 4 + 1] = v.y; b[s][g * 4 + 2] = v.z; b[s][g * 4 + 3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < BST; ++j) b[s][BVG * 4 + j] = (ok && BVG * 64 + j * 16 + c < K) ? B[row * ldb + BVG * 64 + j * 16 + c] : 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int j = 0; j < BT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+  }
+  // accumulator element r of tile (i, j) in lane (c, q) is C[m][k] with m / k the REAL columns behind (tile i, index 4q + r) / (tile j, index c)
+  float* p = part + gw * (int64_t)mt16 * kt16;
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+      const int k = j < BVG * 4 ? (j / 4) * 64 + 4 * c + (j % 4) : BVG * 64 + (j - BVG * 4) * 16 + c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mi = 4 * q + r;
+        const int m = i < AVG * 4 ? (i / 4) * 64 + 4 * mi + (i % 4) : AVG * 64 + (i - AVG * 4) * 16 + mi;
+        if (m < mt16 && k < kt16) p[m * kt16 + k] = acc[i][j][r];
+      }
+    }
+}
+
+template <int AVG, int AST>
+static bool launch_xty_v4_b(int bvg, int bst, int waves, int64_t n, int M, int K, int mt16, int kt16, const float* A, int64_t lda,
+                            const float* B, int64_t ldb, float* part, hipStream_t s) {
+#define MGX_XTY4(G, T) if (bvg == G && bst == T) { hipLaunchKernelGGL((xty_partial_v4_kernel<AVG, AST, G, T>), dim3(waves / kWavesPerBlock), dim3(kBlock), 0, s, n, M, K, mt16, kt16, A, lda, B, ldb, part); return true; }
+  MGX_XTY4(2, 0) MGX_XTY4(1, 0) MGX_XTY4(1, 1) MGX_XTY4(1, 2) MGX_XTY4(1, 3) MGX_XTY4(1, 4)
+#undef MGX_XTY4
+  return false;
+}
+
+// 16-byte loads for the operand(s) that allow it; false = use the dword kernels above
+static bool launch_xty_v4(int mt, int kt, int waves, int64_t n, int M, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                          float* part, hipStream_t s) {
+  if (MGX_ENV_FLAG("MGX_XTY_V1")) return false;  // A/B switch
+  const bool bvec = ldb % 4 == 0 && (uintptr_t)B % 16 == 0 && K % 4 == 0 && K >= 64;
+  if (!bvec) return false;
+  const int bvg = K >= 128 ? 2 : 1, bst = (K - bvg * 64 + 15) / 16;
+  const bool avec = lda % 4 == 0 && (uintptr_t)A % 16 == 0 && M == 64;
+  const int mt16 = mt * 16, kt16 = kt * 16;
+  if (avec) return launch_xty_v4_b<1, 0>(bvg, bst, waves, n, M, K, mt16, kt16, A, lda, B, ldb, part, s);
+  switch (mt) {
+    case 1: return launch_xty_v4_b<0, 1>(bvg, bst, waves, n, M, K, mt16, kt16, A, lda, B, ldb, part, s);
+    case 2: return launch_xty_v4_b<0, 2>(bvg, bst, waves, n, M, K, mt16, kt16, A, lda, B, ldb, part, s);
+    case 3: return launch_xty_v4_b<0, 3>(bvg, bst, waves, n, M, K, mt16, kt16, A, lda, B, ldb, part, s);
+    default: return launch_xty_v4_b<0, 4>(bvg, bst, waves, n, M, K, mt16, kt16, A, lda, B, ldb, part, s);
+  }
+}
+
 // 16 output elements x 16 slices of the partial list per workgroup; slices combined in slice order
 __global__ __launch_bounds__(kBlock) void xty_finish_kernel(int M, int K, int ldm /* KT*16 */, int tile /* MT*16*KT*16 */, int waves,
                                                             const float* __restrict__ part, float* __restrict__ out, int64_t ldc) {
@@ -243,8 +335,8 @@ extern "C" int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int6
     return MGX_OK;
   }
   const int waves = xty_waves(n);
-  bool ok = false;
-  switch (mt) {
+  bool ok = launch_xty_v4(mt, kt, waves, n, (int)M, (int)K, a, lda, b, ldb, part, s);
+  if (!ok) switch (mt) {
     case 1: ok = launch_xty_kt<1>(kt, waves, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
     case 2: ok = launch_xty_kt<2>(kt, waves, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
     case 3: ok = launch_xty_kt<3>(kt, waves, n, (int)M, (int)K, a, lda, b, ldb, part, s); break;
