@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-pmc --no-controls --no-plain"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-pmc --no-controls --no-plain --no-scale-model"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_bench_trace -- $BENCH --steps 5 --warmup 2 > $O/${TAG}_bench_trace.log 2>&1
 python3 $R/experiments/epoch_timeline.py $O/${TAG}_bench_trace > $O/${TAG}_epoch_timeline.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_bench_fetch -- $BENCH --steps 3 --warmup 1 > $O/${TAG}_bench_fetch.log 2>&1
@@ -26,5 +26,6 @@ python3 $R/profiles/summarize.py ${TAG}_molhiv $O/${TAG}_molhiv_trace >> $O/${TA
 cp $R/profiles/${TAG}_*kernel_stats.txt $R/profiles/${TAG}_pmc_summary.txt $O/ 2>/dev/null
 (python3 $R/profiles/gat_roofline.py $O/${TAG}_gat8_trace 232965 11839883 8 16; python3 $R/profiles/gat_roofline.py $O/${TAG}_gat8_trace 232965 11839883 1 41) > $O/${TAG}_gat8_roofline.txt 2>&1
 python3 $R/dgl-0.5-benchmark_amd/generate_result.py --out $O/${TAG}_generate_result.csv > $O/${TAG}_generate_result.txt 2>&1
+python3 $R/bench.py --emulate-ranks 2,4,8 --steps 10 --warmup 3 --report $O/${TAG}_scale_model.txt > $O/${TAG}_emu_bench_line.json 2> $O/${TAG}_emu_bench_line.err
 python3 $R/bench.py --steps 10 --warmup 3 > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench_line.err
 tail -c 600 $O/${TAG}_bench_line.json
