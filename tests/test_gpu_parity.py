@@ -800,3 +800,22 @@ def test_wide_rows_are_aggregated_on_a_line_padded_copy(oracle):
     rp, rx, re = oracle.coo_to_csr(n, src, dst)
     ref = oracle.spmm(rp, rx, re, "copy_lhs", "sum", (w.cpu().numpy() / deg[:, None]).astype(np.float32), None)
     assert rel(x.grad.cpu(), ref) < RTOL
+
+
+@pytest.mark.parametrize("D", [4, 16, 64, 100, 128, 260, 7])
+def test_gather_rows_dense_strided_and_odd_widths(D):
+    """mgx_gather_rows / mgx_gather_rows_strided (the pack of a partition's boundary rows, dist.py): bit-exact row copies out of a dense
+    matrix, out of the left half of a wider one (row stride 2 D + 8), with int32 and int64 indices, repeated and out-of-order rows."""
+    from mi355x_graph import sparse
+    rng = np.random.default_rng(D)
+    n, m = 5000, 12345
+    wide = T(rng.standard_normal((n, 2 * D + 8)).astype(np.float32))
+    dense = wide[:, :D].contiguous()
+    be = sparse.backend_for(wide)
+    for dtype in (torch.int32, torch.int64):
+        idx = torch.from_numpy(rng.integers(0, n, m)).to(DEV).to(dtype)
+        want = dense[idx.long()]
+        assert torch.equal(be.gather_rows(dense, idx), want)
+        assert torch.equal(be.gather_rows(wide[:, :D], idx), want)          # strided view (falls back to a dense copy for odd D)
+        assert torch.equal(be.gather_rows(wide[:, 8:8 + D], idx), wide[:, 8:8 + D].contiguous()[idx.long()])
+    assert be.gather_rows(dense, torch.zeros(0, dtype=torch.int32, device=DEV)).shape == (0, D)
