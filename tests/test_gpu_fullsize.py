@@ -362,3 +362,22 @@ def test_int32_ids_with_a_gathered_matrix_beyond_4_gib(oracle):
     else:
         ref = oracle.spmm(ip, ix, ei, "copy_lhs", "sum", xh, None)
         assert_rows_close(out.cpu().numpy(), ref, np.abs(ref), np.diff(ip), "strided, 9 GB operand")
+
+
+def test_reddit_full_size_tile_kernel_every_row_against_the_oracle(reddit_full, oracle):
+    """kernel/dgl-new.py:61 at the dataset's own size (N = 232,965, E = 114,615,892, 492 in-edges per node): what gspmm selects here is
+    the LDS-staged TILE kernel (64- and 16-column geometries) -- every output element against the oracle, hub rows of 21 k terms included."""
+    from mi355x_graph import _lib
+    g, src, dst, n = reddit_full
+    oracle.set_num_threads(_host_cores())
+    ip, ix, ei = oracle.coo_to_csr(n, dst.to(torch.int32).cpu().numpy(), src.to(torch.int32).cpu().numpy())
+    csc = g._index.csc()
+    assert np.array_equal(ip, csc.indptr.cpu().numpy()) and np.array_equal(ix, csc.indices.cpu().numpy())
+    deg = np.diff(ip)
+    for D in (64, 16):
+        gen = torch.Generator(device=DEV).manual_seed(200 + D)
+        x = torch.rand(n, D, device=DEV, generator=gen)
+        got = ops.gspmm(g, "copy_lhs", "mean", x, None).cpu().numpy()
+        assert _lib.lib().mgx_last_spmm_kernel().decode() == "tile"
+        ref = oracle.spmm(ip, ix, ei, "copy_lhs", "mean", x.cpu().numpy(), None)
+        assert_rows_close(got, ref, np.abs(ref), deg, "reddit E = 114.6 M, tile kernel, D=%d" % D)
