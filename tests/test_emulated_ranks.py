@@ -268,3 +268,38 @@ def test_every_rank_of_a_partition_on_the_hip_path_matches_one_gpu(world):
     # every rank ends on the same gradients bit for bit (rank-ordered sum)
     for a, b in zip(res[0][3], res[-1][3]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_bench_emulate_ranks_line_carries_the_scaling_model(tmp_path):
+    """`python bench.py --emulate-ranks 2,4` end to end on a 2 % graph: the N = 1 line gains config.partition.predicted with, per P, the
+    per-rank compute, the halo bytes and the priced epochs; every emulated partition ends on the 1-GPU loss (dropout 0); the report
+    file is written."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    report = str(tmp_path / "scale.txt")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--scale", "0.02", "--steps", "2", "--warmup", "1", "--dropout", "0",
+           "--emulate-ranks", "2,4", "--report", report]
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["ms_per_step"] > 0
+    pred = line["config"]["partition"]["predicted"]
+    assert "MODEL" in pred["kind"] and abs(pred["epoch_ms_1gpu_measured"] - line["ms_per_step"]) < 1e-2
+    for P in (2, 4):
+        m = pred["P=%d" % P]
+        assert "error" not in m, m
+        assert len(m["per_rank"]) == P and all(r["owned_rows"] > 0 and r["compute_ms"] > 0 for r in m["per_rank"])
+        assert sum(r["owned_rows"] for r in m["per_rank"]) == line["roofline"]["rows"]
+        assert abs(m["final_loss"] - line["config"]["final_loss"]) <= 1e-4 * max(1.0, abs(line["config"]["final_loss"]))
+        assert m["exchanges_per_epoch"] == 4 and m["max_pair_bytes_per_exchange"] > 0
+        fast, slow = m["predicted"]["64 GB/s per link"], m["predicted"]["32 GB/s per link"]
+        assert 0 < fast["epoch_ms_overlapped"] <= slow["epoch_ms_overlapped"]
+        assert fast["epoch_ms_overlapped"] <= fast["epoch_ms_not_overlapped"] + 1e-9
+        assert m["predicted"]["no exchange cost (compute only, lock step)"]["epoch_ms_overlapped"] <= fast["epoch_ms_overlapped"] + 1e-9
+    text = open(report).read()
+    assert "== P = 2" in text and "== P = 4" in text and "halo MB per exchange" in text
