@@ -446,6 +446,7 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
 
   int r = wave;
   if (r >= a.rpb || item_base + r >= item_stop) return;
+  const bool early_accum = a.accum && !a.mean && a.dst_scale == nullptr;  // wave-uniform: see the accumulator's initial value below
   int64_t row;
   int32_t beg, end;
   load_meta(item_base + r, row, beg, end);
@@ -470,7 +471,13 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
       load_meta(item_base + rn, nrow, nbeg, nend);
       load_ids(nbeg, nend, ngoff, neid, nsc, ncnt0, ngidx);
     }
+    // out += result (MGX_SPMM_ACCUMULATE: the backward aggregation of the one-node SAGE layer): the row to add to is requested
+    // BEFORE the item's gathers, not in the epilogue, where its round trip was paid per item with nothing left to hide it behind
+    // (products D = 64: the accumulating launch ran 2.63 ms against 2.26 ms for the plain one for 0.11 ms worth of bytes)
+    // -- as the INITIAL value of lane group 0's accumulator (no register of its own: 65 VGPRs, 7 waves per SIMD as before), which is
+    // exact when nothing scales the sum afterwards (no mean, no dst_scale: the backward launches); scaled sums add it in the epilogue.
     V acc = (V)(0.f);
+    if (early_accum && row >= 0 && factive && sub == 0 && !tail) acc = *reinterpret_cast<const V*>(a.out + row * (int64_t)a.ldo + f);
     for (int32_t cbase = beg; cbase < end; cbase += kWave) {
       int cnt = cnt0;
       if (cbase != beg) {
@@ -511,7 +518,7 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
       if (!tail) {
         if (row >= 0) {  // separate pointers: the output store keeps its non-temporal hint
           float* op = a.out + row * (int64_t)a.ldo + f;
-          if (a.accum) acc += *reinterpret_cast<const V*>(op);
+          if (a.accum && !early_accum) acc += *reinterpret_cast<const V*>(op);
           __builtin_nontemporal_store((VA)acc, reinterpret_cast<V*>(op));
         } else {
           *reinterpret_cast<V*>(a.partial + (-(row + 1)) * (int64_t)a.D + f) = acc;

