@@ -227,6 +227,9 @@ def main():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--dataset", default="products")
     p.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; makes the line invalid)")
+    p.add_argument("--mixing", type=float, default=None,
+                   help="share of edges that leave their planted community (the benchmark graph: 0.25).  A CONTROL for the scaling "
+                        "model -- any other value makes the line a control, not the benchmark (config.workload says so)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     p.add_argument("--no-controls", action="store_true", help="skip the control graphs (roofline.controls)")
@@ -288,7 +291,8 @@ def main():
     spec = SHAPES[cfg["dataset"]]
     n = max(64, int(spec["n"] * args.scale))
     m = max(64, int(spec["m"] * args.scale))
-    src, dst = synthetic_edges(n, m, min(spec["max_deg"], n - 1), spec["seed"], device, symmetric=spec["symmetric"])
+    gen_kw = {} if args.mixing is None else {"mixing": args.mixing}
+    src, dst = synthetic_edges(n, m, min(spec["max_deg"], n - 1), spec["seed"], device, symmetric=spec["symmetric"], **gen_kw)
     num_edges = int(src.shape[0])
     torch.cuda.synchronize()
     progress("graph generated on the device (%d edges)" % num_edges)
@@ -480,7 +484,8 @@ def main():
         "config": {"workload": "configs[3]: 3-layer GraphSAGE full-graph on ogbn-products shape "
                                "(N=%d, E=%d directed, D=%d->%d->%d->%d), %s" %
                                (n, num_edges, spec["feat"], cfg["hidden"], cfg["hidden"], spec["classes"],
-                                "1 GPU" if world == 1 else "edge-cut partition over %d GPUs, RCCL all_to_all halo" % world),
+                                "1 GPU" if world == 1 else "edge-cut partition over %d GPUs, RCCL all_to_all halo" % world)
+                               + ("" if args.mixing is None else " -- CONTROL GRAPH: %g of the edges leave their community (benchmark: 0.25)" % args.mixing),
                    "spmm_per_epoch": 2 * cfg["num_layers"] - 1, "final_loss": loss,
                    "schedule": os.environ.get("MGX_SCHEDULE", "auto"), "partition": part_stats,
                    "module_graph": "full_graph.GraphSAGE (default form): a SAGE layer as ONE GEMM on [h | mean_agg(h)], the same form on "
