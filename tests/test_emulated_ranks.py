@@ -304,3 +304,15 @@ def test_bench_emulate_ranks_line_carries_the_scaling_model(tmp_path):
         assert m["predicted"]["no exchange cost (compute only, lock step)"]["epoch_ms_overlapped"] <= fast["epoch_ms_overlapped"] + 1e-9
     text = open(report).read()
     assert "== P = 2" in text and "== P = 4" in text and "halo MB per exchange" in text
+    # the emulated world against a REAL 2-process run of the same program (both ranks on cuda:0, gloo staging): the emulation took
+    # warm-up 1 + one discarded traced step + 2 timed steps = 4 optimizer steps, so does `--warmup 1 --steps 3`
+    real = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "3", "--warmup", "1",
+                           "--dropout", "0", "--no-pmc", "--no-controls", "--no-cpu-baseline", "--no-plain"],
+                          env=dict(env, MGX_BENCH_SHARE_GPU="1", MGX_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=600)
+    assert real.returncode == 0, real.stdout[-1500:] + real.stderr[-3000:]
+    two = json.loads([ln for ln in real.stdout.splitlines() if ln.startswith("{")][-1])
+    assert two["n_gpus"] == 2
+    assert abs(two["config"]["final_loss"] - pred["P=2"]["final_loss"]) <= 1e-4 * max(1.0, abs(two["config"]["final_loss"]))
+    real_rows = sorted(r["owned_rows"] for r in two["config"]["partition"]["per_rank"])
+    assert real_rows == sorted(r["owned_rows"] for r in pred["P=2"]["per_rank"])            # the same partition
+    assert sorted(r["halo_rows"] for r in two["config"]["partition"]["per_rank"]) == sorted(r["halo_rows"] for r in pred["P=2"]["per_rank"])
