@@ -545,6 +545,18 @@ def main():
             finally:
                 os.environ["MGX_SAGE_L1_PROJECT_FIRST"] = "0"
             torch.cuda.empty_cache()
+            # both exact variants together (still not the headline)
+            if os.environ.get("MGX_SAGE_SPARSE_LAST", "0") != "1":
+                os.environ["MGX_SAGE_L1_PROJECT_FIRST"] = os.environ["MGX_SAGE_SPARSE_LAST"] = "1"
+                try:
+                    bm = make_model()
+                    bopt = torch.optim.Adam(bm.parameters(), lr=cfg["lr"])
+                    bel, bloss, _ = timed(make_step(bm, bopt, None), psteps, min(args.warmup, 3), False)
+                    line["epoch_ms_both_exact_variants"] = round(bel / psteps * 1e3, 3)
+                    del bm, bopt
+                finally:
+                    os.environ["MGX_SAGE_L1_PROJECT_FIRST"] = os.environ["MGX_SAGE_SPARSE_LAST"] = "0"
+                torch.cuda.empty_cache()
 
     # ---- the 2 / 4 / 8-GPU curve as a MODEL measured on this one GPU: every rank of the partitioned program run here, one at a
     # time, exchanges priced per xGMI link (scale_model.py; never a measured multi-GPU number, and labelled so)
