@@ -120,7 +120,23 @@ class GATConv(nn.Module):
             return False  # frozen mask under capture: see forward
         return ops.gat_fused_supported(graph, feat.view(feat.shape[0], 1, k))
 
-    def forward(self, graph, feat, get_attention=False):
+    def _forward_on_partition(self, graph, feat):
+        """A partition of the graph (dist.DistGraph): every owned node has all its in-edges here, its remote in-neighbours'
+        rows travel ONCE per layer -- the layer's input or its projection, whichever is narrower (reddit: 602 -> 16: the 16 projected
+        columns) -- through the halo exchange (autograd adds the halo rows' gradients back into their owners), and the layer then
+        runs on the local block graph [owned | halo] -> owned exactly as on a sampled block."""
+        h = self.feat_drop(feat)
+        blk = graph._block
+        if self._in_src_feats <= self._num_heads * self._out_feats:
+            return self.forward(blk, graph.halo_exchange(h), _dropped=True)
+        proj = graph.halo_exchange(self.fc(h))                      # [n_own + n_halo, H * F]
+        return self.forward(blk, h, _projected=proj)
+
+    def forward(self, graph, feat, get_attention=False, _dropped=False, _projected=None):
+        if hasattr(graph, "halo_exchange") and _projected is None and not _dropped:
+            if isinstance(feat, tuple) or get_attention or not hasattr(self, "fc"):
+                raise DGLError("GATConv on a partitioned graph takes one feature tensor of the owned nodes (no attention output)")
+            return self._forward_on_partition(graph, feat)
         with graph.local_scope():
             if not self._allow_zero_in_degree:
                 if _has_zero_in_degree(graph):
@@ -130,11 +146,11 @@ class GATConv(nn.Module):
                         "Adding self-loop on the input graph by calling `g = dgl.add_self_loop(g)` will resolve "
                         "the issue. Setting ``allow_zero_in_degree`` to be `True` when constructing this module "
                         "will suppress the check and let the code run.")
-            if self._aggregate_first(graph, feat, get_attention):
+            if _projected is None and self._aggregate_first(graph, feat, get_attention):
                 # ONE head: a[e] is a scalar, so sum_e a[e] (h[u] W^T) = (sum_e a[e] h[u]) W^T and el = h (W^T attn_l): the
                 # fused block runs at the INPUT width and the projection follows it (reddit GAT's 16 -> 41 output layer:
                 # three gather walks at 64-byte rows instead of 164-byte ones).  Same function, other fp32 summation order.
-                h = self.feat_drop(feat)
+                h = feat if _dropped else self.feat_drop(feat)
                 w = self.fc.weight                                    # [F, in]
                 v = torch.cat([self.attn_l.view(1, -1), self.attn_r.view(1, -1)], 0) @ w  # [2, in]
                 lr = h @ v.t()                                        # [N, 2]: el, er
@@ -150,7 +166,11 @@ class GATConv(nn.Module):
                 if self.activation:
                     rst = self.activation(rst)
                 return rst
-            if isinstance(feat, tuple):
+            if _projected is not None:  # a partition: `feat` = the owned rows after feat_drop, `_projected` = fc of [owned | halo]
+                h_dst = feat
+                feat_src = _projected.view(-1, self._num_heads, self._out_feats)
+                feat_dst = feat_src[:graph.number_of_dst_nodes()]
+            elif isinstance(feat, tuple):
                 h_src = self.feat_drop(feat[0])
                 h_dst = self.feat_drop(feat[1])
                 if not hasattr(self, "fc_src"):
@@ -160,7 +180,7 @@ class GATConv(nn.Module):
                     feat_src = self.fc_src(h_src).view(-1, self._num_heads, self._out_feats)
                     feat_dst = self.fc_dst(h_dst).view(-1, self._num_heads, self._out_feats)
             else:
-                h_src = h_dst = self.feat_drop(feat)
+                h_src = h_dst = feat if _dropped else self.feat_drop(feat)
                 feat_src = feat_dst = self.fc(h_src).view(-1, self._num_heads, self._out_feats)
                 if graph.is_block:
                     feat_dst = feat_src[:graph.number_of_dst_nodes()]

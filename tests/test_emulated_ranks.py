@@ -316,3 +316,71 @@ def test_bench_emulate_ranks_line_carries_the_scaling_model(tmp_path):
     real_rows = sorted(r["owned_rows"] for r in two["config"]["partition"]["per_rank"])
     assert real_rows == sorted(r["owned_rows"] for r in pred["P=2"]["per_rank"])            # the same partition
     assert sorted(r["halo_rows"] for r in two["config"]["partition"]["per_rank"]) == sorted(r["halo_rows"] for r in pred["P=2"]["per_rank"])
+
+
+def _gat_problem(world):
+    import test_dist
+    n, src, dst, feats, labels, train, assign = test_dist.make_ring_problem(world)
+    loops = torch.arange(n)
+    return n, torch.cat([src, loops]), torch.cat([dst, loops]), feats, labels, train, assign   # dgl.add_self_loop: no 0-in-degree node
+
+
+def _gat_model(g, device="cpu"):
+    import full_graph
+    torch.manual_seed(3)
+    # layer 1: 12 -> 2 heads x 8 (input narrower than its projection: the INPUT rows travel); layer 2: 16 -> 1 head x 5 (the PROJECTED rows)
+    return full_graph.GAT(g, 2, 12, 8, 5, [2, 1], feat_drop=0.0, attn_drop=0.0).to(device)
+
+
+def _run_gat_partition(world, device):
+    import torch.nn.functional as F
+    n, src, dst, feats, labels, train, assign = [t.to(device) if isinstance(t, torch.Tensor) else t for t in _gat_problem(world)]
+    g1 = mg.graph((src, dst), num_nodes=n).int()
+    ref_model = _gat_model(g1, device)
+    ref_out = ref_model(feats)
+    ref_loss = F.nll_loss(ref_out.log_softmax(-1)[train], labels[train])
+    ref_loss.backward()
+    ref_grads = [p.grad.clone() for p in ref_model.parameters()]
+
+    def body(rank):
+        block, plan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
+        g = mdist.DistGraph(block, plan)
+        model = _gat_model(g, device)
+        mdist.broadcast_parameters(model)
+        x, y, m = feats[own], labels[own], train[own]
+        bucket = mdist.GradBucket(model)
+        bucket.zero()
+        out = model(x)
+        loss = F.nll_loss(out.log_softmax(-1)[m], y[m], reduction="sum") / float(train.sum())
+        loss.backward()
+        bucket.all_reduce()
+        lsum = loss.detach().clone()
+        mdist.all_reduce(lsum)
+        return own, out.detach(), float(lsum), [p.grad.clone() for p in model.parameters()], g._comm.n_exchanges
+
+    res = emulate.EmuWorld(world, None if device == "cpu" else device).run(body)
+    got = torch.zeros_like(ref_out.detach())
+    for own, out, lsum, grads, n_ex in res:
+        got[own] = out
+        assert n_ex == 3        # one exchange per layer forward, one backward for layer 2 (the input features need no gradient)
+        assert abs(lsum - float(ref_loss)) < 1e-5 * max(1.0, abs(float(ref_loss)))
+        for a, b in zip(grads, ref_grads):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), float((a - b).abs().max())
+    assert torch.allclose(got, ref_out.detach(), rtol=1e-4, atol=1e-6)
+
+
+def test_gat_on_a_partition_matches_single_process_on_cpu():
+    """GATConv on a dist.DistGraph (main_dgl_reddit_gat.py's model, partitioned): the layer's input rows or its projected rows cross the
+    halo exchange once per layer, the block then runs as a sampled block does; 4 ranks, uneven ring, against the 1-process model."""
+    oracle_backend.install()
+    try:
+        _run_gat_partition(4, "cpu")
+    finally:
+        oracle_backend.uninstall()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_gat_on_a_partition_on_the_hip_path():
+    """The same on cuda:0: the fused GAT kernels on the bipartite [owned | halo] -> owned blocks of every rank."""
+    _run_gat_partition(4, "cuda:0")
