@@ -565,6 +565,13 @@ class DistGraph(DGLGraph):
     def halo_exchange(self, x):
         return HaloExchange.apply(x, self._plan, self._comm)
 
+    def out_degrees(self, u="__ALL__"):
+        # the local block holds the owned nodes' IN-edges only; their out-edges into other parts live on other ranks
+        raise DGLError("out_degrees() is not available on a partition (dist.DistGraph holds in-edges only); "
+                       "take the degrees on the whole graph before partitioning")
+
+    out_degree = out_degrees
+
     def _local(self, fields):
         src = Frame(self._plan.n_own + self._plan.n_halo, kind="node")
         for f in fields:
