@@ -481,9 +481,11 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "value_spmm_only_edges_per_s": (agg_edges / (spmm_ms_per_epoch * 1e-3)) if spmm_ms_per_epoch > 0 and world == 1 else None,
         "spmm_ms_per_epoch": round(spmm_ms_per_epoch, 4) if world == 1 else None,
-        "config": {"workload": "configs[3]: 3-layer GraphSAGE full-graph on ogbn-products shape "
-                               "(N=%d, E=%d directed, D=%d->%d->%d->%d), %s" %
-                               (n, num_edges, spec["feat"], cfg["hidden"], cfg["hidden"], spec["classes"],
+        "config": {"workload": "%s %d-layer GraphSAGE full-graph on %s shape "
+                               "(N=%d, E=%d directed, D=%s), %s" %
+                               ("configs[3]:" if args.dataset == "products" else "(not the headline workload)", cfg["num_layers"],
+                                "ogbn-products" if args.dataset == "products" else "the " + args.dataset,
+                                n, num_edges, "->".join(str(v) for v in [spec["feat"]] + [cfg["hidden"]] * (cfg["num_layers"] - 1) + [spec["classes"]]),
                                 "1 GPU" if world == 1 else "edge-cut partition over %d GPUs, RCCL all_to_all halo" % world)
                                + ("" if args.mixing is None else " -- CONTROL GRAPH: %g of the edges leave their community (benchmark: 0.25)" % args.mixing),
                    "spmm_per_epoch": 2 * cfg["num_layers"] - 1, "final_loss": loss,

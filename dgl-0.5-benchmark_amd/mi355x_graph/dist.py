@@ -476,6 +476,65 @@ class DistSageMeanCatFn(torch.autograd.Function):
         return None, None, None, dh, dws, dwn, db, None
 
 
+class DistSageProjectFirstFn(torch.autograd.Function):
+    """ops.SageMeanProjectFirstFn on a partition: y = h W_self^T + mean_agg(h W_neigh^T) + b with the aggregation -- and the halo exchange
+    -- at the OUTPUT width (main_dgl_reddit_sage.py:73-80: 602 -> 16, so a boundary row travels as 16 floats instead of 602):
+
+      forward   s = h W_self^T (+ b), z = h W_neigh^T; pack boundary rows of z -> all_to_all (async) || aggregation of z over owned
+                sources accumulating into s -> wait -> aggregation of the received z rows accumulating into s
+      backward  dn = dy / deg; halo-row gradients of z first -> all_to_all (async) || reversed aggregation over owned rows -> wait ->
+                returned rows added; dW_self = dy^T h, dW_neigh = dz^T h, dh = dy W_self + dz W_neigh."""
+
+    @staticmethod
+    def forward(ctx, plan, comm, h, w_self, w_neigh, bias):
+        be = sparse.backend_for(h)
+        comm.mark("dense")
+        s = torch.nn.functional.linear(h, w_self, bias)
+        z = torch.nn.functional.linear(h, w_neigh)
+        comm.mark("pack")
+        send = be.gather_rows(z, plan.send_idx) if plan.send_idx.numel() else z.new_empty((0, z.shape[1]))
+        recv = torch.empty((plan.n_halo, z.shape[1]), dtype=z.dtype, device=z.device)
+        work = comm.all_to_all_async(recv, send, plan.recv_splits, plan.send_splits)
+        comm.mark("owned-source aggregation")
+        sparse.gspmm_raw(plan.loc.csc(), "copy_lhs", "sum", z, None, dst_scale=plan.inv_deg, accumulate_into=s)
+        work.wait()
+        comm.mark("halo-source aggregation")
+        if plan.n_halo:
+            sparse.gspmm_raw(plan.halo.csc(), "copy_lhs", "sum", recv, None, dst_scale=plan.inv_deg, accumulate_into=s)
+        comm.mark("dense")
+        ctx.plan, ctx.comm = plan, comm
+        ctx.save_for_backward(h, w_self, w_neigh)
+        return s
+
+    @staticmethod
+    @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
+    def backward(ctx, dy):
+        from . import ops
+        h, w_self, w_neigh = ctx.saved_tensors
+        plan, comm = ctx.plan, ctx.comm
+        need = ctx.needs_input_grad
+        be = sparse.backend_for(dy)
+        dy = dy.contiguous()
+        dn = dy * plan.inv_deg.view(-1, 1)  # d(sum / deg)
+        K = dy.shape[1]
+        back = torch.empty((plan.send_idx.shape[0], K), dtype=dy.dtype, device=dy.device)
+        comm.mark("halo-row gradients")
+        g_halo = sparse.gspmm_grad_raw(plan.halo.csr(), dn) if plan.n_halo else dy.new_empty((0, K))
+        work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
+        comm.mark("owned-row reversed aggregation")
+        dz = sparse.gspmm_grad_raw(plan.loc.csr(), dn, dense_out=True)
+        comm.mark("dense (inside the exchange window)")
+        dws = ops._weight_grad(dy, h) if need[3] else None
+        db = be.column_sum(dy) if need[5] else None
+        work.wait()
+        comm.mark("return-add")
+        plan.add_returned_rows(dz, back)
+        comm.mark("dense")
+        dwn = ops._weight_grad(dz, h) if need[4] else None
+        dh = (dy @ w_self).addmm_(dz, w_neigh) if need[2] else None
+        return None, None, dh, dws, dwn, db
+
+
 class HaloExchange(torch.autograd.Function):
     """x_own [n_own, ...] -> [n_own + n_halo, ...]; backward adds halo gradients into their owners."""
 
@@ -608,6 +667,20 @@ class DistGraph(DGLGraph):
     def apply_edges(self, func, edges="__ALL__", etype=None):
         blk = self._local(self._u_fields(func))
         core.apply_edges(blk, func)
+
+    def sage_project_first(self, h, w_self, w_neigh, bias):
+        """SAGEConv with the projection before the aggregation on this partition (ops.sage_project_first dispatches here); None when
+        the reference's order (aggregate, then project) moves fewer columns -- the rule of the one-GPU form."""
+        K, D = w_self.shape
+        plan = self._plan
+        if (plan.loc is None or h.dim() != 2 or h.dtype != torch.float32 or h.shape[0] != plan.n_own or h.shape[1] != D
+                or not torch.is_grad_enabled() or os.environ.get("MGX_SAGE_PROJECT_FIRST", "1") != "1"
+                or (bias is not None and K > getattr(sparse.backend_for(h), "COLUMN_SUM_MAX", 256))):
+            return None
+        aggs_now = 2 if h.requires_grad else 1
+        if 2 * max(K, 16) * 1.1 > aggs_now * D:
+            return None
+        return DistSageProjectFirstFn.apply(plan, self._comm, h, w_self, w_neigh, bias)
 
     def sage_mean_layer(self, h, w_self, w_neigh, bias, cat):
         """The one-GEMM SAGE layer on this partition (ops.sage_mean_layer dispatches here); None when it does not apply."""

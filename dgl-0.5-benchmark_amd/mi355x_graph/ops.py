@@ -973,6 +973,8 @@ def sage_project_first(g, h, w_self, w_neigh, bias=None):
     DGLGraph, 2-D float32 HIP features, out_feats a multiple of 4, and TWO aggregations at the output width (forward and
     backward) cheaper than ONE at the input width (the input needs no gradient) resp. two (it does)."""
     K, D = w_self.shape
+    if hasattr(g, "sage_project_first"):  # dist.DistGraph: the same form with the halo exchange at the output width
+        return g.sage_project_first(h, w_self, w_neigh, bias)
     if (type(g) is not DGLGraph or g.is_block or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda
             or h.device.type not in sparse._BACKENDS or not torch.is_grad_enabled() or g.idtype != torch.int32
             or g.number_of_src_nodes() != g.number_of_dst_nodes() or h.shape[0] != g.number_of_src_nodes()

@@ -384,3 +384,70 @@ def test_gat_on_a_partition_matches_single_process_on_cpu():
 def test_gat_on_a_partition_on_the_hip_path():
     """The same on cuda:0: the fused GAT kernels on the bipartite [owned | halo] -> owned blocks of every rank."""
     _run_gat_partition(4, "cuda:0")
+
+
+def _run_sage_project_first(world, device):
+    """dist.DistSageProjectFirstFn (reddit's 602 -> 16 layer on a partition: the boundary rows travel at the OUTPUT width): a 2-layer SAGE
+    whose first layer narrows 40 -> 8 (constant input), against the 1-process model."""
+    import torch.nn.functional as F
+    import test_dist
+    import full_graph
+    n, src, dst, feats, labels, train, assign = [t.to(device) if isinstance(t, torch.Tensor) else t for t in test_dist.make_ring_problem(world)]
+    torch.manual_seed(9)
+    wide = torch.rand(n, 40).to(device)
+
+    def model():
+        torch.manual_seed(4)
+        return full_graph.GraphSAGE(40, 8, 5, 2, dropout=0.0).to(device)
+
+    g1 = mg.graph((src, dst), num_nodes=n).int()
+    ref = model()
+    ref_out = ref(g1, wide)
+    F.nll_loss(ref_out[train], labels[train]).backward()
+    ref_grads = [p.grad.clone() for p in ref.parameters()]
+    taken = {"n": 0}
+    orig = mdist.DistSageProjectFirstFn.forward
+
+    def counting(*a, **k):
+        taken["n"] += 1
+        return orig(*a, **k)
+
+    def body(rank):
+        block, plan, own = mdist.build_local_partition(src, dst, n, assign, rank, world)
+        g = mdist.DistGraph(block, plan)
+        m = model()
+        mdist.broadcast_parameters(m)
+        x, y, msk = wide[own], labels[own], train[own]
+        bucket = mdist.GradBucket(m)
+        bucket.zero()
+        out = m(g, x)
+        (F.nll_loss(out[msk], y[msk], reduction="sum") / float(train.sum())).backward()
+        bucket.all_reduce()
+        return own, out.detach(), [p.grad.clone() for p in m.parameters()]
+
+    mdist.DistSageProjectFirstFn.forward = staticmethod(counting)
+    try:
+        res = emulate.EmuWorld(world, None if device == "cpu" else device).run(body)
+    finally:
+        mdist.DistSageProjectFirstFn.forward = staticmethod(orig)
+    assert taken["n"] == world          # layer 1 (40 -> 8, constant input) projects first on every rank; layer 2 (8 -> 5) does not
+    got = torch.zeros_like(ref_out.detach())
+    for own, out, grads in res:
+        got[own] = out
+        for a, b in zip(grads, ref_grads):
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), float((a - b).abs().max())
+    assert torch.allclose(got, ref_out.detach(), rtol=1e-4, atol=1e-6)
+
+
+def test_sage_projecting_first_on_a_partition_matches_single_process_on_cpu():
+    oracle_backend.install()
+    try:
+        _run_sage_project_first(3, "cpu")
+    finally:
+        oracle_backend.uninstall()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_sage_projecting_first_on_a_partition_on_the_hip_path():
+    _run_sage_project_first(4, "cuda:0")
