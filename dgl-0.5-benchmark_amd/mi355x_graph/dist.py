@@ -674,6 +674,7 @@ class DistGraph(DGLGraph):
         K, D = w_self.shape
         plan = self._plan
         if (plan.loc is None or h.dim() != 2 or h.dtype != torch.float32 or h.shape[0] != plan.n_own or h.shape[1] != D
+                or K % 4 or K > 128  # the one-GPU form's widths (ops.sage_project_first): N = 1 and N > 1 run the same module graph
                 or not torch.is_grad_enabled() or os.environ.get("MGX_SAGE_PROJECT_FIRST", "1") != "1"
                 or (bias is not None and K > getattr(sparse.backend_for(h), "COLUMN_SUM_MAX", 256))):
             return None
