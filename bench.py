@@ -241,6 +241,8 @@ def main():
                         "plain-model / controls / counter / CPU legs.  Default for a plain N = 1 run: 2,4,8")
     p.add_argument("--no-scale-model", action="store_true", help="skip the emulated-ranks scaling model")
     p.add_argument("--report", default=None, help="with --emulate-ranks: also write the human-readable table to this file")
+    p.add_argument("--tune-dense", action="store_true",
+                   help="experiment, with --emulate-ranks: PyTorch TunableOp chooses the dense GEMMs of the per-rank shapes in the warm-up")
     args = p.parse_args()
     if args.emulate_ranks is not None:
         args.no_plain = args.no_controls = args.no_pmc = args.no_cpu_baseline = True
@@ -571,6 +573,7 @@ def main():
             try:
                 models.append(scale_model.run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P,
                                               steps=min(args.steps, 5), warmup=min(args.warmup, 2), dropout=args.dropout,
+                                              tune_dense=args.tune_dense,
                                               progress=lambda msg: print("[scale model] " + msg, file=sys.stderr, flush=True)))
             except Exception as err:  # the model must not lose the bench line
                 models.append({"ranks": P, "error": "%s: %s" % (type(err).__name__, str(err)[:300])})

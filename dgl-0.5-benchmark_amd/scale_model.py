@@ -20,7 +20,7 @@ import torch
 LINK_RATES_GBPS = (32.0, 48.0, 64.0)  # per link and direction; see report(): MI355X xGMI is 7 links x ~153 GB/s bidirectional
 
 
-def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, warmup=2, dropout=None, progress=None):
+def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, warmup=2, dropout=None, progress=None, tune_dense=False):
     """Partition the graph P ways and run `warmup` + `steps` training epochs of every rank (the step of bench.py) inside an
     emulated world.  Returns a dict: partition statistics, per-rank typical-epoch stages (median over the steps), byte matrices, priced epochs."""
     import full_graph
@@ -65,8 +65,23 @@ def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, w
             g._comm.mark("dense")
             return loss.item()
 
+        if tune_dense and rank == 0:
+            # experiment (bench.py --tune-dense): PyTorch TunableOp picks the GEMMs of the per-rank shapes during the warm-up.  The
+            # environment variable wins over torch.cuda.tunable.tuning_enable(); results go to a scratch file, never to the staged
+            # copy of the committed selections.
+            import os
+            import tempfile
+            torch.cuda.tunable.enable(True)
+            torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), "mgx_tunableop_emulated_%d.csv" % os.getpid()))
+            torch.cuda.tunable.set_max_tuning_duration(10)
+            torch.cuda.tunable.set_max_tuning_iterations(5)
+            os.environ["PYTORCH_TUNABLEOP_TUNING"] = "1"
         for _ in range(warmup):
             step()
+        if tune_dense:
+            ctx.barrier()
+            import os
+            os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
         ctx.start_trace()  # one traced epoch thrown away: the first use of the timing events
         step()
         ctx.stop_trace()
