@@ -65,9 +65,27 @@ static unsigned long long* g_tile_stamps = nullptr;
 #define MGX_STAMP() __builtin_amdgcn_s_memtime()
 #endif
 
+// ---- per-slot FULL / FREE words instead of the per-chunk workgroup barrier (FLAGS = true; A/B: MGX_TILE_FLAGS=1) -------------------
+// flags[s] counts the loader waves that have published a chunk into ring slot s (a chunk is readable once NL * (its generation + 1)
+// have); flags[8 + s] counts the consumer waves that have released it (refillable once NC * generation have).  LDS atomics by lane 0,
+// volatile LDS polls with s_sleep; a poll gives up after 2^20 rounds so that a bug shows as a wrong answer, never as a hung GPU.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;  // LDS address space: ds_* instructions (lgkmcnt), never flat loads (vmcnt)
+__device__ __forceinline__ void flag_add(lds_u32* f) {
+  if ((threadIdx.x & (kWave - 1)) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void flag_wait(lds_u32* f, uint32_t target) {
+  volatile lds_u32* vf = f;
+  for (int spin = 0; spin < (1 << 20); ++spin) {
+    if (*vf >= target) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 // ---- loader waves ---------------------------------------------------------------------------------------------------------
-template <int W, int NL, int RING>
-__device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, int wave, int lane, int tile, int cbeg, int n, int col0) {
+template <int W, int NL, int RING, bool FLAGS>
+__device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, lds_u32* flags, int wave, int lane, int tile, int cbeg, int n,
+                                            int col0) {
+  constexpr int NC = W - NL;
   constexpr int PER = kDmaPerChunk / NL;  // DMA instructions per loader wave per chunk
   static_assert((RING - 2) * PER <= 48, "the counted vmcnt wait must stay below the 6-bit counter");
   const int g = lane >> 4, l = lane & 15;
@@ -112,7 +130,12 @@ __device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, int w
 #ifdef MGX_TILE_STAMPS
     const unsigned long long t1 = MGX_STAMP();
 #endif
-    __builtin_amdgcn_s_barrier();  // chunk c has landed; every consumer has finished chunk c - 1
+    if (FLAGS) {
+      flag_add(flags + c % RING);  // this wave's share of chunk c has landed: publish
+      if (c >= 1 && c + RING - 1 < n) flag_wait(flags + 8 + (c - 1) % RING, (uint32_t)(NC * ((c - 1) / RING + 1)));  // chunk c - 1 released
+    } else {
+      __builtin_amdgcn_s_barrier();  // chunk c has landed; every consumer has finished chunk c - 1
+    }
     asm volatile("" ::: "memory");
 #ifdef MGX_TILE_STAMPS
     const unsigned long long t2 = MGX_STAMP();
@@ -136,8 +159,9 @@ __device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, int w
 }
 
 // ---- consumer waves -------------------------------------------------------------------------------------------------------
-template <int W, int NL, int NACC, int RING>
-__device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int cw, int lane, int tile, int cbeg, int n, int col0) {
+template <int W, int NL, int NACC, int RING, bool FLAGS>
+__device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, lds_u32* flags, int cw, int lane, int tile, int cbeg, int n,
+                                              int col0) {
   constexpr int NC = W - NL;
   constexpr int R = NC * NACC * 4;
   const int g = lane >> 4, l = lane & 15;
@@ -190,7 +214,12 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int
 #ifdef MGX_TILE_STAMPS
       const unsigned long long tb0 = MGX_STAMP();
 #endif
-      __builtin_amdgcn_s_barrier();                         // chunk c is in its ring slot
+      if (FLAGS) {
+        if (c > 0) flag_add(flags + 8 + (c - 1) % RING);    // this wave is done with chunk c - 1: its slot may be refilled
+        flag_wait(flags + c % RING, (uint32_t)(NL * (c / RING + 1)));  // chunk c is in its ring slot
+      } else {
+        __builtin_amdgcn_s_barrier();                       // chunk c is in its ring slot
+      }
       asm volatile("" ::: "memory");
 #ifdef MGX_TILE_STAMPS
       const unsigned long long tb1 = MGX_STAMP();
@@ -364,10 +393,15 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int
   }
 }
 
-template <int W, int NL, int NACC, int RING>
+template <int W, int NL, int NACC, int RING, bool FLAGS = false>
 __global__ __launch_bounds__(W * kWave, 4) void spmm_tile_kernel(const TileArgs a) {
   // W = 16: one workgroup per CU (4 waves per SIMD); W = 8: two per CU -- either way 128 registers per lane
   __shared__ __attribute__((aligned(1024))) char ring[RING * kChunkBytes + W * kStreamRingBytes];
+  __shared__ uint32_t flags[16];
+  if (FLAGS) {
+    if (threadIdx.x < 16) flags[threadIdx.x] = 0;
+    __syncthreads();
+  }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & (kWave - 1);
   // block b serves XCD b % 8 (observed round-robin placement; speed only): consecutive tiles of the schedule -- which share
@@ -378,8 +412,8 @@ __global__ __launch_bounds__(W * kWave, 4) void spmm_tile_kernel(const TileArgs 
   const int cbeg = a.tile_chunk_ptr[tile];
   const int n = a.tile_chunk_ptr[tile + 1] - cbeg;
   const int col0 = blockIdx.y * kPassCols;
-  if (wave < NL) tile_loader<W, NL, RING>(a, ring, wave, lane, tile, cbeg, n, col0);
-  else tile_consumer<W, NL, NACC, RING>(a, ring, wave - NL, lane, tile, cbeg, n, col0);
+  if (wave < NL) tile_loader<W, NL, RING, FLAGS>(a, ring, (lds_u32*)flags, wave, lane, tile, cbeg, n, col0);
+  else tile_consumer<W, NL, NACC, RING, FLAGS>(a, ring, (lds_u32*)flags, wave - NL, lane, tile, cbeg, n, col0);
 }
 
 // ---- narrow rows ------------------------------------------------------------------------------------------------------------
@@ -697,7 +731,10 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
 
 #define MGX_TILE_LAUNCH(W_, NL_, NACC_, RING_)                                                                      \
   do {                                                                                                             \
-    hipLaunchKernelGGL((spmm_tile_kernel<W_, NL_, NACC_, RING_>), grid, dim3(W_ * kWave), 0, s, a);                \
+    if (MGX_ENV_FLAG("MGX_TILE_FLAGS") && (NACC_) == 6)                                                           \
+      hipLaunchKernelGGL((spmm_tile_kernel<W_, NL_, NACC_, RING_, true>), grid, dim3(W_ * kWave), 0, s, a);        \
+    else                                                                                                           \
+      hipLaunchKernelGGL((spmm_tile_kernel<W_, NL_, NACC_, RING_>), grid, dim3(W_ * kWave), 0, s, a);              \
     return true;                                                                                                   \
   } while (0)
 
