@@ -143,7 +143,8 @@ class CsrView(object):
             # MGX_TILE_DIRECT=split (A/B, measured slower: reddit D = 64 1.13 -> 1.42 ms, docs/LOG_r04.md §8): the tile's once-used
             # sources as a second, accumulating launch of the row kernel instead of the tile kernel's own direct part
             split = lg == 4 and os.environ.get("MGX_TILE_DIRECT", "kernel") == "split"
-            tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=lg, split_direct=split)
+            tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=lg, split_direct=split,
+                                          tail=float(os.environ.get("MGX_TILE_TAIL", "0")))  # A/B: tiles that shrink toward a stretch's end
             if _VALIDATE_TILE_PLANS:
                 tileplan.validate(tp, self)
             tp.direct_csr = None

@@ -142,6 +142,7 @@ def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None, groups=GROUPS, 
     return ssteps, base, total, stream
 
 
+XCDS = 8
 NUM_CUS = 256
 WG_SLOTS = 2 * NUM_CUS  # 8-wave workgroups, two per CU
 
@@ -157,7 +158,8 @@ def _longest_first(tile_edges, T, xcds=8):
     return torch.sort(key, stable=True)[1].to(torch.int32)
 
 
-def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, pair_rank=False, split_direct=False):
+def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, pair_rank=False, split_direct=False,
+                    tail=0.0):
     """csr: CsrView (int32, device or host); base: SpmmPlan over it (items in schedule order; None = natural rows).
     pair_rank (the plans of the fused GAT walks, gat_tile.inc): every entry also carries the RANK k of its edge among the parallel
     edges of its (row, source) pair, in edge-id order -- (destination, source, k) is then a key per edge that both CSRs of a graph
@@ -206,6 +208,24 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         it_tile = torch.cumsum(newt, 0) - 1
         it_first = torch.cummax(torch.where(newt.bool(), torch.arange(I, device=dev), torch.zeros(I, dtype=torch.int64, device=dev)), 0)[0]
         T = int(it_tile[-1]) + 1
+    elif tail > 0.0 and I >= 64 * R:
+        # tiles that SHRINK toward the end of every XCD's stretch (round 4, MGX_TILE_TAIL=f): a launch is only a few tiles per workgroup
+        # slot deep, so whatever a stretch's last tiles take is idle time on the other slots.  The last fraction f of a stretch's items
+        # goes into tiles of R / 2 items (first half of it) and R / 4 items (the rest); every stretch is padded to the same tile count.
+        idx = torch.arange(I, device=dev)
+        x = torch.div(idx * XCDS, I, rounding_mode="floor")
+        starts = torch.div(torch.arange(XCDS + 1, device=dev) * I + XCDS - 1, XCDS, rounding_mode="floor")  # first item of stretch x: ceil(x I / 8)
+        sx, nx = starts[:-1][x], (starts[1:] - starts[:-1])[x]
+        j = idx - sx
+        A = (nx.double() * (1.0 - tail)).long() // R * R            # whole tiles of R
+        B = A + ((nx - A).double() * 0.5).long() // (R // 2) * (R // 2)
+        tA, tB = A // R, (B - A) // (R // 2)
+        t_loc = torch.where(j < A, j // R, torch.where(j < B, tA + (j - A) // (R // 2), tA + tB + (j - B) // (R // 4)))
+        f_loc = torch.where(j < A, j // R * R, torch.where(j < B, A + (j - A) // (R // 2) * (R // 2), B + (j - B) // (R // 4) * (R // 4)))
+        tpx = int(t_loc.max()) + 1
+        it_tile = x * tpx + t_loc
+        it_first = sx + f_loc
+        T = XCDS * tpx
     else:
         it_tile = torch.arange(I, device=dev) // R
         it_first = it_tile * R
