@@ -424,6 +424,8 @@ def main():
         fence()
         if profile:
             sparse.PROFILE = []
+            if world > 1:
+                g._comm.trace = []  # exposed exchange time per rank (dist._TimedWork): what the scaling model predicts, measured
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
@@ -437,6 +439,19 @@ def main():
     progress("starting warm-up + timed steps")
     elapsed, loss, records = timed(make_step(model, opt, bucket), args.steps, args.warmup, True)
     progress("timed region done")
+    if world > 1:
+        tr = g._comm.trace or []  # the timed steps' exchanges (set in timed(), after the warm-up)
+        g._comm.trace = None
+        exposed = sum(a.elapsed_time(b) for a, b, _ in tr) / max(args.steps, 1)
+        ex = torch.zeros(world * 2, dtype=torch.float64, device=device)
+        ex[rank * 2], ex[rank * 2 + 1] = exposed, sum(nb for _, _, nb in tr) / max(args.steps, 1)
+        mdist.all_reduce(ex)
+        ex = ex.view(world, 2).cpu().tolist()
+        for r, rec in enumerate(part_stats.get("per_rank", [])):
+            rec["exposed_exchange_ms_per_epoch"] = round(ex[r][0], 4)
+            rec["bytes_received_per_epoch"] = int(ex[r][1])
+        part_stats["exposed_exchange_note"] = ("per rank and epoch: compute-stream time between two HIP events around every all_to_all wait() "
+                                               "in the timed region (0 over gloo staging, which exchanges synchronously)")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         mdist.all_reduce(t, op=dist.ReduceOp.MAX)

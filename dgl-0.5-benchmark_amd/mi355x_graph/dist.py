@@ -283,6 +283,7 @@ class _Comm(object):
     def __init__(self, group=None):
         self.group = group
         self.n_exchanges = 0
+        self.trace = None  # bench.py sets a list: (event before wait, event after wait, bytes received) per exchange of the timed region
 
     def mark(self, label):
         """Names the stretch of work that starts here -- recorded only by an emulated rank (emulate.EmuRank.mark)."""
@@ -328,12 +329,31 @@ class _Comm(object):
             self.all_to_all(out, inp, out_splits, in_splits)
             return _Done()
         self.n_exchanges += 1
-        return dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
+        work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
+        if self.trace is None or not out.is_cuda:
+            return work
+        return _TimedWork(work, self.trace, int(out.numel() * out.element_size()))
 
 
 class _Done(object):
     def wait(self):
         return True
+
+
+class _TimedWork(object):
+    """An RCCL work handle whose wait() is bracketed by two HIP events on the compute stream: what lies between them is the time the
+    compute stream stood still for the collective -- the EXPOSED part of the exchange, the number the scaling model predicts."""
+
+    def __init__(self, work, trace, nbytes):
+        self.work, self.trace, self.nbytes = work, trace, nbytes
+
+    def wait(self):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        ok = self.work.wait()
+        b.record()
+        self.trace.append((a, b, self.nbytes))
+        return ok
 
 
 class DistCopyU(torch.autograd.Function):

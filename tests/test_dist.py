@@ -283,9 +283,14 @@ def test_rccl_api_path_single_rank():
         g = mdist.DistGraph(block, plan)
         model = build_model().to(dev)
         mdist.broadcast_parameters(model)
+        g._comm.trace = []  # bench.py's measurement of the exposed exchange: events around every wait() on the RCCL work handle
         out = model(g, feats)
         loss = F.nll_loss(out[train], labels[train])
         loss.backward()
+        torch.cuda.synchronize()
+        assert len(g._comm.trace) == g._comm.n_exchanges > 0
+        assert all(a.elapsed_time(b) >= 0.0 and nb == 0 for a, b, nb in g._comm.trace)  # one rank: nothing to receive
+        g._comm.trace = None
         mdist.allreduce_gradients(model)
         ref_out, ref_loss, ref_grads, ref_gen, _ = single_process_reference("cuda:0")
         assert torch.allclose(out.detach().cpu(), ref_out, rtol=1e-4, atol=1e-6)
