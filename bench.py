@@ -365,6 +365,8 @@ def main():
         train_idx = torch.nonzero(train_mask[own_cpu]).flatten().to(device)
         total_train = float(train_mask.sum())
         t2 = time.perf_counter()
+        if cfg["batch_norm"]:  # statistics over the union of every rank's rows (main_dgl_arxiv_sage.py:70-77 on a partition)
+            model = mdist.convert_batchnorm(model)
         mdist.broadcast_parameters(model)
         bucket = mdist.GradBucket(model)
         torch.cuda.synchronize()

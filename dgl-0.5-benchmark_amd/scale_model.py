@@ -44,6 +44,8 @@ def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, w
         torch.manual_seed(1234)
         model = full_graph.GraphSAGE(spec["feat"], cfg["hidden"], spec["classes"], cfg["num_layers"], p_drop,
                                      cfg["batch_norm"], cfg["neigh_bias"]).to(device)
+        if cfg["batch_norm"]:
+            model = mdist.convert_batchnorm(model)
         model.rows_are_distinct = True
         own_c = own.cpu()
         x, y = feats[own_c].to(device), labels[own_c].to(device)
