@@ -54,6 +54,7 @@ struct SpmmFastArgs {
   int mean;
   int accum;  // out += result (MGX_SPMM_ACCUMULATE)
   int ragged; // D % 4 != 0 handled with 16-byte gathers (RAGGED kernel)
+  int short_rows;  // MGX_SPMM_SHORT_ROWS: the caller vouches for short, even work items -> one item per lane group (spmm_rowgroup32_kernel)
   int lds;    // row stride of `src` in floats (>= D; == D unless mgx_spmm_copy_u_strided)
   int ldo;    // row stride of `out` in floats
 };
@@ -558,6 +559,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup32_kernel(const SpmmFastA
   typedef typename VecT<VEC>::type V;
   constexpr int NB = kWave / G;
   constexpr int U = 4;
+  constexpr int kLong = 32;  // edges a lane group walks alone (8 steps of 4 gathers); longer items: the whole wave, see below
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int sub = lane / G;
@@ -618,9 +620,13 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup32_kernel(const SpmmFastA
       ngoff = load_ids(nbeg, nend);
     }
     V acc = (V)(0.f);
+    // items longer than kLong edges are NOT walked by their lane group alone (one group gathering 256 edges, 4 in flight, is 64
+    // dependent round trips -- the tail of the whole launch on a skewed graph): the wave takes them together below
+    const bool deferred = ok && (end - beg) > kLong;
+    const int32_t gend = deferred ? beg : end;
     int32_t cbase = beg;
     for (;;) {  // chunks of G edges; wave-uniform trip count (the longest item of the batch), per-group predicates inside
-      const int cnt = (end - cbase) < G ? (end - cbase) : G;
+      const int cnt = (gend - cbase) < G ? (gend - cbase) : G;
       for (int k = 0; k < G; k += U) {
         if (__builtin_amdgcn_ballot_w64(k < cnt) == 0) break;
         V val[U];
@@ -635,8 +641,45 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup32_kernel(const SpmmFastA
         for (int u = 0; u < U; ++u) acc += val[u];
       }
       cbase += G;
-      if (__builtin_amdgcn_ballot_w64(cbase < end) == 0) break;
-      goff = load_ids(cbase, end);
+      if (__builtin_amdgcn_ballot_w64(cbase < gend) == 0) break;
+      goff = load_ids(cbase, gend);
+    }
+    // ---- long items of this batch, one after the other, by the WHOLE wave: 64 ids per coalesced load, lane group `sub` gathers edges
+    // k + u * NB + sub, the groups' partial sums meet in an xor-shuffle tree, the owner group keeps the result
+    uint64_t dmask = __builtin_amdgcn_ballot_w64(deferred);
+    while (dmask) {
+      const int src_lane = __builtin_amdgcn_readfirstlane(__builtin_ctzll(dmask));
+      const int gsel = src_lane / G;
+      const int32_t cb = __builtin_amdgcn_readlane(beg, src_lane), ce = __builtin_amdgcn_readlane(end, src_lane);
+      V part = (V)(0.f);
+      for (int32_t base = cb; base < ce; base += kWave) {
+        const int32_t q = base + lane;
+        uint32_t go = 0;
+        if (q < ce) {
+          int32_t gid;
+          if (MODE == MODE_COPY_RHS) gid = a.eids ? __builtin_nontemporal_load(&a.eids[q]) : q;
+          else gid = __builtin_nontemporal_load(&a.indices[q]);
+          go = (uint32_t)gid * rowbytes;
+        }
+        const int ccnt = (ce - base) < kWave ? (ce - base) : kWave;
+        for (int k = 0; k < ccnt; k += NB * U) {
+          V val[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int e = k + u * NB + sub;
+            const bool live = e < ccnt;
+            const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute((live ? e : 0) * 4, (int)go) + f4;
+            val[u] = (V)(0.f);
+            if (live) val[u] = *reinterpret_cast<const V*>(srcb + off);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) part += val[u];
+        }
+      }
+#pragma unroll
+      for (int off = G; off < kWave; off <<= 1) part += vec_shfl_xor<VEC>(part, off);
+      if (sub == gsel) acc = part;  // (its own accumulator is still zero: the item was deferred)
+      dmask &= ~((G >= 64 ? ~0ull : ((1ull << G) - 1ull)) << (gsel * G));
     }
     if (ok && factive) {
       if (row >= 0) {
@@ -660,20 +703,20 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup32_kernel(const SpmmFastA
 
 template <int VEC, int G, int MODE>
 static bool launch_rowgroup32(SpmmFastArgs<int32_t> a, int64_t nnz, hipStream_t s) {
-  // MGX_ROWGROUP: 0 = never, 1 = whenever eligible (A/B runs: experiments/exp_rowgroup.py); default: work items shorter on
-  // average than 3 edges per lane group of the wave, at most 16 -- measured on MI355X (profiles/r04_rowgroup.txt, uniform random
-  // sources): 3.4 edges per row D = 64 0.39 -> 0.19 ms, D = 16 0.27 -> 0.08 ms; 6.9 per row (arxiv shape) D = 64 69 -> 55 us,
-  // D = 16 56 -> 26 us, but D = 100 / 128 (two groups per wave) 100 -> 102 us; 11 per row: equal at D = 64 (both at the fabric's
-  // random-gather rate), better below; from 20 per row on the row-per-wave kernel wins at every width.
+  // Taken when the CALLER vouches for short, even work items (MGX_SPMM_SHORT_ROWS in `flags`).  An average-only rule decided here made
+  // the arxiv-shaped graph (6.9 in-edges on average, power-law tail, a 13 k-edge hub = 52 consecutive 256-edge chunks) TWICE AS SLOW
+  // at D = 4 .. 32 (81 -> 180 us) while uniform short rows gain 2 - 3.5x (profiles/r04_rowgroup.txt, r04_rowgroup_skew.txt); the host
+  // layer decides per CSR and lane-group count from the item lengths (mi355x_graph/sparse.py: CsrView.short_rows).
+  // MGX_ROWGROUP=0 never, =1 whenever eligible (A/B runs).
   static const int env = getenv("MGX_ROWGROUP") ? atoi(getenv("MGX_ROWGROUP")) : -1;
   constexpr int NB = kWave / G;
-  const double max_avg = NB >= 8 ? 16.0 : 3.0 * NB;
   if constexpr (NB < 2 || VEC != 4 || MODE == MODE_MUL_EDGE) {
     return false;
   } else {
     if (env == 0 || a.ragged || a.src_scale || a.src_bits || a.D % 4 != 0) return false;
     if (a.src_rows * (int64_t)a.lds * 4 >= (int64_t(1) << 32) || MGX_ENV_FLAG("MGX_SPMM_V1")) return false;
-    if (env != 1 && (a.n_items == 0 || (double)nnz / (double)a.n_items >= max_avg)) return false;
+    if (env != 1 && !a.short_rows) return false;
+    (void)nnz;
     note_spmm_kernel("rowgroup32");
     a.rpb = 2 * kWavesPerBlock * NB;  // two batches per wave: the second's ids travel under the first's gathers
     const dim3 grid((unsigned)xcd_ranges(a.plan, a.n_items, a.rpb, a.xcd), (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
@@ -917,12 +960,13 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
 }
 
 template <typename Idx>
-static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* partial_ws, int accumulate, int32_t op, int32_t reduce, const float* U, const float* E,
+static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* partial_ws, int flag_bits, int32_t op, int32_t reduce, const float* U, const float* E,
                          int64_t u_len, int64_t e_len, int64_t out_len, const int64_t* u_off,
                          const int64_t* e_off, const float* src_scale, const float* dst_scale, float* out,
                          void* arg_u, void* arg_e, hipStream_t s, const uint32_t* src_bits = nullptr, int64_t u_stride = 0,
                          int64_t out_stride = 0) {
   const int64_t n_rows = csr->num_rows;
+  const int accumulate = (flag_bits & MGX_SPMM_ACCUMULATE) ? 1 : 0;
   if (n_rows == 0 || out_len == 0) return MGX_OK;
   const int64_t nblocks = round_up((n_rows + kRowsPerBlock - 1) / kRowsPerBlock, kXcds);
   MGX_CHECK_ARG(nblocks < (int64_t(1) << 31), "mgx_spmm_csr: too many rows (%lld)", (long long)n_rows);
@@ -945,6 +989,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     a.n_rows = n_rows; a.nblocks = nblocks; a.D = (int)out_len; a.H = 1; a.F = (int)out_len;
     a.mean = reduce == MGX_REDUCE_MEAN;
     a.accum = accumulate;
+    a.short_rows = (flag_bits & MGX_SPMM_SHORT_ROWS) ? 1 : 0;
     a.ragged = 0;
     a.lds = u_stride ? (int)u_stride : (int)out_len;
     a.ldo = out_stride ? (int)out_stride : (int)out_len;
@@ -1098,7 +1143,7 @@ extern "C" int32_t mgx_spmm_copy_u_masked(const mgx_csr* csr, const mgx_spmm_pla
   MGX_CHECK_ARG(csr->num_rows == 0 || csr->indptr, "mgx_spmm_copy_u_masked: indptr is NULL");
   MGX_CHECK_ARG(csr->nnz == 0 || (csr->indices && ufeat), "mgx_spmm_copy_u_masked: indices / ufeat is NULL");
   MGX_CHECK_ARG(out != nullptr || csr->num_rows == 0 || D == 0, "mgx_spmm_copy_u_masked: out is NULL");
-  return spmm_impl<int32_t>(csr, plan, partial_ws, (flags & MGX_SPMM_ACCUMULATE) ? 1 : 0, MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0, D,
+  return spmm_impl<int32_t>(csr, plan, partial_ws, flags & MGX_SPMM_ACCUMULATE, MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0, D,
                             nullptr, nullptr, nullptr, dst_scale, out, nullptr, nullptr, (hipStream_t)stream, src_bits);
 }
 
@@ -1116,7 +1161,7 @@ extern "C" int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_pl
   MGX_CHECK_ARG((ufeat != nullptr || csr->num_cols == 0) && (out != nullptr || csr->num_rows == 0 || D == 0),
                 "mgx_spmm_copy_u_strided: ufeat / out is NULL");
   if (csr->idx_bits != 32) MGX_UNSUPPORTED("mgx_spmm_copy_u_strided: int32 graphs only");
-  return spmm_impl<int32_t>(csr, plan, partial_ws, (flags & MGX_SPMM_ACCUMULATE) ? 1 : 0, MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0,
+  return spmm_impl<int32_t>(csr, plan, partial_ws, flags & (MGX_SPMM_ACCUMULATE | MGX_SPMM_SHORT_ROWS), MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0,
                             D, nullptr, nullptr, nullptr, dst_scale, out, nullptr, nullptr, (hipStream_t)stream, nullptr, u_stride,
                             out_stride);
 }
@@ -1147,8 +1192,8 @@ extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, i
   MGX_CHECK_ARG(!accumulate || !cmp, "mgx_spmm_csr: MGX_SPMM_ACCUMULATE only with SUM/MEAN");
   hipStream_t s = (hipStream_t)stream;
   if (csr->idx_bits == 32)
-    return spmm_impl<int32_t>(csr, plan, partial_ws, accumulate, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
+    return spmm_impl<int32_t>(csr, plan, partial_ws, flags & (MGX_SPMM_ACCUMULATE | MGX_SPMM_SHORT_ROWS), op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
                               dst_scale, out, arg_u, arg_e, s);
-  return spmm_impl<int64_t>(csr, plan, partial_ws, accumulate, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
+  return spmm_impl<int64_t>(csr, plan, partial_ws, flags & MGX_SPMM_ACCUMULATE, op, reduce, ufeat, efeat, u_len, e_len, out_len, u_off, e_off, src_scale,
                             dst_scale, out, arg_u, arg_e, s);
 }

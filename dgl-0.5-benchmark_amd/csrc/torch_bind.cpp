@@ -4,7 +4,8 @@
 // The seam DGL v0.6 crosses at _CAPI_DGLKernelSpMM / _CAPI_DGLKernelSDDMM (UPSTREAM python/dgl/sparse.py::_gspmm/_gsddmm, reached
 // from kernel/dgl-new.py:20,39) as torch ops over plain tensors:
 //
-//   mi355x_graph::gspmm(indptr, indices, eids?, num_cols, op, reduce, ufeat?, efeat?, plan=0)  -> (out, arg_u, arg_e)
+//   mi355x_graph::gspmm(indptr, indices, eids?, num_cols, op, reduce, ufeat?, efeat?, plan=0, flags=0)  -> (out, arg_u, arg_e)
+//       (flags: MGX_SPMM_SHORT_ROWS = 2, the caller's hint that the work items are short and even)
 //   mi355x_graph::gsddmm(indptr, indices, eids?, num_cols, op, lhs?, rhs?, lhs_target, rhs_target, plan=0) -> out
 //   mi355x_graph::gsddmm_coo(src, dst, num_src, num_dst, op, lhs?, rhs?, lhs_target, rhs_target)            -> out
 //   mi355x_graph::edge_softmax_fwd / _bwd(indptr, indices, eids?, num_cols, ..., plan=0)
@@ -137,7 +138,7 @@ const mgx_spmm_plan* plan_of(int64_t handle) { return reinterpret_cast<const mgx
 // ----------------------------------------------------------------------------- gspmm
 std::tuple<Tensor, Tensor, Tensor> gspmm(const Tensor& indptr, const Tensor& indices, const optional<Tensor>& eids, int64_t num_cols,
                                          std::string op, std::string reduce, const optional<Tensor>& ufeat,
-                                         const optional<Tensor>& efeat, int64_t plan_handle) {
+                                         const optional<Tensor>& efeat, int64_t plan_handle, int64_t flags) {
   const char* what = "mi355x_graph::gspmm";
   mgx_csr csr = make_csr(indptr, indices, eids, num_cols, what);
   int opc = op_code(op, what);
@@ -170,7 +171,7 @@ std::tuple<Tensor, Tensor, Tensor> gspmm(const Tensor& indptr, const Tensor& ind
   check_status(mgx_spmm_csr(&csr, plan, opc, red, U.defined() ? U.data_ptr<float>() : nullptr, E.defined() ? E.data_ptr<float>() : nullptr,
                             u_len, e_len, out_len, nullptr, nullptr, nullptr, nullptr, out.data_ptr<float>(),
                             arg_u.numel() ? arg_u.data_ptr() : nullptr, arg_e.numel() ? arg_e.data_ptr() : nullptr,
-                            partial.defined() ? partial.data_ptr<float>() : nullptr, 0, stream_of(indptr)),
+                            partial.defined() ? partial.data_ptr<float>() : nullptr, (int32_t)(flags & MGX_SPMM_SHORT_ROWS), stream_of(indptr)),
                what);
   return std::make_tuple(out, arg_u, arg_e);
 }
@@ -364,7 +365,7 @@ Tensor in_degrees(const Tensor& indptr) {
 
 TORCH_LIBRARY(mi355x_graph, m) {
   m.def("gspmm(Tensor indptr, Tensor indices, Tensor? eids, int num_cols, str op, str reduce, Tensor? ufeat, Tensor? efeat, "
-        "int plan=0) -> (Tensor, Tensor, Tensor)");
+        "int plan=0, int flags=0) -> (Tensor, Tensor, Tensor)");
   m.def("gsddmm(Tensor indptr, Tensor indices, Tensor? eids, int num_cols, str op, Tensor? lhs, Tensor? rhs, str lhs_target, "
         "str rhs_target, int plan=0) -> Tensor");
   m.def("gsddmm_coo(Tensor src, Tensor dst, int num_src, int num_dst, str op, Tensor? lhs, Tensor? rhs, str lhs_target, "

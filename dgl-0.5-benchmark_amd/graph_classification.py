@@ -228,6 +228,7 @@ class GraphedBatchTrainer(object):
         g._batch_num_edges = None
         for view in (g._index.csc(), g._index.csr()):  # built on the device inside the step; small graphs run without a schedule
             view._plan = None                            # (building one reads a maximum degree back: a host sync)
+            view.short_hint = True                       # molecules + round-robin ghost edges: short rows, one item per lane group
         for bn in self.bns:
             bn.set_valid(buf["mask"], buf["count"])
         out = self.model(g, buf["atom"], buf["bond"])

@@ -44,7 +44,7 @@ class CsrView(object):
     """An immutable CSR over torch tensors (in-CSR: rows = destination nodes)."""
 
     __slots__ = ("__weakref__", "num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan", "_sm_plan",
-                 "_row_order", "dst_is_src_prefix", "_tile_plan")
+                 "_row_order", "dst_is_src_prefix", "_tile_plan", "_short", "short_hint")
 
     def __init__(self, num_rows, num_cols, indptr, indices, eids):
         self.num_rows, self.num_cols = int(num_rows), int(num_cols)
@@ -55,6 +55,8 @@ class CsrView(object):
         self._plan = False  # False = not built yet; None = run without a plan
         self._sm_plan = False
         self._tile_plan = False
+        self._short = {}        # lane groups per wave -> bool: see short_rows()
+        self.short_hint = None  # True / False: the owner's word on short_rows() where the lengths cannot be read back (graph capture)
         self._row_order = (None, None)  # (row order, kind) computed with the first plan
         self.dst_is_src_prefix = False  # block graphs whose destination nodes are the first source nodes
 
@@ -90,6 +92,45 @@ class CsrView(object):
         if self._inv_deg is None:
             self._inv_deg = backend_for(self.indptr).inv_degrees(self)
         return self._inv_deg
+
+    def short_rows(self, width):
+        """True when the summing g-SpMM of `width` columns should give every work item a LANE GROUP of its own (MGX_SPMM_SHORT_ROWS ->
+        spmm_rowgroup32_kernel) instead of a whole wave.  A wave walks B = 64 / G consecutive items side by side, lasts as long as the
+        longest of them, and takes the items beyond 32 edges one after the other with all its lanes.  Three conditions, fitted to the
+        shapes of docs/LOG_r04.md section 2 (uniform halo CSRs: 2-3.5x faster; arxiv at 1.2 M edges: 1.4x SLOWER, at 4.6 M: 1.3x faster):
+          short   fewer than 3 edges per lane group of the wave on average, at most 16;
+          even    sum over batches of max(length clipped at 32) * B <= MGX_ROWGROUP_IMBALANCE (6) x the clipped edge count;
+          no tail the long items of any one batch (consecutive chunks of one hub land together) hold <= max(512, edges / 2048)
+                  edges: one wave's serial stretch against the share of each of the chip's 2048 resident waves.
+        Decided once per CSR and lane-group count (one host sync); a structure rebuilt on the device inside a captured step cannot be
+        read back and says so itself through `short_hint` (graph_classification.GraphedBatchTrainer: molecules, degree <= 6)."""
+        lanes, G = (int(width) + 3) // 4, 1
+        while G < lanes and G < 64:
+            G *= 2
+        nb = 64 // G
+        if nb < 2 or self.idx_bits != 32 or not self.indptr.is_cuda or self.nnz == 0 or width % 4:
+            return False
+        if self.short_hint is not None:
+            return bool(self.short_hint)
+        ok = self._short.get(nb)
+        if ok is None:
+            if torch.cuda.is_current_stream_capturing():
+                return False  # the lengths cannot be read back inside a capture: the wave-per-item kernel, nothing cached
+            plan = self.plan()
+            lens = (plan.item_end - plan.item_beg) if plan is not None else (self.indptr[1:] - self.indptr[:-1])
+            n_items = int(lens.shape[0])
+            ok = False
+            if n_items and self.nnz / n_items < (16.0 if nb >= 8 else 3.0 * nb):
+                pad = (-n_items) % nb
+                if pad:
+                    lens = torch.cat([lens, lens.new_zeros(pad)])
+                lens = lens.view(-1, nb)
+                clipped = lens.clamp(max=32)
+                even = float(clipped.max(dim=1)[0].sum()) * nb <= float(os.environ.get("MGX_ROWGROUP_IMBALANCE", "6.0")) * float(clipped.sum())
+                tail = float((lens * (lens > 32)).sum(dim=1).max())
+                ok = even and tail <= max(512.0, self.nnz / 2048.0)
+            self._short[nb] = ok
+        return ok
 
     def plan(self):
         """Execution schedule for the summing g-SpMM (schedule.py); built on first use, device only."""
@@ -345,6 +386,9 @@ class HipBackend(object):
         partial = None
         if plan is not None and plan.num_slots:
             partial = torch.empty((plan.num_slots, out_len), dtype=torch.float32, device=dev)
+        # MGX_SPMM_SHORT_ROWS: full-width copy_u / copy_e sums over short, even work items take the lane-group-per-item kernel
+        short = (reduce in ("sum", "mean") and src_scale is None and u_off is None and e_off is None
+                 and ((op == "copy_lhs" and u_len == out_len) or (op == "copy_rhs" and e_len == out_len)) and csr.short_rows(out_len))
         with torch.cuda.device(dev):
             rec = None
             if PROFILE is not None:  # bench.py: HIP events on the launch stream around this launch
@@ -356,7 +400,7 @@ class HipBackend(object):
                 ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()),
                 OP[op], REDUCE[reduce], _ptr(U), _ptr(E), u_len, e_len, out_len,
                 _ptr(u_off), _ptr(e_off), _ptr(src_scale), _ptr(dst_scale), _ptr(out), _ptr(arg_u), _ptr(arg_e),
-                _ptr(partial), 1 if accumulate_into is not None else 0, _stream(dev)))
+                _ptr(partial), (1 if accumulate_into is not None else 0) | (2 if short else 0), _stream(dev)))
             if rec is not None:
                 rec["end"].record(torch.cuda.current_stream(dev))
                 PROFILE.append(rec)
@@ -420,8 +464,8 @@ class HipBackend(object):
                 rec["start"].record(torch.cuda.current_stream(dev))
             _lib.check(_lib.lib().mgx_spmm_copy_u_strided(
                 ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,
-                int(U2d.stride(0)), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial), 1 if accumulate else 0,
-                _stream(dev)))
+                int(U2d.stride(0)), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial),
+                (1 if accumulate else 0) | (2 if csr.short_rows(D) else 0), _stream(dev)))
             if rec is not None:
                 rec["end"].record(torch.cuda.current_stream(dev))
                 PROFILE.append(rec)

@@ -121,7 +121,7 @@ def _feat_shape(U, E):
 
 # ----------------------------------------------------------------------------- gspmm
 def _gspmm_py(indptr: Tensor, indices: Tensor, eids: Optional[Tensor], num_cols: int, op: str, reduce: str,
-              ufeat: Optional[Tensor], efeat: Optional[Tensor], plan: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
+              ufeat: Optional[Tensor], efeat: Optional[Tensor], plan: int = 0, flags: int = 0) -> Tuple[Tensor, Tensor, Tensor]:
     csr = _view(indptr, indices, eids, num_cols)
     want_arg = reduce in ("max", "min")
     out, arg_u, arg_e = sparse.gspmm_raw(csr, op, reduce, ufeat, efeat, want_arg=want_arg)
@@ -133,7 +133,7 @@ gspmm = _op("gspmm", _gspmm_py)
 
 
 @gspmm.register_fake
-def _(indptr, indices, eids, num_cols, op, reduce, ufeat, efeat, plan=0):
+def _(indptr, indices, eids, num_cols, op, reduce, ufeat, efeat, plan=0, flags=0):
     U = None if op == "copy_rhs" else ufeat
     E = None if op == "copy_lhs" else efeat
     ref = U if U is not None else E
@@ -329,8 +329,13 @@ def raw_gspmm(csr, op, reduce, X, Y, want_arg=False):
             return sparse.gspmm_raw(csr, op, reduce, X, Y, want_arg=want_arg)
     if not NATIVE:
         register_view(csr)
+    flags = 0
+    if (op == "copy_lhs" or op == "copy_rhs") and (reduce == "sum" or reduce == "mean"):
+        ref = X if op == "copy_lhs" else Y
+        if csr.short_rows(ref.numel() // max(int(ref.shape[0]), 1)):
+            flags = 2  # MGX_SPMM_SHORT_ROWS: one work item per lane group (CsrView.short_rows)
     try:
-        out, au, ae = torch.ops.mi355x_graph.gspmm(csr.indptr, csr.indices, csr.eids, csr.num_cols, op, reduce, X, Y, plan_handle(csr))
+        out, au, ae = torch.ops.mi355x_graph.gspmm(csr.indptr, csr.indices, csr.eids, csr.num_cols, op, reduce, X, Y, plan_handle(csr), flags)
     except DGLError:
         raise
     except RuntimeError as err:  # TORCH_CHECK in csrc/torch_bind.cpp: the operator surface raises DGLError (SURVEY 8b "Errors")

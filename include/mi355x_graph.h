@@ -56,8 +56,17 @@ typedef enum {
 /* reducers selectable with kernel/dgl-new.py:51 --spmm-reduce */
 typedef enum { MGX_REDUCE_SUM = 0, MGX_REDUCE_MAX = 1, MGX_REDUCE_MIN = 2, MGX_REDUCE_MEAN = 3 } mgx_reduce;
 
-/* flags of mgx_spmm_csr */
-enum { MGX_SPMM_ACCUMULATE = 1 };
+/* flags of mgx_spmm_csr / mgx_spmm_copy_u_strided */
+enum {
+  MGX_SPMM_ACCUMULATE = 1, /* out += result (SUM / MEAN only) */
+  MGX_SPMM_SHORT_ROWS = 2  /* the caller vouches that the work items (plan items, or rows without a plan) are SHORT AND EVEN: for every
+                              batch of B = 64 / G consecutive items (G = lanes per feature row = next power of two >= D / 4) the longest is
+                              not much above the batch mean.  copy_lhs / copy_rhs with SUM | MEAN then take the kernel that gives every
+                              item a lane group of its own (2 - 3.5x on rows of ~3 edges); without the flag, or on skewed items, a wave per
+                              item.  Items above 32 edges are taken by the whole wave inside that kernel, one after the other: keep runs of
+                              long items (consecutive chunks of one hub row) out of a batch, or do not set the flag.  A hint: results
+                              are the same either way (other fp32 summation order). */
+};
 
 /* SDDMM operand targets (lhs_target / rhs_target of dgl.ops.gsddmm) */
 typedef enum { MGX_TARGET_U = 0, MGX_TARGET_E = 1, MGX_TARGET_V = 2 } mgx_target;
