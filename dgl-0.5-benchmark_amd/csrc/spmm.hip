@@ -959,6 +959,8 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
   else launch_fast_v<Idx, 1, MODE>(a, nnz, s);
 }
 
+constexpr int kSpmmPartialPlan = 1 << 30;  // internal flag bit: the plan is one part of a two-part plan and need not cover every row
+
 template <typename Idx>
 static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* partial_ws, int flag_bits, int32_t op, int32_t reduce, const float* U, const float* E,
                          int64_t u_len, int64_t e_len, int64_t out_len, const int64_t* u_off,
@@ -968,10 +970,29 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
   const int64_t n_rows = csr->num_rows;
   const int accumulate = (flag_bits & MGX_SPMM_ACCUMULATE) ? 1 : 0;
   if (n_rows == 0 || out_len == 0) return MGX_OK;
+  if (plan && plan->rest) {
+    // A plan in two parts (mgx_spmm_plan::rest): the SHORT direct items here, on the lane-group kernel; everything else -- items above
+    // 32 edges and the chunks of split rows with their hub tables -- in `rest`, on the wave-per-item kernel.  Rows are independent
+    // and every row belongs to exactly one part, so the two calls are the whole operation (accumulate, mean and dst_scale included).
+    MGX_CHECK_ARG((flag_bits & MGX_SPMM_SHORT_ROWS) && (reduce == MGX_REDUCE_SUM || reduce == MGX_REDUCE_MEAN) &&
+                      (op == MGX_OP_COPY_LHS || op == MGX_OP_COPY_RHS) && !u_off && !e_off && !plan->rest->rest && plan->num_slots == 0,
+                  "mgx_spmm_csr: a plan with a `rest` part is for MGX_SPMM_SHORT_ROWS copy_u / copy_e sums (and holds no split rows itself)");
+    mgx_spmm_plan head = *plan;
+    head.rest = nullptr;
+    int32_t st = spmm_impl<Idx>(csr, &head, partial_ws, flag_bits | kSpmmPartialPlan, op, reduce, U, E, u_len, e_len, out_len, u_off, e_off,
+                                src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride);
+    if (st != MGX_OK) return st;
+    const char* head_kernel = mgx_last_spmm_kernel();
+    st = spmm_impl<Idx>(csr, plan->rest, partial_ws, (flag_bits & ~MGX_SPMM_SHORT_ROWS) | kSpmmPartialPlan, op, reduce, U, E, u_len, e_len,
+                        out_len, u_off, e_off, src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride);
+    note_spmm_kernel(head_kernel);  // the family that walked the short items (the bulk of such a plan)
+    return st;
+  }
   const int64_t nblocks = round_up((n_rows + kRowsPerBlock - 1) / kRowsPerBlock, kXcds);
   MGX_CHECK_ARG(nblocks < (int64_t(1) << 31), "mgx_spmm_csr: too many rows (%lld)", (long long)n_rows);
   if (plan) {
-    MGX_CHECK_ARG(plan->num_items >= n_rows && plan->item_row && plan->item_beg && plan->item_end,
+    if ((flag_bits & kSpmmPartialPlan) && plan->num_items == 0) return MGX_OK;
+    MGX_CHECK_ARG((plan->num_items >= n_rows || (flag_bits & kSpmmPartialPlan)) && plan->item_row && plan->item_beg && plan->item_end,
                   "mgx_spmm_csr: malformed plan");
     MGX_CHECK_ARG(plan->num_slots == 0 || (partial_ws && plan->hub_row && plan->hub_slot_ptr),
                   "mgx_spmm_csr: plan has split rows but no partial workspace / hub tables");

@@ -167,7 +167,8 @@ std::tuple<Tensor, Tensor, Tensor> gspmm(const Tensor& indptr, const Tensor& ind
   Tensor arg_e = at::empty((want_arg && opc != MGX_OP_COPY_LHS) ? at::IntArrayRef(shape) : at::IntArrayRef({0}), indptr.options());
   const mgx_spmm_plan* plan = want_arg ? nullptr : plan_of(plan_handle);
   Tensor partial;
-  if (plan && plan->num_slots > 0) partial = at::empty({plan->num_slots, out_len}, ref.options());
+  const int64_t slots = plan ? plan->num_slots + (plan->rest ? plan->rest->num_slots : 0) : 0;  // a two-part plan keeps its split rows in `rest`
+  if (slots > 0) partial = at::empty({slots, out_len}, ref.options());
   check_status(mgx_spmm_csr(&csr, plan, opc, red, U.defined() ? U.data_ptr<float>() : nullptr, E.defined() ? E.data_ptr<float>() : nullptr,
                             u_len, e_len, out_len, nullptr, nullptr, nullptr, nullptr, out.data_ptr<float>(),
                             arg_u.numel() ? arg_u.data_ptr() : nullptr, arg_e.numel() ? arg_e.data_ptr() : nullptr,

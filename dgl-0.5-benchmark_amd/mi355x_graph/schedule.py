@@ -35,6 +35,7 @@ class MgxSpmmPlan(ctypes.Structure):
         ("item_node", ctypes.c_void_p),
         ("xcd_item_start", ctypes.c_int64 * 9),
         ("xcd_item_start_dev", ctypes.c_void_p),
+        ("rest", ctypes.c_void_p),
     ]
 
 
@@ -46,6 +47,7 @@ class SpmmPlan(object):
         self.slot_item = slot_item
         self.item_node = item_node
         self.order_kind = order_kind
+        self.rest = None  # second part of a two-part plan (split_short_items): long items + the hub tables
         self._c = None
         self.xcd_item_start = self._balance_xcds()
         self._xcd_dev = (torch.tensor(self.xcd_item_start, dtype=torch.int64, device=item_row.device)
@@ -74,6 +76,11 @@ class SpmmPlan(object):
     def num_hubs(self):
         return int(self.hub_row.shape[0])
 
+    @property
+    def total_slots(self):
+        """Rows of the partial workspace a g-SpMM over this plan needs (its own slots + those of its `rest` part)."""
+        return self.num_slots + (self.rest.total_slots if self.rest is not None else 0)
+
     def c_struct(self):
         if self._c is None:
             self._c = MgxSpmmPlan(self.num_items, self.item_row.data_ptr(), self.item_beg.data_ptr(),
@@ -83,8 +90,43 @@ class SpmmPlan(object):
                                   self.slot_item.data_ptr() if self.num_slots else None,
                                   None if self.item_node is None else self.item_node.data_ptr(),
                                   (ctypes.c_int64 * 9)(*self.xcd_item_start),
-                                  None if self._xcd_dev is None else self._xcd_dev.data_ptr())
+                                  None if self._xcd_dev is None else self._xcd_dev.data_ptr(),
+                                  None if self.rest is None else ctypes.addressof(self.rest.c_struct()))
         return self._c
+
+
+SHORT_ITEM_EDGES = 32  # the longest item a lane group of spmm_rowgroup32_kernel walks alone
+
+
+def split_short_items(csr, base):
+    """The schedule of `csr` (`base`, or its natural rows when it has no plan) as a TWO-PART plan (mgx_spmm_plan::rest): the direct items
+    of at most 32 edges, in schedule order, for the lane-group kernel; every other item -- longer rows, the 256-edge chunks of split
+    rows with the hub tables -- in `rest` for the wave-per-item kernel.  Returns (plan, short_lengths); plan is `base` itself (may be
+    None) when nothing is long.  One host read of the long-item count."""
+    dev = csr.indptr.device
+    if base is not None:
+        row, beg, end, node = base.item_row, base.item_beg, base.item_end, base.item_node
+    else:
+        row = torch.arange(csr.num_rows, dtype=torch.int32, device=dev)
+        beg, end, node = csr.indptr[:-1], csr.indptr[1:], row
+    lens = end - beg
+    long_ = (lens > SHORT_ITEM_EDGES) | (row < 0)
+    n_long = int(long_.sum())
+    if n_long == 0:
+        return base, lens
+    keep = ~long_
+    kind = base.order_kind if base is not None else "natural"
+    i32 = lambda k: torch.zeros(k, dtype=torch.int32, device=dev)
+    head = SpmmPlan(row[keep].contiguous(), beg[keep].contiguous(), end[keep].contiguous(), i32(0), i32(1), 0, kind, i32(0), node[keep].contiguous())
+    if base is not None and base.num_slots:
+        new_index = torch.cumsum(long_.to(torch.int64), 0) - 1
+        hub_row, hub_ptr, slots = base.hub_row, base.hub_slot_ptr, base.num_slots
+        slot_item = new_index[base.slot_item.long()].to(torch.int32).contiguous()
+    else:
+        hub_row, hub_ptr, slots, slot_item = i32(0), i32(1), 0, i32(0)
+    head.rest = SpmmPlan(row[long_].contiguous(), beg[long_].contiguous(), end[long_].contiguous(), hub_row, hub_ptr, slots, kind, slot_item,
+                         node[long_].contiguous())
+    return head, lens[keep]
 
 
 def label_propagation(indptr, indices, n, rounds=5, seed=0, node_w=None, max_weight=None):

@@ -55,7 +55,7 @@ class CsrView(object):
         self._plan = False  # False = not built yet; None = run without a plan
         self._sm_plan = False
         self._tile_plan = False
-        self._short = {}        # lane groups per wave -> bool: see short_rows()
+        self._short = {}        # lane groups per wave -> None | True | two-part SpmmPlan (see _short_choice); "split": its tables
         self.short_hint = None  # True / False: the owner's word on short_rows() where the lengths cannot be read back (graph capture)
         self._row_order = (None, None)  # (row order, kind) computed with the first plan
         self.dst_is_src_prefix = False  # block graphs whose destination nodes are the first source nodes
@@ -94,43 +94,58 @@ class CsrView(object):
         return self._inv_deg
 
     def short_rows(self, width):
-        """True when the summing g-SpMM of `width` columns should give every work item a LANE GROUP of its own (MGX_SPMM_SHORT_ROWS ->
-        spmm_rowgroup32_kernel) instead of a whole wave.  A wave walks B = 64 / G consecutive items side by side, lasts as long as the
-        longest of them, and takes the items beyond 32 edges one after the other with all its lanes.  Three conditions, fitted to the
-        shapes of docs/LOG_r04.md section 2 (uniform halo CSRs: 2-3.5x faster; arxiv at 1.2 M edges: 1.4x SLOWER, at 4.6 M: 1.3x faster):
-          short   fewer than 3 edges per lane group of the wave on average, at most 16;
-          even    sum over batches of max(length clipped at 32) * B <= MGX_ROWGROUP_IMBALANCE (6) x the clipped edge count;
-          no tail the long items of any one batch (consecutive chunks of one hub land together) hold <= max(512, edges / 2048)
-                  edges: one wave's serial stretch against the share of each of the chip's 2048 resident waves.
-        Decided once per CSR and lane-group count (one host sync); a structure rebuilt on the device inside a captured step cannot be
+        """True when the summing g-SpMM of `width` columns gives the work items a LANE GROUP each (see spmm_plan_for)."""
+        return self._short_choice(width) is not None
+
+    def spmm_plan_for(self, width):
+        """(plan, short) for a full-width copy_u / copy_e sum of `width` columns: the CSR's schedule and False, or -- short rows -- the
+        plan to pass with MGX_SPMM_SHORT_ROWS set: the schedule itself when no item is long, else its two-part form (mgx_spmm_plan::rest)."""
+        choice = self._short_choice(width)
+        if choice is None:
+            return self.plan(), False
+        return (self.plan() if choice is True else choice), True
+
+    def _short_choice(self, width):
+        """None: a wave per work item (spmm_rowwave32_kernel).  Otherwise every work item of at most 32 edges gets a lane group of its own
+        (spmm_rowgroup32_kernel, G = lanes per feature row, B = 64 / G items per wave side by side): True = pass the CSR's own schedule,
+        a SpmmPlan = pass this two-part plan, whose `rest` (longer items, chunks of split rows) keeps the wave-per-item kernel.
+        Taken when (measurements: docs/LOG_r04.md section 2)
+          most work is short     at least 90 % of the items have <= 32 edges (one dependent chain per item is what the wave-per-item kernel
+                                 pays for: arxiv, 97.7 % of the items / 48 % of the edges, gains up to 2x), or they hold half of the edges; a
+                                 second launch for less only adds its latency (reddit-small at 1/10 scale, 80 % / 22 %: 0.03 -> 0.05 ms),
+          and short on average   those average fewer than 3 edges per lane group of the wave, at most 16,
+          and even               sum over batches of B consecutive short items of max(length) * B <= MGX_ROWGROUP_IMBALANCE (6) x their edges:
+                                 a wave lasts as long as the longest item of its batch.
+        Decided once per CSR and lane-group count (two host reads); a structure rebuilt on the device inside a captured step cannot be
         read back and says so itself through `short_hint` (graph_classification.GraphedBatchTrainer: molecules, degree <= 6)."""
         lanes, G = (int(width) + 3) // 4, 1
         while G < lanes and G < 64:
             G *= 2
         nb = 64 // G
         if nb < 2 or self.idx_bits != 32 or not self.indptr.is_cuda or self.nnz == 0 or width % 4:
-            return False
+            return None
         if self.short_hint is not None:
-            return bool(self.short_hint)
-        ok = self._short.get(nb)
-        if ok is None:
+            return True if self.short_hint else None
+        if nb not in self._short:
             if torch.cuda.is_current_stream_capturing():
-                return False  # the lengths cannot be read back inside a capture: the wave-per-item kernel, nothing cached
-            plan = self.plan()
-            lens = (plan.item_end - plan.item_beg) if plan is not None else (self.indptr[1:] - self.indptr[:-1])
-            n_items = int(lens.shape[0])
-            ok = False
-            if n_items and self.nnz / n_items < (16.0 if nb >= 8 else 3.0 * nb):
-                pad = (-n_items) % nb
-                if pad:
-                    lens = torch.cat([lens, lens.new_zeros(pad)])
-                lens = lens.view(-1, nb)
-                clipped = lens.clamp(max=32)
-                even = float(clipped.max(dim=1)[0].sum()) * nb <= float(os.environ.get("MGX_ROWGROUP_IMBALANCE", "6.0")) * float(clipped.sum())
-                tail = float((lens * (lens > 32)).sum(dim=1).max())
-                ok = even and tail <= max(512.0, self.nnz / 2048.0)
-            self._short[nb] = ok
-        return ok
+                return None  # the lengths cannot be read back inside a capture: the wave-per-item kernel, nothing cached
+            if "split" not in self._short:
+                from . import schedule
+                self._short["split"] = schedule.split_short_items(self, self.plan())
+            plan, lens = self._short["split"]
+            n_short = int(lens.shape[0])
+            n_items = n_short + (plan.rest.num_items if plan is not None and plan.rest is not None else 0)
+            choice = None
+            if n_short and 2 * n_short >= n_items:
+                pad = (-n_short) % nb
+                padded = torch.cat([lens, lens.new_zeros(pad)]) if pad else lens
+                stats = torch.stack([lens.sum(), padded.view(-1, nb).max(dim=1)[0].sum() * nb]).tolist()  # one host read
+                edges, worst = float(stats[0]), float(stats[1])
+                if ((10 * n_short >= 9 * n_items or 2.0 * edges >= self.nnz) and edges / n_short < (16.0 if nb >= 8 else 3.0 * nb)
+                        and worst <= float(os.environ.get("MGX_ROWGROUP_IMBALANCE", "6.0")) * edges):
+                    choice = True if (plan is None or plan.rest is None) else plan
+            self._short[nb] = choice
+        return self._short[nb]
 
     def plan(self):
         """Execution schedule for the summing g-SpMM (schedule.py); built on first use, device only."""
@@ -382,13 +397,17 @@ class HipBackend(object):
                 else:
                     out.copy_(res)
                 return out, None, None
-        plan = csr.plan() if reduce in ("sum", "mean") else None
-        partial = None
-        if plan is not None and plan.num_slots:
-            partial = torch.empty((plan.num_slots, out_len), dtype=torch.float32, device=dev)
         # MGX_SPMM_SHORT_ROWS: full-width copy_u / copy_e sums over short, even work items take the lane-group-per-item kernel
-        short = (reduce in ("sum", "mean") and src_scale is None and u_off is None and e_off is None
-                 and ((op == "copy_lhs" and u_len == out_len) or (op == "copy_rhs" and e_len == out_len)) and csr.short_rows(out_len))
+        plan, short = None, False
+        if reduce in ("sum", "mean"):
+            if (src_scale is None and u_off is None and e_off is None
+                    and ((op == "copy_lhs" and u_len == out_len) or (op == "copy_rhs" and e_len == out_len))):
+                plan, short = csr.spmm_plan_for(out_len)
+            else:
+                plan = csr.plan()
+        partial = None
+        if plan is not None and plan.total_slots:
+            partial = torch.empty((plan.total_slots, out_len), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rec = None
             if PROFILE is not None:  # bench.py: HIP events on the launch stream around this launch
@@ -453,8 +472,8 @@ class HipBackend(object):
             tp = csr.tile_plan(D)
             if tp is not None:
                 return self.spmm_tile_copy_u(csr, tp, reduce, U2d, out2d, accumulate, dst_scale)
-        plan = csr.plan()
-        partial = torch.empty((plan.num_slots, D), dtype=torch.float32, device=dev) if plan is not None and plan.num_slots else None
+        plan, short = csr.spmm_plan_for(D)
+        partial = torch.empty((plan.total_slots, D), dtype=torch.float32, device=dev) if plan is not None and plan.total_slots else None
         with torch.cuda.device(dev):
             rec = None
             if PROFILE is not None:
@@ -465,7 +484,7 @@ class HipBackend(object):
             _lib.check(_lib.lib().mgx_spmm_copy_u_strided(
                 ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,
                 int(U2d.stride(0)), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial),
-                (1 if accumulate else 0) | (2 if csr.short_rows(D) else 0), _stream(dev)))
+                (1 if accumulate else 0) | (2 if short else 0), _stream(dev)))
             if rec is not None:
                 rec["end"].record(torch.cuda.current_stream(dev))
                 PROFILE.append(rec)

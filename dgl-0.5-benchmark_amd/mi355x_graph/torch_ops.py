@@ -329,13 +329,16 @@ def raw_gspmm(csr, op, reduce, X, Y, want_arg=False):
             return sparse.gspmm_raw(csr, op, reduce, X, Y, want_arg=want_arg)
     if not NATIVE:
         register_view(csr)
-    flags = 0
-    if (op == "copy_lhs" or op == "copy_rhs") and (reduce == "sum" or reduce == "mean"):
+    flags, handle = 0, None
+    if (op == "copy_lhs" or op == "copy_rhs") and (reduce == "sum" or reduce == "mean") and NATIVE and csr.indptr.is_cuda:
         ref = X if op == "copy_lhs" else Y
-        if csr.short_rows(ref.numel() // max(int(ref.shape[0]), 1)):
-            flags = 2  # MGX_SPMM_SHORT_ROWS: one work item per lane group (CsrView.short_rows)
+        plan, short = csr.spmm_plan_for(ref.numel() // max(int(ref.shape[0]), 1))
+        if short:  # MGX_SPMM_SHORT_ROWS: one work item per lane group, over the schedule or its two-part form (CsrView.spmm_plan_for)
+            flags, handle = 2, (0 if plan is None else ctypes.addressof(plan.c_struct()))
+    if handle is None:
+        handle = plan_handle(csr)
     try:
-        out, au, ae = torch.ops.mi355x_graph.gspmm(csr.indptr, csr.indices, csr.eids, csr.num_cols, op, reduce, X, Y, plan_handle(csr), flags)
+        out, au, ae = torch.ops.mi355x_graph.gspmm(csr.indptr, csr.indices, csr.eids, csr.num_cols, op, reduce, X, Y, handle, flags)
     except DGLError:
         raise
     except RuntimeError as err:  # TORCH_CHECK in csrc/torch_bind.cpp: the operator surface raises DGLError (SURVEY 8b "Errors")

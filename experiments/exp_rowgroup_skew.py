@@ -64,6 +64,9 @@ for name, scale in (("arxiv", 1.0), ("reddit-small", 0.1), ("arxiv", 4.0)):
         acc = torch.zeros(n, D, device=dev)
         t = timed(lambda: sparse.gspmm_raw(csc, "copy_lhs", "sum", x, None, accumulate_into=acc))
         imb, avg = imbalance(csc, max(nb, 2))
-        print("%-12s x%.1f n %8d avg item %5.1f D %4d  batch %2d  imbalance(clip 32) %5.2f  %-10s %8.4f ms"
-              % (name, scale, n, avg, D, nb, imb, _lib.lib().mgx_last_spmm_kernel().decode(), t))
+        plan, short = csc.spmm_plan_for(D)
+        form = "-" if not short else ("two-part plan (%d short + %d other items)" % (plan.num_items, plan.rest.num_items)
+                                      if plan is not None and plan.rest is not None else "whole schedule")
+        print("%-12s x%.1f n %8d avg item %5.1f D %4d  batch %2d  imbalance(clip 32) %5.2f  %-10s %8.4f ms  policy: %s"
+              % (name, scale, n, avg, D, nb, imb, _lib.lib().mgx_last_spmm_kernel().decode(), t, form))
     del g, csc

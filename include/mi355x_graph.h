@@ -63,9 +63,9 @@ enum {
                               batch of B = 64 / G consecutive items (G = lanes per feature row = next power of two >= D / 4) the longest is
                               not much above the batch mean.  copy_lhs / copy_rhs with SUM | MEAN then take the kernel that gives every
                               item a lane group of its own (2 - 3.5x on rows of ~3 edges); without the flag, or on skewed items, a wave per
-                              item.  Items above 32 edges are taken by the whole wave inside that kernel, one after the other: keep runs of
-                              long items (consecutive chunks of one hub row) out of a batch, or do not set the flag.  A hint: results
-                              are the same either way (other fp32 summation order). */
+                              item.  Items above 32 edges are taken by the whole wave inside that kernel, one after the other: keep them
+                              (rows above 32 edges, the chunks of split rows) out of the way in the plan's `rest` part (mgx_spmm_plan),
+                              or do not set the flag.  A hint: results are the same either way (other fp32 summation order). */
 };
 
 /* SDDMM operand targets (lhs_target / rhs_target of dgl.ops.gsddmm) */
@@ -110,6 +110,12 @@ typedef struct mgx_spmm_plan {
    * by blockIdx costs scalar registers and, through them, resident workgroups). */
   int64_t xcd_item_start[9];
   const int64_t* xcd_item_start_dev;
+  /* Optional second part (NULL: this plan is the whole schedule).  With `rest`, THIS plan holds only short direct items (item_row >= 0,
+   * at most 32 edges, no slots or hubs) and `rest` holds every other item with the hub tables; together they cover each row once.
+   * Accepted by mgx_spmm_csr / mgx_spmm_copy_u_strided with MGX_SPMM_SHORT_ROWS for copy_lhs / copy_rhs with SUM | MEAN only: the short
+   * items run on the lane-group kernel, `rest` on the wave-per-item kernel (partial_ws: rest->num_slots * out_len floats).  A hub row
+   * of 13 k edges is 52 consecutive 256-edge chunks; walked by the lane-group kernel they would be one wave's serial tail. */
+  const struct mgx_spmm_plan* rest;
 } mgx_spmm_plan;
 
 /* Device-side construction of the plan tables (hub-row splitting over an optional row order; NULL = natural order).

@@ -19,7 +19,7 @@ def last_kernel():
 
 
 def expected_kernel(csr, D):
-    """The host layer's policy (sparse.CsrView.short_rows): short AND even work items -> one item per lane group."""
+    """The host layer's policy (sparse.CsrView.spmm_plan_for): short AND even work items -> one item per lane group."""
     return "rowgroup32" if csr.short_rows(D) else "rowwave32"
 
 
@@ -123,3 +123,65 @@ def test_policy_long_rows_keep_the_row_per_wave_kernel_and_grads_flow(oracle):
     inv = (1.0 / np.maximum(np.diff(ip), 1)).astype(np.float32)
     want = oracle.spmm(rp, rx, re_, "copy_lhs", "sum", w.cpu().numpy() * inv[:, None], None)
     assert float(np.abs(xr.grad.cpu().numpy() - want).max()) <= 1e-4 * float(np.abs(want).max())
+
+
+def test_skewed_graph_takes_a_two_part_plan(oracle):
+    """Power-law rows (the arxiv shape): the short items on the lane-group kernel, hub chunks and long rows in the plan's `rest` on the
+    wave-per-item kernel; every row written exactly once, whatever the reduce / accumulate / dst_scale / strides."""
+    n_src, n_dst, D = 30000, 30000, 32
+    rng = np.random.default_rng(11)
+    deg = rng.poisson(3.4, n_dst).astype(np.int64)
+    heavy = rng.integers(0, n_dst, n_dst // 50)
+    deg[heavy] = np.minimum(40 * rng.zipf(1.6, heavy.shape[0]), 900)   # 2 % of the rows hold half of the edges, like the arxiv stand-in
+    deg[rng.integers(0, n_dst, n_dst // 8)] = 0
+    deg[17] = 1900                                   # split into 256-edge chunks: partial slots + fix-up, all in `rest`
+    dst = np.repeat(np.arange(n_dst), deg)
+    src = rng.integers(0, n_src, dst.shape[0])
+    perm = rng.permutation(dst.shape[0])
+    src, dst = src[perm], dst[perm]
+    g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=torch.int32, device=DEV)
+    csc = g._index.csc()
+    plan, short = csc.spmm_plan_for(D)
+    assert short and plan is not None and plan.rest is not None
+    lens = (plan.item_end - plan.item_beg)
+    assert int(lens.max()) <= 32 and bool((plan.item_row >= 0).all()) and plan.num_slots == 0
+    rest = plan.rest
+    assert rest.num_slots >= 8 and int((rest.item_row < 0).sum()) == rest.num_slots
+    covered = torch.cat([plan.item_node, rest.item_node[rest.item_row >= 0], rest.hub_row]).long()
+    assert covered.shape[0] == n_dst and bool((torch.bincount(covered, minlength=n_dst) == 1).all())
+    owner = rest.slot_item.long()                    # slot s is written by item slot_item[s] of `rest`
+    assert torch.equal(rest.item_row[owner].long(), -(torch.arange(rest.num_slots, device=DEV) + 1))
+    X = rng.standard_normal((n_src, D)).astype(np.float32)
+    x = torch.from_numpy(X).to(DEV)
+    ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
+    for red in ("sum", "mean"):
+        out = ops.gspmm(g, "copy_lhs", red, x, None).cpu().numpy()
+        assert last_kernel() == "rowgroup32"
+        ref = oracle.spmm(ip, ix, ei, "copy_lhs", red, X, None)
+        assert np.array_equal(out[deg <= 32], ref[deg <= 32])     # a lane group adds in storage order
+        scale = oracle.spmm(ip, ix, ei, "copy_lhs", "sum", np.abs(X), None)
+        if red == "mean":
+            scale = scale / np.maximum(deg, 1)[:, None]
+        assert bool((np.abs(out - ref) <= 1e-4 * scale + 1e-30).all())
+    be = sparse.backend_for(csc.indptr)
+    sc = torch.from_numpy(rng.random(n_dst).astype(np.float32) + 0.5).to(DEV)
+    base = torch.from_numpy(rng.standard_normal((n_dst, 2 * D)).astype(np.float32)).to(DEV)
+    wide = base.clone()
+    be.spmm_copy_u_strided(csc, "sum", x, wide[:, D:], accumulate=True, dst_scale=sc)
+    assert last_kernel() == "rowgroup32"
+    want = base[:, D:].cpu().numpy() + oracle.spmm(ip, ix, ei, "copy_lhs", "sum", X, None) * sc.cpu().numpy()[:, None]
+    assert float(np.abs(wide[:, D:].cpu().numpy() - want).max()) <= 1e-4 * float(np.abs(want).max())
+    assert torch.equal(wide[:, :D], base[:, :D])
+    E = rng.standard_normal((src.shape[0], 16)).astype(np.float32)
+    out_e = ops.gspmm(g, "copy_rhs", "sum", None, torch.from_numpy(E).to(DEV)).cpu().numpy()
+    ref_e = oracle.spmm(ip, ix, ei, "copy_rhs", "sum", None, E)
+    assert np.array_equal(out_e[deg <= 32], ref_e[deg <= 32])
+    assert float(np.abs(out_e - ref_e).max()) <= 1e-4 * float(np.abs(ref_e).max())
+    # a two-part plan is refused where it does not belong (max has no split form here)
+    import ctypes
+    out_m = torch.empty(n_dst, D, device=DEV)
+    ws = torch.empty(rest.num_slots, D, device=DEV)
+    P = sparse._ptr
+    status = _lib.lib().mgx_spmm_csr(ctypes.byref(csc.c_struct()), ctypes.byref(plan.c_struct()), sparse.OP["copy_lhs"], sparse.REDUCE["max"],
+                                     P(x), None, D, 0, D, None, None, None, None, P(out_m), None, None, P(ws), 2, None)
+    assert status != 0 and b"rest" in _lib.lib().mgx_last_error()
