@@ -101,8 +101,9 @@ SHORT_ITEM_EDGES = 32  # the longest item a lane group of spmm_rowgroup32_kernel
 def split_short_items(csr, base):
     """The schedule of `csr` (`base`, or its natural rows when it has no plan) as a TWO-PART plan (mgx_spmm_plan::rest): the direct items
     of at most 32 edges, in schedule order, for the lane-group kernel; every other item -- longer rows, the 256-edge chunks of split
-    rows with the hub tables -- in `rest` for the wave-per-item kernel.  Returns (plan, short_lengths); plan is `base` itself (may be
-    None) when nothing is long.  One host read of the long-item count."""
+    rows with the hub tables -- in `rest` for the wave-per-item kernel.  Returns (plan, short_lengths, short_edges); plan is `base`
+    itself (may be None) when nothing is long.  None when the short items are neither 90 % of the items nor half of the edges: a
+    second launch for a minority of the work only adds its latency, and nothing is materialised.  One host read."""
     dev = csr.indptr.device
     if base is not None:
         row, beg, end, node = base.item_row, base.item_beg, base.item_end, base.item_node
@@ -111,9 +112,13 @@ def split_short_items(csr, base):
         beg, end, node = csr.indptr[:-1], csr.indptr[1:], row
     lens = end - beg
     long_ = (lens > SHORT_ITEM_EDGES) | (row < 0)
-    n_long = int(long_.sum())
+    n_long, long_edges = [int(v) for v in torch.stack([long_.sum(), (lens * long_).sum()]).tolist()]
+    n_items = int(lens.shape[0])
+    n_short, short_edges = n_items - n_long, csr.nnz - long_edges
+    if n_short == 0 or not (10 * n_short >= 9 * n_items or 2 * short_edges >= csr.nnz):
+        return None
     if n_long == 0:
-        return base, lens
+        return base, lens, short_edges
     keep = ~long_
     kind = base.order_kind if base is not None else "natural"
     i32 = lambda k: torch.zeros(k, dtype=torch.int32, device=dev)
@@ -126,7 +131,7 @@ def split_short_items(csr, base):
         hub_row, hub_ptr, slots, slot_item = i32(0), i32(1), 0, i32(0)
     head.rest = SpmmPlan(row[long_].contiguous(), beg[long_].contiguous(), end[long_].contiguous(), hub_row, hub_ptr, slots, kind, slot_item,
                          node[long_].contiguous())
-    return head, lens[keep]
+    return head, lens[keep], short_edges
 
 
 def label_propagation(indptr, indices, n, rounds=5, seed=0, node_w=None, max_weight=None):

@@ -132,17 +132,14 @@ class CsrView(object):
             if "split" not in self._short:
                 from . import schedule
                 self._short["split"] = schedule.split_short_items(self, self.plan())
-            plan, lens = self._short["split"]
-            n_short = int(lens.shape[0])
-            n_items = n_short + (plan.rest.num_items if plan is not None and plan.rest is not None else 0)
             choice = None
-            if n_short and 2 * n_short >= n_items:
+            if self._short["split"] is not None:
+                plan, lens, edges = self._short["split"]
+                n_short = int(lens.shape[0])
                 pad = (-n_short) % nb
                 padded = torch.cat([lens, lens.new_zeros(pad)]) if pad else lens
-                stats = torch.stack([lens.sum(), padded.view(-1, nb).max(dim=1)[0].sum() * nb]).tolist()  # one host read
-                edges, worst = float(stats[0]), float(stats[1])
-                if ((10 * n_short >= 9 * n_items or 2.0 * edges >= self.nnz) and edges / n_short < (16.0 if nb >= 8 else 3.0 * nb)
-                        and worst <= float(os.environ.get("MGX_ROWGROUP_IMBALANCE", "6.0")) * edges):
+                worst = float(padded.view(-1, nb).max(dim=1)[0].sum()) * nb  # one host read
+                if edges / n_short < (16.0 if nb >= 8 else 3.0 * nb) and worst <= float(os.environ.get("MGX_ROWGROUP_IMBALANCE", "6.0")) * edges:
                     choice = True if (plan is None or plan.rest is None) else plan
             self._short[nb] = choice
         return self._short[nb]
