@@ -27,6 +27,9 @@ The JSON line also carries
                 package's -- timed right after the headline loop.  The headline (default) model computes the same function
                 with this package's dense-side forms: a SAGE layer as one autograd node and one GEMM on [h | neigh], fused
                 relu+dropout, the loss tail on the training rows only (DESIGN 6);
+  epoch_ms_plain_model_accelerated_linear   the same unmodified modules as `import dgl` runs them by default: torch.nn.Linear's
+                backward on tall matrices through this package's column-sum / X^T Y kernels (mi355x_graph.utils.accelerate_linear();
+                epoch_ms_plain_model is measured with it switched off = MGX_ACCELERATE_LINEAR=0);
   cpu_baseline  the CPU oracle (OpenMP port of DGL's CPU algorithm) timed on the host cores on the g-SpMMs of one epoch
                 (rank 0, N = 1 only, bounded to ~30 s).
 """
@@ -540,6 +543,8 @@ def main():
     if single and not args.no_plain:
         del model, opt
         torch.cuda.empty_cache()
+        from mi355x_graph import utils as mutils
+        was_accelerated = mutils.accelerate_linear(False)  # this leg: PyTorch's own torch.nn.Linear backward (MGX_ACCELERATE_LINEAR=0)
         pm = make_model(plain=True)
         popt = torch.optim.Adam(pm.parameters(), lr=cfg["lr"])
         psteps = min(args.steps, 10)
@@ -550,6 +555,22 @@ def main():
                                "steps": psteps, "final_loss": ploss,
                                "value_edges_per_s": agg_edges / (pel / psteps)}
         del pm, popt
+        torch.cuda.empty_cache()
+        # ---- the same unmodified modules with mi355x_graph.utils.accelerate_linear(): torch.nn.Linear's backward through this package's
+        # column-sum / X^T Y kernels (PyTorch's bias-gradient reduction alone is 19 ms of the epoch above)
+        mutils.accelerate_linear(True)
+        try:
+            pm = make_model(plain=True)
+            popt = torch.optim.Adam(pm.parameters(), lr=cfg["lr"])
+            pel2, ploss2, _ = timed(make_step(pm, popt, None), psteps, min(args.warmup, 3), False)
+            line["epoch_ms_plain_model_accelerated_linear"] = round(pel2 / psteps * 1e3, 3)
+            line["plain_model"]["accelerated_linear"] = {"what": "what `import dgl` does by default (mi355x_graph.utils.accelerate_linear(); "
+                                                                 "MGX_ACCELERATE_LINEAR=0 opts out): same modules, same script; F.linear's "
+                                                                 "backward on tall matrices by mgx_column_sum / mgx_xty",
+                                                         "final_loss": ploss2}
+            del pm, popt
+        finally:
+            mutils.accelerate_linear(was_accelerated)
         torch.cuda.empty_cache()
         # ---- the default model again with the backward of the LAST layer formed on the loss rows only (ops.SageMeanCatRowsFn,
         # MGX_SAGE_SPARSE_LAST=1): same forward, same gradients -- the output gradient is zero outside the 8 % training rows, so the
