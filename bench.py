@@ -178,15 +178,23 @@ def profile_avg_us(tag=None):
         files = [f for f in files if os.path.basename(f).startswith(tag + "_")]
     if not files:
         return {}
-    out = {}
+    out, group = {}, {}
     for ln in open(files[-1]):
-        # the row kernel only: spmm_tile*_kernel<W, NL, ...> carries other template arguments
-        m = re.match(r"void mgx::spmm_rowwave32_kernel<(\d+), (\d+),.*?\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s*$", ln)
+        # the row kernels only: spmm_tile*_kernel<W, NL, ...> carries other template arguments.  A launch over a two-part
+        # plan (short items: spmm_rowgroup32_kernel<VEC, G, ...>; the rest: spmm_rowwave32_kernel<VEC, G, ...>) is the SUM of the two.
+        m = re.match(r"void mgx::spmm_(rowwave32|rowgroup32)_kernel<(\d+), (\d+),.*?\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+[\d.]+\s*$", ln)
         if m:
-            vec, g, calls, _total, avg = int(m.group(1)), int(m.group(2)), int(m.group(3)), m.group(4), float(m.group(5))
+            fam, vec, g, calls, total_ms = m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5))
             for width in (64, 100):  # lane-group width G covers D = 4 G columns (D = 100: G = 32 with idle lanes)
-                if (vec * g >= width > vec * g // 2) and width not in out:
-                    out[width] = {"avg_us": avg, "calls": calls, "file": os.path.basename(files[-1])}
+                if vec * g >= width > vec * g // 2:
+                    if fam == "rowwave32" and width not in out:
+                        out[width] = {"avg_us": float(m.group(6)), "calls": calls, "file": os.path.basename(files[-1])}
+                    elif fam == "rowgroup32" and width not in group:
+                        group[width] = (calls, total_ms)
+    for width, (calls, total_ms) in group.items():
+        if width in out and calls == out[width]["calls"]:  # one lane-group launch per wave-per-item launch: the same calls, in two parts
+            out[width]["avg_us"] = round(out[width]["avg_us"] + total_ms * 1e3 / calls, 2)
+            out[width]["kernels"] = "spmm_rowgroup32_kernel + spmm_rowwave32_kernel (two-part plan)"
     return out
 
 

@@ -151,19 +151,29 @@ def parse_pmc_dir(path):
         d = disp.setdefault(int(r["Dispatch_Id"]), {"name": r["Kernel_Name"], "c": {}})
         d["c"][r["Counter_Name"]] = d["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
         d["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    blocks, cur = [], {"counters": {}, "launches": 0, "kernel": None, "ns": 0}
+    def fresh():
+        return {"counters": {}, "launches": 0, "kernel": None, "ns": 0, "names": {}}
+
+    def close(b):  # a call over a two-part plan is two main kernels: launches = calls of the most frequent one, kernel = all names
+        if b["names"]:
+            b["launches"] = max(b["names"].values())
+            b["kernel"] = " + ".join(b["names"])
+        del b["names"]
+        return b
+
+    blocks, cur = [], fresh()
     for k in sorted(disp):
         d = disp[k]
         if MARKER in d["name"]:
-            blocks.append(cur)
-            cur = {"counters": {}, "launches": 0, "kernel": None, "ns": 0}
+            blocks.append(close(cur))
+            cur = fresh()
         elif "mgx::spmm" in d["name"]:
             for c, v in d["c"].items():
                 cur["counters"][c] = cur["counters"].get(c, 0.0) + v
             cur["ns"] += d["ns"]
             if "fixup" not in d["name"]:
-                cur["launches"] += 1
-                cur["kernel"] = d["name"].split("(")[0].replace("void ", "")
+                name = d["name"].split("(")[0].replace("void ", "")
+                cur["names"][name] = cur["names"].get(name, 0) + 1
     return blocks
 
 

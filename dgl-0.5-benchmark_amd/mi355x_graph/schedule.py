@@ -95,15 +95,25 @@ class SpmmPlan(object):
         return self._c
 
 
-SHORT_ITEM_EDGES = 32  # the longest item a lane group of spmm_rowgroup32_kernel walks alone
+SHORT_ITEM_EDGES = 32     # the longest item a lane group of spmm_rowgroup32_kernel walks alone (kLong in csrc/spmm.hip)
+MIN_SHORT_ITEMS = 100_000  # fewer short items than this do not pay for a second launch (see split_short_items)
 
 
-def split_short_items(csr, base):
+def short_item_limit(lane_groups):
+    """Edges up to which an item counts as short when `lane_groups` (= 64 / G) items share a wave: 4 per lane group of the wave, at most
+    32.  Measured on the products graph (experiments/exp_two_part_products.py): D = 64 (4 lane groups) best at 16 (8: -1.7 %, 16: -5.4 %,
+    24: -4.8 %, 32: -4.1 % of the one-launch time), D = 16 (16 lane groups) at 24 .. 32 (-18 %), D = 100 (2 lane groups) at none."""
+    return min(SHORT_ITEM_EDGES, 4 * int(lane_groups))
+
+
+def split_short_items(csr, base, any_share=False, limit=SHORT_ITEM_EDGES):
     """The schedule of `csr` (`base`, or its natural rows when it has no plan) as a TWO-PART plan (mgx_spmm_plan::rest): the direct items
-    of at most 32 edges, in schedule order, for the lane-group kernel; every other item -- longer rows, the 256-edge chunks of split
-    rows with the hub tables -- in `rest` for the wave-per-item kernel.  Returns (plan, short_lengths, short_edges); plan is `base`
-    itself (may be None) when nothing is long.  None when the short items are neither 90 % of the items nor half of the edges: a
-    second launch for a minority of the work only adds its latency, and nothing is materialised.  One host read."""
+    of at most `limit` edges, in schedule order, for the lane-group kernel; every other item -- longer rows, the 256-edge chunks of
+    split rows with the hub tables -- in `rest` for the wave-per-item kernel.  Returns (plan, short_lengths, short_edges); plan is
+    `base` itself (may be None) when nothing is long.  None when something is long but fewer than MIN_SHORT_ITEMS items are short:
+    what the lane-group kernel saves grows with the number of short items (0.05 - 0.2 ns each: arxiv x 1 165 k items -8 us, arxiv x 4
+    662 k -120 us, products 1.3 M -110 us) and the second launch costs 10 - 20 us whatever it holds (reddit-small / 10, 18 k short
+    items: 0.03 -> 0.05 ms); nothing is materialised then (any_share=True: experiments).  One host read."""
     dev = csr.indptr.device
     if base is not None:
         row, beg, end, node = base.item_row, base.item_beg, base.item_end, base.item_node
@@ -111,11 +121,11 @@ def split_short_items(csr, base):
         row = torch.arange(csr.num_rows, dtype=torch.int32, device=dev)
         beg, end, node = csr.indptr[:-1], csr.indptr[1:], row
     lens = end - beg
-    long_ = (lens > SHORT_ITEM_EDGES) | (row < 0)
+    long_ = (lens > limit) | (row < 0)
     n_long, long_edges = [int(v) for v in torch.stack([long_.sum(), (lens * long_).sum()]).tolist()]
     n_items = int(lens.shape[0])
     n_short, short_edges = n_items - n_long, csr.nnz - long_edges
-    if n_short == 0 or not (10 * n_short >= 9 * n_items or 2 * short_edges >= csr.nnz):
+    if n_short == 0 or (n_long > 0 and n_short < MIN_SHORT_ITEMS and not any_share):
         return None
     if n_long == 0:
         return base, lens, short_edges

@@ -106,16 +106,15 @@ class CsrView(object):
         return (self.plan() if choice is True else choice), True
 
     def _short_choice(self, width):
-        """None: a wave per work item (spmm_rowwave32_kernel).  Otherwise every work item of at most 32 edges gets a lane group of its own
-        (spmm_rowgroup32_kernel, G = lanes per feature row, B = 64 / G items per wave side by side): True = pass the CSR's own schedule,
-        a SpmmPlan = pass this two-part plan, whose `rest` (longer items, chunks of split rows) keeps the wave-per-item kernel.
+        """None: a wave per work item (spmm_rowwave32_kernel).  Otherwise the SHORT work items -- at most schedule.short_item_limit(B)
+        edges, B = 64 / G the items a wave walks side by side, G = lanes per feature row -- get a lane group each
+        (spmm_rowgroup32_kernel): True = every item is short, pass the CSR's own schedule; a SpmmPlan = pass this two-part plan, whose
+        `rest` (longer rows, chunks of split rows) keeps the wave-per-item kernel in a second launch of the same call.
         Taken when (measurements: docs/LOG_r04.md section 2)
-          most work is short     at least 90 % of the items have <= 32 edges (one dependent chain per item is what the wave-per-item kernel
-                                 pays for: arxiv, 97.7 % of the items / 48 % of the edges, gains up to 2x), or they hold half of the edges; a
-                                 second launch for less only adds its latency (reddit-small at 1/10 scale, 80 % / 22 %: 0.03 -> 0.05 ms),
-          and short on average   those average fewer than 3 edges per lane group of the wave, at most 16,
-          and even               sum over batches of B consecutive short items of max(length) * B <= MGX_ROWGROUP_IMBALANCE (6) x their edges:
-                                 a wave lasts as long as the longest item of its batch.
+          enough items are short  all of them, or at least schedule.MIN_SHORT_ITEMS (what the second launch has to pay for),
+          short on average        the short items average fewer than 3 edges per lane group of the wave, at most 16,
+          and even                sum over batches of B consecutive short items of max(length) * B <= MGX_ROWGROUP_IMBALANCE (6) x their
+                                  edges: a wave lasts as long as the longest item of its batch.
         Decided once per CSR and lane-group count (two host reads); a structure rebuilt on the device inside a captured step cannot be
         read back and says so itself through `short_hint` (graph_classification.GraphedBatchTrainer: molecules, degree <= 6)."""
         lanes, G = (int(width) + 3) // 4, 1
@@ -129,12 +128,13 @@ class CsrView(object):
         if nb not in self._short:
             if torch.cuda.is_current_stream_capturing():
                 return None  # the lengths cannot be read back inside a capture: the wave-per-item kernel, nothing cached
-            if "split" not in self._short:
-                from . import schedule
-                self._short["split"] = schedule.split_short_items(self, self.plan())
-            choice = None
-            if self._short["split"] is not None:
-                plan, lens, edges = self._short["split"]
+            from . import schedule
+            limit = schedule.short_item_limit(nb)
+            if ("split", limit) not in self._short:
+                self._short[("split", limit)] = schedule.split_short_items(self, self.plan(), limit=limit)
+            split, choice = self._short[("split", limit)], None
+            if split is not None:
+                plan, lens, edges = split
                 n_short = int(lens.shape[0])
                 pad = (-n_short) % nb
                 padded = torch.cat([lens, lens.new_zeros(pad)]) if pad else lens
@@ -290,6 +290,13 @@ def _device_table(arr, device):
 
 
 # ----------------------------------------------------------------------------- backends
+def _short_variant(plan):
+    """Label of a MGX_SPMM_SHORT_ROWS launch in bench.py's records: which kernels one call runs."""
+    if plan is not None and plan.rest is not None:
+        return "lane-group (spmm_rowgroup32_kernel, %d short items) + row (spmm_rowwave32_kernel, %d items)" % (plan.num_items, plan.rest.num_items)
+    return "lane-group (spmm_rowgroup32_kernel)"
+
+
 class HipBackend(object):
     """Calls the gfx950 library through its C ABI on PyTorch's current HIP stream."""
 
@@ -411,6 +418,8 @@ class HipBackend(object):
                 rec = {"op": op, "reduce": reduce, "out_len": out_len, "n_rows": csr.num_rows, "n_cols": csr.num_cols,
                        "nnz": csr.nnz, "accumulate": accumulate_into is not None, "start": torch.cuda.Event(enable_timing=True),
                        "end": torch.cuda.Event(enable_timing=True)}
+                if short:
+                    rec["variant"] = _short_variant(plan)
                 rec["start"].record(torch.cuda.current_stream(dev))
             _lib.check(_lib.lib().mgx_spmm_csr(
                 ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()),
@@ -477,6 +486,8 @@ class HipBackend(object):
                 rec = {"op": "copy_lhs", "reduce": reduce, "out_len": D, "n_rows": csr.num_rows, "n_cols": csr.num_cols,
                        "nnz": csr.nnz, "accumulate": bool(accumulate), "strides": (int(U2d.stride(0)), int(out2d.stride(0))),
                        "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
+                if short:
+                    rec["variant"] = _short_variant(plan)
                 rec["start"].record(torch.cuda.current_stream(dev))
             _lib.check(_lib.lib().mgx_spmm_copy_u_strided(
                 ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,

@@ -74,7 +74,7 @@ def test_short_rows_copy_u_against_the_oracle(oracle, D, avg):
 
 
 def test_short_rows_strided_operands_and_copy_e(oracle):
-    n_src, n_dst, D = 6000, 9000, 64
+    n_src, n_dst, D = 6000, 130000, 64          # (two hub rows: a two-part plan needs schedule.MIN_SHORT_ITEMS short rows to be taken)
     src, dst, deg = short_row_graph(n_src, n_dst, 3.4, seed=5)
     g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=torch.int32, device=DEV)
     csc = g._index.csc()
@@ -88,7 +88,7 @@ def test_short_rows_strided_operands_and_copy_e(oracle):
     ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
     ref = oracle.spmm(ip, ix, ei, "copy_lhs", "mean", wide_in[:, D:2 * D].contiguous().cpu().numpy(), None)
     got = wide_out.cpu().numpy()
-    assert np.array_equal(got[:, D:2 * D][deg <= 32], ref[deg <= 32])
+    assert np.array_equal(got[:, D:2 * D][deg <= 16], ref[deg <= 16])
     assert float(np.abs(got[:, :D]).sum()) == 0.0 and float(np.abs(got[:, 2 * D:]).sum()) == 0.0   # nothing written beside the block
     be.spmm_copy_u_strided(csc, "sum", wide_in[:, D:2 * D], wide_out[:, D:2 * D], accumulate=True)
     ref2 = ref + oracle.spmm(ip, ix, ei, "copy_lhs", "sum", wide_in[:, D:2 * D].contiguous().cpu().numpy(), None)
@@ -128,7 +128,7 @@ def test_policy_long_rows_keep_the_row_per_wave_kernel_and_grads_flow(oracle):
 def test_skewed_graph_takes_a_two_part_plan(oracle):
     """Power-law rows (the arxiv shape): the short items on the lane-group kernel, hub chunks and long rows in the plan's `rest` on the
     wave-per-item kernel; every row written exactly once, whatever the reduce / accumulate / dst_scale / strides."""
-    n_src, n_dst, D = 30000, 30000, 32
+    n_src, n_dst, D = 30000, 160000, 32
     rng = np.random.default_rng(11)
     deg = rng.poisson(3.4, n_dst).astype(np.int64)
     heavy = rng.integers(0, n_dst, n_dst // 50)
