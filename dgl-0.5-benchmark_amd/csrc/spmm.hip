@@ -54,7 +54,8 @@ struct SpmmFastArgs {
   int mean;
   int accum;  // out += result (MGX_SPMM_ACCUMULATE)
   int ragged; // D % 4 != 0 handled with 16-byte gathers (RAGGED kernel)
-  int short_rows;  // MGX_SPMM_SHORT_ROWS: the caller vouches for short, even work items -> one item per lane group (spmm_rowgroup32_kernel)
+  int short_rows;  // MGX_SPMM_SHORT_ROWS: the caller vouches for short, even work items -> one item per lane group (spmm_rowgroup32_kernel);
+                   // 2: ... and this is the head of a two-part plan (no item above 32 edges)
   int lds;    // row stride of `src` in floats (>= D; == D unless mgx_spmm_copy_u_strided)
   int ldo;    // row stride of `out` in floats
 };
@@ -554,7 +555,9 @@ __global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t
 // at the end.  Terms are added in storage order (exactly the CPU oracle's order for rows that are not split).
 // COPY_LHS / COPY_RHS, sum / mean, dst_scale, accumulate, row strides, plan items with partial slots; int32 ids, gathered
 // matrix below 4 GiB, D % 4 == 0.  The next batch's bounds and ids are requested before the current batch's gathers.
-template <int VEC, int G, int MODE, bool LANEMASK>
+// LONG = false: the head of a two-part plan, whose items are short by contract -- the whole-wave path for long items is compiled out
+// (registers: see launch_rowgroup32); a longer item would still be summed correctly, by its lane group alone.
+template <int VEC, int G, int MODE, bool LANEMASK, bool LONG>
 __global__ __launch_bounds__(kBlock) void spmm_rowgroup32_kernel(const SpmmFastArgs<int32_t> a) {
   typedef typename VecT<VEC>::type V;
   constexpr int NB = kWave / G;
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup32_kernel(const SpmmFastA
     V acc = (V)(0.f);
     // items longer than kLong edges are NOT walked by their lane group alone (one group gathering 256 edges, 4 in flight, is 64
     // dependent round trips -- the tail of the whole launch on a skewed graph): the wave takes them together below
-    const bool deferred = ok && (end - beg) > kLong;
+    const bool deferred = LONG && ok && (end - beg) > kLong;
     const int32_t gend = deferred ? beg : end;
     int32_t cbase = beg;
     for (;;) {  // chunks of G edges; wave-uniform trip count (the longest item of the batch), per-group predicates inside
@@ -646,8 +649,8 @@ __global__ __launch_bounds__(kBlock) void spmm_rowgroup32_kernel(const SpmmFastA
     }
     // ---- long items of this batch, one after the other, by the WHOLE wave: 64 ids per coalesced load, lane group `sub` gathers edges
     // k + u * NB + sub, the groups' partial sums meet in an xor-shuffle tree, the owner group keeps the result
-    uint64_t dmask = __builtin_amdgcn_ballot_w64(deferred);
-    while (dmask) {
+    uint64_t dmask = LONG ? __builtin_amdgcn_ballot_w64(deferred) : 0;
+    while (LONG && dmask) {
       const int src_lane = __builtin_amdgcn_readfirstlane(__builtin_ctzll(dmask));
       const int gsel = src_lane / G;
       const int32_t cb = __builtin_amdgcn_readlane(beg, src_lane), ce = __builtin_amdgcn_readlane(end, src_lane);
@@ -720,8 +723,13 @@ static bool launch_rowgroup32(SpmmFastArgs<int32_t> a, int64_t nnz, hipStream_t 
     note_spmm_kernel("rowgroup32");
     a.rpb = 2 * kWavesPerBlock * NB;  // two batches per wave: the second's ids travel under the first's gathers
     const dim3 grid((unsigned)xcd_ranges(a.plan, a.n_items, a.rpb, a.xcd), (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
-    if (a.D % (G * VEC) != 0) hipLaunchKernelGGL((spmm_rowgroup32_kernel<VEC, G, MODE, true>), grid, dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((spmm_rowgroup32_kernel<VEC, G, MODE, false>), grid, dim3(kBlock), 0, s, a);
+    if (a.short_rows == 2) {  // head of a two-part plan: every item short
+      if (a.D % (G * VEC) != 0) hipLaunchKernelGGL((spmm_rowgroup32_kernel<VEC, G, MODE, true, false>), grid, dim3(kBlock), 0, s, a);
+      else hipLaunchKernelGGL((spmm_rowgroup32_kernel<VEC, G, MODE, false, false>), grid, dim3(kBlock), 0, s, a);
+    } else {
+      if (a.D % (G * VEC) != 0) hipLaunchKernelGGL((spmm_rowgroup32_kernel<VEC, G, MODE, true, true>), grid, dim3(kBlock), 0, s, a);
+      else hipLaunchKernelGGL((spmm_rowgroup32_kernel<VEC, G, MODE, false, true>), grid, dim3(kBlock), 0, s, a);
+    }
     return true;
   }
 }
@@ -1010,7 +1018,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     a.n_rows = n_rows; a.nblocks = nblocks; a.D = (int)out_len; a.H = 1; a.F = (int)out_len;
     a.mean = reduce == MGX_REDUCE_MEAN;
     a.accum = accumulate;
-    a.short_rows = (flag_bits & MGX_SPMM_SHORT_ROWS) ? 1 : 0;
+    a.short_rows = (flag_bits & MGX_SPMM_SHORT_ROWS) ? ((flag_bits & kSpmmPartialPlan) ? 2 : 1) : 0;
     a.ragged = 0;
     a.lds = u_stride ? (int)u_stride : (int)out_len;
     a.ldo = out_stride ? (int)out_stride : (int)out_len;
