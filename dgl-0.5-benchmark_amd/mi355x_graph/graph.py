@@ -35,6 +35,7 @@ class GraphIndex(object):
         self._canonical = None
         self.dst_is_src_prefix = False  # blocks: destination nodes are the first source nodes
         self.max_in_degree_hint = None
+        self.ephemeral = False  # a structure used for ONE step (a sampled block): its views decide kernel forms without host reads
 
     # -- basic facts
     def _any(self):
@@ -106,11 +107,16 @@ class GraphIndex(object):
             src, dst = self.coo()
             view = sparse.coo_to_csr(self.num_dst, self.num_src, dst, src)
         view.dst_is_src_prefix = self.dst_is_src_prefix
+        self._mark_ephemeral(view)
         if self.allowed("csc"):
             self._csc = view
         else:
             self._hidden_csc = view
         return view
+
+    def _mark_ephemeral(self, view):
+        if self.ephemeral and view.short_hint is None:
+            view.short_hint = view.nnz / float(max(view.num_rows, 1))  # average row length: CsrView._short_choice decides on it, sync-free
 
     def csr(self):
         """out-CSR: rows = src, indices = dst, eids -> edge id (the reversed graph's in-CSR)."""
@@ -124,6 +130,7 @@ class GraphIndex(object):
         else:
             src, dst = self.coo()
             view = sparse.coo_to_csr(self.num_src, self.num_dst, src, dst)
+        self._mark_ephemeral(view)
         if self.allowed("csr"):
             self._csr = view
         else:
@@ -191,6 +198,7 @@ class GraphIndex(object):
         g = GraphIndex(self.num_src, self.num_dst, coo, mv(self._csr), mv(self._csc), self._formats)
         g._hidden_csc, g._hidden_csr = mv(self._hidden_csc), mv(self._hidden_csr)
         g.dst_is_src_prefix = self.dst_is_src_prefix
+        g.ephemeral = self.ephemeral
         return g
 
     def astype(self, dtype):
@@ -203,6 +211,7 @@ class GraphIndex(object):
         g = GraphIndex(self.num_src, self.num_dst, coo, cv(self._csr), cv(self._csc), self._formats)
         g._hidden_csc, g._hidden_csr = cv(self._hidden_csc), cv(self._hidden_csr)
         g.dst_is_src_prefix = self.dst_is_src_prefix
+        g.ephemeral = self.ephemeral
         return g
 
     def in_degrees(self):

@@ -93,6 +93,9 @@ def to_block(g_or_edges, dst_nodes, num_nodes=None, idtype=torch.int64, dst_sort
     block = DGLGraph(GraphIndex(src_nodes.shape[0], dst_nodes.shape[0], coo=(l_src, l_dst), csc=csc), is_block=True)
     block._index.dst_is_src_prefix = True
     block._index.max_in_degree_hint = max_in_degree
+    block._index.ephemeral = True  # one training step: kernel forms from host-known numbers, no analysis of the row lengths
+    if csc is not None:
+        block._index._mark_ephemeral(csc)
     block.srcdata[NID] = src_nodes
     block.dstdata[NID] = dst_nodes
     if eid is not None:
@@ -174,6 +177,7 @@ def node_subgraph(g, nodes):
     ls, ld = lut[src.long()], lut[dst.long()]
     keep = (ls >= 0) & (ld >= 0)
     sub = DGLGraph(GraphIndex(nodes.shape[0], nodes.shape[0], coo=(ls[keep].to(g.idtype).contiguous(), ld[keep].to(g.idtype).contiguous())))
+    sub._index.ephemeral = True  # a cluster / mini-batch subgraph: see GraphIndex.ephemeral
     for k, v in g.ndata.items():
         sub.ndata[k] = v[nodes.to(v.device)]
     for k, v in g.edata.items():

@@ -56,7 +56,8 @@ class CsrView(object):
         self._sm_plan = False
         self._tile_plan = False
         self._short = {}        # lane groups per wave -> None | True | two-part SpmmPlan (see _short_choice); "split": its tables
-        self.short_hint = None  # True / False: the owner's word on short_rows() where the lengths cannot be read back (graph capture)
+        self.short_hint = None  # the owner's word on short rows where reading the lengths back is impossible (graph capture) or not
+                                # worth it (a sampled block): True / False, or the average row length (see _short_choice)
         self._row_order = (None, None)  # (row order, kind) computed with the first plan
         self.dst_is_src_prefix = False  # block graphs whose destination nodes are the first source nodes
 
@@ -124,7 +125,11 @@ class CsrView(object):
         if nb < 2 or self.idx_bits != 32 or not self.indptr.is_cuda or self.nnz == 0 or width % 4:
             return None
         if self.short_hint is not None:
-            return True if self.short_hint else None
+            if self.short_hint is True or self.short_hint is False:
+                return True if self.short_hint else None
+            # a number: the average row length of a structure that lives for one step (a sampled block) -- the average rule alone,
+            # from host-known sizes; rows above 32 edges are taken by the whole wave inside the kernel
+            return True if float(self.short_hint) < (16.0 if nb >= 8 else 3.0 * nb) else None
         if nb not in self._short:
             if torch.cuda.is_current_stream_capturing():
                 return None  # the lengths cannot be read back inside a capture: the wave-per-item kernel, nothing cached
@@ -225,14 +230,18 @@ class CsrView(object):
         return self._sm_plan
 
     def to(self, device):
-        return CsrView(self.num_rows, self.num_cols, self.indptr.to(device), self.indices.to(device),
-                       None if self.eids is None else self.eids.to(device))
+        out = CsrView(self.num_rows, self.num_cols, self.indptr.to(device), self.indices.to(device),
+                      None if self.eids is None else self.eids.to(device))
+        out.short_hint = self.short_hint  # a property of the structure, not of where it lives
+        return out
 
     def astype(self, dtype):
         if self.indptr.dtype == dtype:
             return self
-        return CsrView(self.num_rows, self.num_cols, self.indptr.to(dtype), self.indices.to(dtype),
-                       None if self.eids is None else self.eids.to(dtype))
+        out = CsrView(self.num_rows, self.num_cols, self.indptr.to(dtype), self.indices.to(dtype),
+                      None if self.eids is None else self.eids.to(dtype))
+        out.short_hint = self.short_hint
+        return out
 
 
 # ----------------------------------------------------------------------------- broadcasting

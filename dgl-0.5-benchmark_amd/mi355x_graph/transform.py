@@ -131,6 +131,7 @@ def batch(graphs, ndata="__ALL__", edata="__ALL__"):
     node_off = np.concatenate([[0], np.cumsum(n_nodes[:-1], dtype=np.int64)]) if len(n_nodes) > 1 else np.zeros(1, np.int64)
     edge_off = torch.from_numpy(np.repeat(node_off, n_edges)).to(device=device, dtype=idtype)
     out = DGLGraph(GraphIndex(total, total, coo=(torch.cat(srcs) + edge_off, torch.cat(dsts) + edge_off)))
+    out._index.ephemeral = True  # a batch of small graphs lives for one step: see GraphIndex.ephemeral
     out._batch_num_nodes = torch.tensor(bn, dtype=torch.int64, device=device)
     out._batch_num_edges = torch.tensor(be, dtype=torch.int64, device=device)
     for frames, target in ((lambda g: g._src_frame, out.ndata), (lambda g: g._edge_frame, out.edata)):
