@@ -185,3 +185,26 @@ def test_skewed_graph_takes_a_two_part_plan(oracle):
     status = _lib.lib().mgx_spmm_csr(ctypes.byref(csc.c_struct()), ctypes.byref(plan.c_struct()), sparse.OP["copy_lhs"], sparse.REDUCE["max"],
                                      P(x), None, D, 0, D, None, None, None, None, P(out_m), None, None, P(ws), 2, None)
     assert status != 0 and b"rest" in _lib.lib().mgx_last_error()
+
+
+def test_one_step_structures_decide_without_reading_lengths_back():
+    """A sampled block / a batch lives for one step: its views carry the average row length (host-known) and _short_choice uses the
+    average rule alone -- no split tables, no host reads (ns-sage-dgl.py's epoch went 0.40 -> 0.51 s with an analysis per block)."""
+    n = 50000
+    gen = torch.Generator().manual_seed(0)
+    src, dst = torch.randint(0, n, (400000,), generator=gen), torch.randint(0, n, (400000,), generator=gen)
+    g = mg.graph((src, dst), num_nodes=n).int().to(DEV)
+    from mi355x_graph import sampling
+    blocks = sampling.MultiLayerNeighborSampler([10, 5]).sample_blocks(g, torch.arange(2000, device=DEV))
+    for b in blocks:
+        assert b._index.ephemeral
+        for view in (b._index.csc(), b._index.csr()):
+            assert isinstance(view.short_hint, float) and abs(view.short_hint - view.nnz / view.num_rows) < 1e-9
+            want = view.short_hint < 16.0
+            assert view.short_rows(16) == want and "split" not in str(list(view._short))    # D = 16: 16 lane groups, average below 16
+            assert view.short_rows(128) == (view.short_hint < 6.0)                         # D = 128: 2 lane groups, 3 edges each
+        x = torch.rand(b.number_of_src_nodes(), 16, device=DEV)
+        ops.gspmm(b, "copy_lhs", "mean", x, None)
+        assert last_kernel() == ("rowgroup32" if b._index.csc().short_hint < 16.0 else "rowwave32")
+    moved = blocks[0]._index.csc().to(torch.device("cpu")).to(DEV)
+    assert moved.short_hint == blocks[0]._index.csc().short_hint
