@@ -208,3 +208,52 @@ def test_one_step_structures_decide_without_reading_lengths_back():
         assert last_kernel() == ("rowgroup32" if b._index.csc().short_hint < 16.0 else "rowwave32")
     moved = blocks[0]._index.csc().to(torch.device("cpu")).to(DEV)
     assert moved.short_hint == blocks[0]._index.csc().short_hint
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_two_part_plans_fuzz_against_the_oracle(oracle, seed):
+    """Random skewed multigraphs, every width class, forced two-part plans at several limits (also where the policy would refuse them):
+    copy_u and copy_e, sum and mean, plain / accumulate / dst_scale -- each output element within 1e-4 of the sum of |terms|."""
+    from mi355x_graph import schedule
+    rng = np.random.default_rng(100 + seed)
+    n_src, n_dst = int(rng.integers(500, 6000)), int(rng.integers(500, 9000))
+    deg = np.minimum(rng.zipf(1.5 + 0.3 * rng.random(), n_dst), 1500).astype(np.int64)
+    deg[rng.integers(0, n_dst, n_dst // 5)] = 0
+    dst = np.repeat(np.arange(n_dst), deg)
+    src = rng.integers(0, n_src, dst.shape[0])
+    perm = rng.permutation(dst.shape[0])
+    src, dst = src[perm], dst[perm]
+    g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=torch.int32, device=DEV)
+    csc = g._index.csc()
+    ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
+    be = sparse.backend_for(csc.indptr)
+    for D in (4, 16, 32, 64, 100, 128):
+        limit = int(rng.choice([1, 5, 16, 32]))
+        split = schedule.split_short_items(csc, csc.plan(), any_share=True, limit=limit)
+        if split is None:          # no item that short
+            continue
+        plan = split[0]
+        csc._short = {nb: (plan if plan is not None and plan.rest is not None else True) for nb in (2, 4, 8, 16, 32, 64)}
+        X = rng.standard_normal((n_src, D)).astype(np.float32)
+        x = torch.from_numpy(X).to(DEV)
+        absX = np.abs(X)
+        for red in ("sum", "mean"):
+            out = ops.gspmm(g, "copy_lhs", red, x, None).cpu().numpy()
+            assert last_kernel() == "rowgroup32", (D, limit)
+            ref = oracle.spmm(ip, ix, ei, "copy_lhs", red, X, None)
+            bound = oracle.spmm(ip, ix, ei, "copy_lhs", red, absX, None)
+            assert bool((np.abs(out - ref) <= 1e-4 * bound + 1e-30).all()), (D, limit, red)
+        sc = (rng.random(n_dst).astype(np.float32) + 0.5)
+        base = rng.standard_normal((n_dst, D)).astype(np.float32)
+        acc = torch.from_numpy(base).to(DEV)
+        sparse.gspmm_raw(csc, "copy_lhs", "sum", x, None, dst_scale=torch.from_numpy(sc).to(DEV), accumulate_into=acc)
+        ref = base + oracle.spmm(ip, ix, ei, "copy_lhs", "sum", X, None) * sc[:, None]
+        bound = np.abs(base) + oracle.spmm(ip, ix, ei, "copy_lhs", "sum", absX, None) * sc[:, None]
+        assert bool((np.abs(acc.cpu().numpy() - ref) <= 1e-4 * bound + 1e-30).all()), (D, limit, "accumulate")
+        if D <= 32:
+            E = rng.standard_normal((src.shape[0], D)).astype(np.float32)
+            out = ops.gspmm(g, "copy_rhs", "sum", None, torch.from_numpy(E).to(DEV)).cpu().numpy()
+            ref = oracle.spmm(ip, ix, ei, "copy_rhs", "sum", None, E)
+            bound = oracle.spmm(ip, ix, ei, "copy_rhs", "sum", None, np.abs(E))
+            assert bool((np.abs(out - ref) <= 1e-4 * bound + 1e-30).all()), (D, limit, "copy_e")
+        csc._short = {}
