@@ -439,11 +439,26 @@ def main():
             sparse.PROFILE = []
             if world > 1:
                 g._comm.trace = []  # exposed exchange time per rank (dist._TimedWork): what the scaling model predicts, measured
+        # as timeit does: no cyclic garbage collection inside the timed loop (a full collection of this process' heap is an 80 ms host
+        # stall that landed in the last step of one leg, run after run: 17.5 ms steps, one of 97 ms)
+        import gc
+        gc.collect()
+        gc_was = gc.isenabled()
+        gc.disable()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step()
-        fence()
-        elapsed = time.perf_counter() - t0
+        marks = []
+        try:
+            for _ in range(steps):
+                loss = step()
+                marks.append(time.perf_counter())  # (step() ends with loss.item(): the device has finished the step)
+            fence()
+            elapsed = time.perf_counter() - t0
+        finally:
+            if gc_was:
+                gc.enable()
+        if os.environ.get("MGX_BENCH_STEP_TIMES") == "1" and rank == 0:
+            print("[bench] step times, ms: " + " ".join("%.2f" % ((b - a) * 1e3) for a, b in zip([t0] + marks[:-1], marks)),
+                  file=sys.stderr, flush=True)
         records = None
         if profile:
             records, sparse.PROFILE = sparse.PROFILE, None
@@ -606,9 +621,12 @@ def main():
             try:
                 lm = make_model()
                 lopt = torch.optim.Adam(lm.parameters(), lr=cfg["lr"])
+                built0 = ops.STATIC_AGGREGATIONS_BUILT[0]
                 lel, lloss, _ = timed(make_step(lm, lopt, None), psteps, min(args.warmup, 3), False)
                 line["epoch_ms_layer1_projected_first"] = round(lel / psteps * 1e3, 3)
                 line["layer1_projected_first"] = {"switch": "MGX_SAGE_L1_PROJECT_FIRST=1", "steps": psteps, "final_loss": lloss,
+                                                  "constant_input_aggregated": "%d time(s) in %d steps" % (
+                                                      ops.STATIC_AGGREGATIONS_BUILT[0] - built0, psteps + min(args.warmup, 3)),
                                                   "value_edges_per_s": agg_edges / (lel / psteps),
                                                   "aggregation_widths": [cfg["hidden"]] * (2 * cfg["num_layers"] - 1)}
                 del lm, lopt

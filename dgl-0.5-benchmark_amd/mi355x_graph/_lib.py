@@ -81,6 +81,7 @@ SIGNATURES = {
     "mgx_column_affine": (_i32, [_i64, _i64, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     "mgx_xty_workspace": (_i64, [_i64, _i64]),
     "mgx_xty": (_i32, [_i64, _i64, _i64, _fp, _i64, _fp, _i64, _fp, _i64, _vp, _vp]),
+    "mgx_rows_gemm": (_i32, [_i64, _i64, _i64, _fp, _i64, _fp, _i64, _i32, _fp, _fp, _i64, _fp, _i64, _vp]),
     "mgx_column_sum_workspace": (_i64, [_i64]),
     "mgx_column_sum": (_i32, [_i64, _i64, _fp, _fp, _vp, _vp]),
     "mgx_coo_to_csr_workspace": (_i64, [_i64, _i64, _i32]),
@@ -114,6 +115,9 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+ERR_UNSUPPORTED = 2  # MGX_ERR_UNSUPPORTED: the entry point has no kernel for these operands; the caller takes its fallback
 
 
 def check(status):

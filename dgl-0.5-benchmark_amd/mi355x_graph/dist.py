@@ -451,7 +451,8 @@ class DistSageMeanCatFn(torch.autograd.Function):
         ctx.plan, ctx.comm, ctx.cat, ctx.generation = plan, comm, cat, cat.generation
         ctx.save_for_backward(w_self, w_neigh)
         comm.mark("dense")
-        return torch.nn.functional.linear(cat.buf, torch.cat([w_self, w_neigh], dim=1), bias)
+        from . import ops
+        return ops._rows_linear(be, cat.buf, torch.cat([w_self, w_neigh], dim=1), bias)
 
     @staticmethod
     @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
@@ -467,9 +468,8 @@ class DistSageMeanCatFn(torch.autograd.Function):
         K = cat.K
         dh = None
         if need[3]:
-            dcat = dy @ torch.cat([w_self, w_neigh], dim=1)  # [n_own, 2K] = d[h | neigh]
+            dcat = ops._rows_dgrad(be, dy, torch.cat([w_self, w_neigh], dim=1), plan.inv_deg, K)  # [n_own, 2K] = d[h | neigh / deg]
             dn = dcat[:, K:]
-            dn.mul_(plan.inv_deg.view(-1, 1))  # d(sum / deg)
             back = torch.empty((plan.send_idx.shape[0], K), dtype=dy.dtype, device=dy.device)
             g_halo = torch.empty((plan.n_halo, K), dtype=dy.dtype, device=dy.device)
             comm.mark("halo-row gradients")

@@ -389,6 +389,15 @@ int64_t mgx_xty_workspace(int64_t M, int64_t K);
 int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldc,
                 void* workspace, void* stream);
 
+/* C[n, M] = A[n, K] x B (+ bias[M]) for A with millions of rows and small K, M -- the dense projections either side of an aggregation
+ * (SAGEConv's fc_self / fc_neigh on [h | mean_agg(h)], main_dgl_product_sage.py:23-24,64, and the input gradient d[h | neigh] = dY x W).
+ * B: [K, M] row-major with ldb, or -- b_transposed -- [M, K] (torch.nn.Linear's weight layout).  row_scale (may be NULL): C[r, m] is
+ * multiplied by row_scale[r] for the columns m >= scale_from (the 1 / deg of fn.mean's backward on the `neigh` half).  fp32 MFMA, fixed
+ * summation order.  K x M padded to 16 must fit a 64 KB stage and be one of the built shapes, else MGX_ERR_UNSUPPORTED (use a GEMM). */
+int32_t mgx_rows_gemm(int64_t n, int64_t K, int64_t M, const float* a, int64_t lda, const float* b, int64_t ldb, int32_t b_transposed,
+                      const float* bias /* [M] or NULL */, const float* row_scale /* [n] or NULL */, int64_t scale_from, float* c,
+                      int64_t ldc, void* stream);
+
 /* y = dropout_p(relu(x)) in one pass (inverted dropout: kept values scaled by 1/(1-p)); the activation between two
  * aggregations (main_dgl_product_sage.py:93-95).  n elements, n % 4 == 0, 16-byte aligned; mask: n/4 bytes, 4 bits per
  * float4 = (x > 0 AND kept), all that backward needs: dx = mask ? dy/(1-p) : 0.  Random bits are a counter-based function

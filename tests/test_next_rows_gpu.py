@@ -220,7 +220,9 @@ def test_plain_reference_modules_match_the_default_model(batch_norm):
     assert abs(losses[0] - losses[1]) < 1e-5 * abs(losses[1])
     for (name, p1), (_, p2) in zip(models[0].named_parameters(), models[1].named_parameters()):
         err, ref = float((p1.grad - p2.grad).abs().max()), float(p2.grad.abs().max())
-        assert err < 1e-3 * ref + 1e-7, (name, err, ref)  # two fp32 summation orders over 70 k rows (GEMM vs mgx_xty)
+        # fp32 summation orders differ in every dense product (library GEMM vs mgx_rows_gemm forward and input gradient, GEMM vs mgx_xty
+        # weight gradient over 70 k rows); both sides are within 1e-5 of the sum of |terms| of the fp64 product (tests/test_rows_gemm.py)
+        assert err < 2e-3 * ref + 1e-7, (name, err, ref)
 
 
 def test_fused_sage_layer_node_matches_the_composition(monkeypatch):
