@@ -432,6 +432,8 @@ def main():
         torch.cuda.synchronize()
 
     def timed(step, steps, warmup, profile):
+        import gc
+        gc.collect()  # before the warm-up: what it releases is back in the allocator's pool by the time the clock starts
         for _ in range(warmup):
             step()
         fence()
@@ -441,8 +443,6 @@ def main():
                 g._comm.trace = []  # exposed exchange time per rank (dist._TimedWork): what the scaling model predicts, measured
         # as timeit does: no cyclic garbage collection inside the timed loop (a full collection of this process' heap is an 80 ms host
         # stall that landed in the last step of one leg, run after run: 17.5 ms steps, one of 97 ms)
-        import gc
-        gc.collect()
         gc_was = gc.isenabled()
         gc.disable()
         t0 = time.perf_counter()

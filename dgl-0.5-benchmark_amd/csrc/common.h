@@ -52,6 +52,14 @@ void note_spmm_kernel(const char* name);  // mgx_last_spmm_kernel(): which kerne
 // Called after every kernel launch: reports launch-configuration errors without synchronising.
 #define MGX_CHECK_LAUNCH() MGX_CHECK_HIP(hipGetLastError())
 
+// counter-based random bits of relu+dropout (elementwise.hip, rowsgemm.hip): a function of (seed, element index) only
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 

@@ -10,13 +10,6 @@
 
 namespace mgx {
 
-__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
-}
-
 // Rows of c4 float4s; x rows are ldx4 float4s apart, y rows ldy4 (dense: c4 = n4, one row).  The mask and the random stream
 // are indexed by the DENSE element number, so a strided call draws the same mask as the dense one.
 __global__ __launch_bounds__(kBlock) void relu_dropout_fwd_kernel(int64_t n4, const v4f* __restrict__ x, v4f* __restrict__ y,

@@ -24,12 +24,23 @@ constexpr int kRgWaves = kRgBlock / kWave;  // MFMAs of a tile are ~3/4 of its m
 
 __device__ __forceinline__ int rows_gemm_col(int mt, int c) { return 64 * (mt / 4) + 4 * c + (mt % 4); }
 
+// relu + inverted dropout in the epilogue (ACT): the activation between two layers (main_dgl_product_sage.py:93-95) written straight
+// into its destination with the 4 mask bits per float4, exactly as mgx_relu_dropout_fwd_strided would from the stored GEMM result --
+// same random stream (splitmix64 of seed and DENSE float4 index), same arithmetic, so the same bits -- without writing and
+// re-reading the N x M pre-activation.
+struct RowsGemmAct {
+  uint8_t* mask;        // [n * M / 4]
+  uint32_t drop_below;  // keep when the 32 random bits are >= this
+  float scale;          // 1 / (1 - p)
+  uint64_t seed, offset;
+};
+
 // KS = k-steps of 4 (K_pad / 4; a multiple of 4 in the float4 form), MT = column tiles of 16 (a multiple of 4: groups of 64 columns)
-template <int KS, int MT, bool V4>
+template <int KS, int MT, bool V4, bool ACT>
 __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, int M, const float* __restrict__ A, int64_t lda,
                                                            const float* __restrict__ B, int64_t ldb, int b_transposed,
                                                            const float* __restrict__ bias, const float* __restrict__ row_scale,
-                                                           int scale_from, float* __restrict__ C, int64_t ldc) {
+                                                           int scale_from, float* __restrict__ C, int64_t ldc, RowsGemmAct act) {
   __shared__ float Bl[KS * MT * 64];
   const int lane = threadIdx.x & (kWave - 1);
   const int c = lane % 16, q = lane / 16;
@@ -129,7 +140,22 @@ __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, i
           v[t] = acc[4 * g + t][r] + bv[4 * g + t];
           if (row_scale && m0 + t >= scale_from) v[t] *= rs[r];
         }
-        if (row < n) {
+        if (ACT) {  // (the host checked: float4 stores possible, M % 4 == 0)
+          if (row < n && m0 + 3 < M) {
+            const uint64_t i = (uint64_t)row * (uint64_t)(M / 4) + (uint64_t)(m0 / 4);
+            const uint64_t q0 = splitmix64(act.seed ^ ((act.offset + i) * 2));
+            const uint64_t q1 = splitmix64(act.seed ^ ((act.offset + i) * 2 + 1));
+            const bool k0 = (uint32_t)q0 >= act.drop_below && v[0] > 0.f, k1 = (uint32_t)(q0 >> 32) >= act.drop_below && v[1] > 0.f;
+            const bool k2 = (uint32_t)q1 >= act.drop_below && v[2] > 0.f, k3 = (uint32_t)(q1 >> 32) >= act.drop_below && v[3] > 0.f;
+            v4f o;
+            o.x = k0 ? v[0] * act.scale : 0.f;
+            o.y = k1 ? v[1] * act.scale : 0.f;
+            o.z = k2 ? v[2] * act.scale : 0.f;
+            o.w = k3 ? v[3] * act.scale : 0.f;
+            *reinterpret_cast<v4f*>(C + row * ldc + m0) = o;
+            act.mask[i] = (uint8_t)((k0 ? 1 : 0) | (k1 ? 2 : 0) | (k2 ? 4 : 0) | (k3 ? 8 : 0));
+          }
+        } else if (row < n) {
           if (cvec && m0 + 3 < M) {
             v4f o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
             *reinterpret_cast<v4f*>(C + row * ldc + m0) = o;
@@ -146,13 +172,41 @@ __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, i
 
 template <int KS, int MT, bool V4>
 static void launch_rows_gemm(int64_t n, int K, int M, const float* A, int64_t lda, const float* B, int64_t ldb, int bt, const float* bias,
-                             const float* rs, int scale_from, float* C, int64_t ldc, hipStream_t s) {
+                             const float* rs, int scale_from, float* C, int64_t ldc, const RowsGemmAct* act, hipStream_t s) {
   // waves: one per 16 rows up to 6 per SIMD of the chip (the stage of B is paid once per workgroup)
   int64_t blocks = (n + 16 * kRgWaves - 1) / (16 * kRgWaves);
   const int64_t cap = 256 * 3;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL((rows_gemm_kernel<KS, MT, V4>), dim3((unsigned)blocks), dim3(kRgBlock), 0, s, n, K, M, A, lda, B, ldb, bt, bias, rs,
-                     scale_from, C, ldc);
+  if (act) {
+    hipLaunchKernelGGL((rows_gemm_kernel<KS, MT, V4, true>), dim3((unsigned)blocks), dim3(kRgBlock), 0, s, n, K, M, A, lda, B, ldb, bt, bias,
+                       rs, scale_from, C, ldc, *act);
+  } else {
+    hipLaunchKernelGGL((rows_gemm_kernel<KS, MT, V4, false>), dim3((unsigned)blocks), dim3(kRgBlock), 0, s, n, K, M, A, lda, B, ldb, bt, bias,
+                       rs, scale_from, C, ldc, RowsGemmAct{});
+  }
+}
+
+// shape -> kernel; false when none is built for it
+static bool rows_gemm_dispatch(bool dry, int64_t n, int64_t K, int64_t M, const float* a, int64_t lda, const float* b, int64_t ldb, int bt,
+                               const float* bias, const float* rs, int64_t scale_from, float* c, int64_t ldc, const RowsGemmAct* act,
+                               hipStream_t s) {
+  const bool v4 = K % 4 == 0 && lda % 4 == 0 && (dry || (uintptr_t)a % 16 == 0);
+  const int mt = (int)((M + 63) / 64) * 4;  // column tiles in groups of four (64 columns)
+  const int ks = v4 ? (int)((K + 15) / 16) * 4 : (int)((K + 3) / 4);
+  if (ks * mt * 64 > kRowsGemmLdsFloats) return false;
+  bool ok = false;
+#define MGX_RG(KS_, MT_, V4_)                                                                                                             \
+  if (!ok && ks == KS_ && mt == MT_ && v4 == V4_) {                                                                                       \
+    if (!dry) launch_rows_gemm<KS_, MT_, V4_>(n, (int)K, (int)M, a, lda, b, ldb, bt, bias, rs, (int)scale_from, c, ldc, act, s);          \
+    ok = true;                                                                                                                            \
+  }
+  // float4 form: K = 32 .. 208, M <= 64 / 128 -- the SAGE layers of the products model and of 64-wide models
+  MGX_RG(8, 4, true) MGX_RG(8, 8, true) MGX_RG(12, 4, true) MGX_RG(12, 8, true) MGX_RG(16, 4, true) MGX_RG(16, 8, true)
+  MGX_RG(32, 4, true) MGX_RG(32, 8, true) MGX_RG(52, 4, true)
+  // dword form: K = 37 .. 48 (the 47-class output gradient of products, 41 of reddit, 40 of arxiv)
+  MGX_RG(12, 8, false) MGX_RG(12, 4, false) MGX_RG(11, 8, false) MGX_RG(11, 4, false) MGX_RG(10, 8, false) MGX_RG(10, 4, false)
+#undef MGX_RG
+  return ok;
 }
 
 }  // namespace mgx
@@ -167,24 +221,36 @@ extern "C" int32_t mgx_rows_gemm(int64_t n, int64_t K, int64_t M, const float* a
   MGX_CHECK_ARG(a && b && c, "mgx_rows_gemm: NULL pointer");
   MGX_CHECK_ARG(lda >= K && ldc >= M && ldb >= (b_transposed ? K : M), "mgx_rows_gemm: leading dimensions smaller than the operands");
   MGX_CHECK_ARG(scale_from >= 0 && scale_from <= M, "mgx_rows_gemm: scale_from outside [0, M]");
-  const bool v4 = K % 4 == 0 && lda % 4 == 0 && (uintptr_t)a % 16 == 0;
-  const int mt = (int)((M + 63) / 64) * 4;  // column tiles in groups of four (64 columns)
-  const int ks = v4 ? (int)((K + 15) / 16) * 4 : (int)((K + 3) / 4);
-  if (ks * mt * 64 > kRowsGemmLdsFloats) MGX_UNSUPPORTED("mgx_rows_gemm: B of %lld x %lld does not fit the 64 KB stage", (long long)K, (long long)M);
-  hipStream_t s = (hipStream_t)stream;
-  bool ok = false;
-#define MGX_RG(KS_, MT_, V4_)                                                                                                             \
-  if (!ok && ks == KS_ && mt == MT_ && v4 == V4_) {                                                                                       \
-    launch_rows_gemm<KS_, MT_, V4_>(n, (int)K, (int)M, a, lda, b, ldb, b_transposed, bias, row_scale, (int)scale_from, c, ldc, s);        \
-    ok = true;                                                                                                                            \
-  }
-  // float4 form: K = 32 .. 208, M <= 64 / 128 -- the SAGE layers of the products model and of 64-wide models
-  MGX_RG(8, 4, true) MGX_RG(8, 8, true) MGX_RG(12, 4, true) MGX_RG(12, 8, true) MGX_RG(16, 4, true) MGX_RG(16, 8, true)
-  MGX_RG(32, 4, true) MGX_RG(32, 8, true) MGX_RG(52, 4, true)
-  // dword form: K = 37 .. 48 (the 47-class output gradient of products, 41 of reddit, 40 of arxiv)
-  MGX_RG(12, 8, false) MGX_RG(12, 4, false) MGX_RG(11, 8, false) MGX_RG(11, 4, false) MGX_RG(10, 8, false) MGX_RG(10, 4, false)
-#undef MGX_RG
-  if (!ok) MGX_UNSUPPORTED("mgx_rows_gemm: no kernel for K = %lld, M = %lld (%s loads)", (long long)K, (long long)M, v4 ? "16-byte" : "4-byte");
+  if (!rows_gemm_dispatch(false, n, K, M, a, lda, b, ldb, b_transposed, bias, row_scale, scale_from, c, ldc, nullptr, (hipStream_t)stream))
+    MGX_UNSUPPORTED("mgx_rows_gemm: no kernel for K = %lld, M = %lld", (long long)K, (long long)M);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_rows_gemm_supported(int64_t K, int64_t M, int64_t lda) {
+  return mgx::rows_gemm_dispatch(true, 0, K, M, nullptr, lda, nullptr, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr) ? 1 : 0;
+}
+
+extern "C" int32_t mgx_rows_gemm_relu_dropout(int64_t n, int64_t K, int64_t M, const float* a, int64_t lda, const float* b, int64_t ldb,
+                                              int32_t b_transposed, const float* bias, float p, uint64_t seed, uint64_t offset, float* y,
+                                              int64_t ldy, uint8_t* mask, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(n >= 0 && K >= 1 && M >= 1 && M % 4 == 0, "mgx_rows_gemm_relu_dropout: bad sizes (M must be a multiple of 4)");
+  MGX_CHECK_ARG(p >= 0.f && p < 1.f, "mgx_rows_gemm_relu_dropout: p must be in [0, 1)");
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(a && b && y && mask, "mgx_rows_gemm_relu_dropout: NULL pointer");
+  MGX_CHECK_ARG(lda >= K && ldy >= M && ldy % 4 == 0 && (uintptr_t)y % 16 == 0 && ldb >= (b_transposed ? K : M),
+                "mgx_rows_gemm_relu_dropout: leading dimensions / alignment (y: 16 bytes, ldy % 4 == 0)");
+  const double thr = (double)p * 4294967296.0;
+  RowsGemmAct act;
+  act.mask = mask;
+  act.drop_below = thr >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)thr;
+  act.scale = 1.f / (1.f - p);
+  act.seed = seed;
+  act.offset = offset;
+  if (!rows_gemm_dispatch(false, n, K, M, a, lda, b, ldb, b_transposed, bias, nullptr, 0, y, ldy, &act, (hipStream_t)stream))
+    MGX_UNSUPPORTED("mgx_rows_gemm_relu_dropout: no kernel for K = %lld, M = %lld", (long long)K, (long long)M);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

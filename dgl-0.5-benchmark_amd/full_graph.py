@@ -130,6 +130,14 @@ class GraphSAGE(nn.Module):
                 self._input_cat = held = (weakref.ref(g), tuple(x.shape), c) if c is not None else None
             cat = None if held is None or not torch.is_grad_enabled() else held[2]
         for i, layer in enumerate(self.layers[:-1]):
+            if not self.plain and not len(self.bns) and self.training and cat is not None and layer.fc_self.bias is None:
+                # layer + relu + dropout as one node: the GEMM's epilogue applies the activation and writes the next layer's left half
+                nxt = ops.cat_buffer_for(g, x, layer.fc_self.weight.shape[0])
+                h = ops.sage_mean_layer_act(g, x, layer.fc_self.weight, layer.fc_neigh.weight, layer.fc_neigh.bias, cat, self.dropout.p,
+                                            None if nxt is None else nxt.left)
+                if h is not None:
+                    x, cat = h, (nxt if nxt is not None and nxt.holds(h) else None)
+                    continue
             x = layer(g, x, cat=cat) if not self.plain else layer(g, x)
             if len(self.bns):
                 x = self.bns[i](x)

@@ -769,7 +769,7 @@ class SageMeanCatFn(torch.autograd.Function):
     backward aggregation reads the right half of d[h | neigh] and accumulates into its left half."""
 
     @staticmethod
-    def forward(ctx, gidx, cat, h, w_self, w_neigh, bias):
+    def forward(ctx, gidx, cat, h, w_self, w_neigh, bias, act=None):
         csc = gidx.csc()
         be = sparse.backend_for(h)
         if not cat.holds(h):
@@ -783,13 +783,33 @@ class SageMeanCatFn(torch.autograd.Function):
         cat.generation += 1
         be.spmm_copy_u_strided(csc, "mean", cat.left, cat.right)
         ctx.gidx, ctx.cat, ctx.generation = gidx, cat, cat.generation
+        if act is not None:
+            # relu + dropout in the GEMM's epilogue (mgx_rows_gemm_relu_dropout): the activation lands in the next layer's buffer and
+            # the N x out pre-activation is never stored.  Same position in the random stream as ops.relu_dropout would take.
+            p, into = act
+            seed = torch.initial_seed() & (2 ** 64 - 1)
+            offset = (ReluDropout._calls * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
+            ReluDropout._calls += 1
+            y, mask = be.rows_gemm_relu_dropout(cat.buf, torch.cat([w_self, w_neigh], dim=1), True, bias, float(p), seed, offset,
+                                                out=None if into is None else into.t)
+            ctx.save_for_backward(w_self, w_neigh, mask)
+            ctx.p = float(p)
+            return y
         ctx.save_for_backward(w_self, w_neigh)
+        ctx.p = None
         return _rows_linear(be, cat.buf, torch.cat([w_self, w_neigh], dim=1), bias)
 
     @staticmethod
     @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy):
-        w_self, w_neigh = ctx.saved_tensors
+        if ctx.p is not None:
+            w_self, w_neigh, mask = ctx.saved_tensors
+            be = sparse.backend_for(dy)
+            if not dy.is_contiguous() and not be._row_strided(dy):
+                dy = dy.contiguous()
+            dy = be.relu_dropout_bwd(dy, mask, ctx.p)  # the gradient of the pre-activation, as ReluDropout.backward forms it
+        else:
+            w_self, w_neigh = ctx.saved_tensors
         cat = ctx.cat
         if cat.generation != ctx.generation:
             raise DGLError("SAGEConv: a later forward pass overwrote the [h | neigh] buffer this backward pass needs "
@@ -818,7 +838,7 @@ class SageMeanCatFn(torch.autograd.Function):
             dw = _weight_grad(dy, cat.buf)                        # [out, 2K]
             dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
         db = be.column_sum(dy) if need[5] else None
-        return None, None, dh, dws, dwn, db
+        return None, None, dh, dws, dwn, db, None
 
 
 _ROW_BITS = {}  # (rows.data_ptr(), len, N) -> (rows, bitmap): the loss rows of a training run are one tensor, reused every step
@@ -1036,6 +1056,28 @@ def sage_mean_layer(g, h, w_self, w_neigh, bias=None, cat=None):
     if cat is not None and _cat_eligible(g, h, cat):
         return SageMeanCatFn.apply(g._index, cat, h, w_self, w_neigh, bias)
     return SageMeanLayerFn.apply(g._index, h, w_self, w_neigh, bias)
+
+
+def sage_mean_layer_act(g, h, w_self, w_neigh, bias, cat, p, out):
+    """dropout(relu(SAGEConv(g, h)), p) as ONE node whose GEMM applies the activation in its epilogue and writes `out` (the left half of
+    the next layer's CatBuffer, or None for a new matrix): bit for bit ops.relu_dropout(ops.sage_mean_layer(...), out=out), one pass
+    over the N x out pre-activation less each way.  None when that form does not apply (the caller composes the two)."""
+    if (os.environ.get("MGX_SAGE_FUSED_ACT", "1") != "1" or not _ROWS_GEMM or type(g) is not DGLGraph or cat is None or capture_path()
+            or not (0.0 < p < 1.0) or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda or h.device.type not in sparse._BACKENDS
+            or not torch.is_grad_enabled() or g.is_block or g.number_of_src_nodes() != g.number_of_dst_nodes()
+            or h.shape[0] != g.number_of_src_nodes() or h.shape[0] < _ROWS_GEMM_MIN or g.idtype != torch.int32
+            or _torch_ops() is not None or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1" or not _cat_eligible(g, h, cat)
+            or (bias is not None and w_self.shape[0] > sparse.backend_for(h).COLUMN_SUM_MAX) or w_self.shape[0] % 4
+            or not sparse.backend_for(h).rows_gemm_supported(2 * cat.K, w_self.shape[0], cat.buf.stride(0))
+            or (out is not None and (out.shape != (h.shape[0], w_self.shape[0]) or out.stride(1) != 1 or out.stride(0) % 4
+                                     or out.data_ptr() % 16 or out.requires_grad))):
+        return None
+    K, D = w_self.shape
+    if os.environ.get("MGX_SAGE_PROJECT_FIRST", "1") == "1" and K % 4 == 0 and K <= 128 and 2 * max(K, 16) * 1.1 <= (2 if h.requires_grad else 1) * D:
+        return None  # sage_project_first's rule: this layer aggregates fewer columns projected first (reddit: 602 -> 16)
+    if os.environ.get("MGX_SAGE_L1_PROJECT_FIRST", "0") == "1" and not h.requires_grad and K < D:
+        return None  # the opt-in layer-1 form (sage_static_input_project) takes this layer
+    return SageMeanCatFn.apply(g._index, cat, h, w_self, w_neigh, bias, (float(p), None if out is None else _Into(out)))
 
 
 def _cat_eligible(g, h, cat):

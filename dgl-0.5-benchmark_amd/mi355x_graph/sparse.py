@@ -876,6 +876,29 @@ class HipBackend(object):
         _lib.check(st)
         return out
 
+    def rows_gemm_supported(self, K, M, lda):
+        return bool(_lib.lib().mgx_rows_gemm_supported(int(K), int(M), int(lda)))
+
+    def rows_gemm_relu_dropout(self, a2d, b2d, b_transposed, bias, p, seed, offset, out=None):
+        """dropout(relu(a2d x B + bias), p) written into `out` (a row-strided [n, M] view, or a new matrix) + the mask of
+        relu_dropout_fwd -- bit for bit what rows_gemm followed by relu_dropout_fwd(seed, offset) gives, without storing the product.
+        None when mgx_rows_gemm has no kernel for the shape."""
+        dev = self._check_dev(a2d, b2d, bias, out)
+        n, K = a2d.shape
+        M = b2d.shape[0] if b_transposed else b2d.shape[1]
+        if (a2d.stride(1) != 1 or b2d.stride(1) != 1 or (b2d.shape[1] if b_transposed else b2d.shape[0]) != K or M % 4
+                or a2d.dtype != torch.float32 or b2d.dtype != torch.float32 or not self.rows_gemm_supported(K, M, a2d.stride(0))):
+            return None
+        y = out if out is not None else torch.empty((n, M), dtype=torch.float32, device=dev)
+        if not self._row_strided(y) or y.shape != (n, M) or y.data_ptr() % 16:
+            return None
+        mask = torch.empty(n * M // 4, dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_rows_gemm_relu_dropout(n, K, M, _ptr(a2d), a2d.stride(0), _ptr(b2d), b2d.stride(0),
+                                                             1 if b_transposed else 0, _ptr(bias), ctypes.c_float(p), ctypes.c_uint64(seed),
+                                                             ctypes.c_uint64(offset), _ptr(y), y.stride(0), _ptr(mask), _stream(dev)))
+        return y, mask
+
     def column_sum(self, x2d):
         dev = self._check_dev(x2d)
         n, C = x2d.shape

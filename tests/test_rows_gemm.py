@@ -92,3 +92,52 @@ def test_sage_layer_takes_it_and_keeps_its_gradients():
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
     for a, b in zip(g1, g0):
         assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7
+
+
+def test_layer_with_the_activation_in_the_epilogue_is_bitwise_the_composition():
+    """ops.sage_mean_layer_act == ops.relu_dropout(ops.sage_mean_layer(...), out=...): same random stream position, same arithmetic ->
+    the same bits in the activation, the loss and every gradient of the products-shaped model (dropout 0.5, three layers)."""
+    import full_graph
+    from mi355x_graph import ops
+    n = 70000
+    gen = torch.Generator().manual_seed(7)
+    src, dst = torch.randint(0, n, (6 * n,), generator=gen), torch.randint(0, n, (6 * n,), generator=gen)
+    g = mg.graph((src, dst), num_nodes=n).int().to(DEV)
+    x = torch.rand(n, 100, generator=gen).to(DEV)
+    y = torch.randint(0, 47, (n,), generator=gen).to(DEV)
+    rows = torch.arange(0, n, 7, device=DEV)
+    results = []
+    for fused in ("1", "0"):
+        os.environ["MGX_SAGE_FUSED_ACT"] = fused
+        try:
+            torch.manual_seed(11)
+            ops.ReluDropout._calls = 0
+            model = full_graph.GraphSAGE(100, 64, 47, 3, 0.5, False, True).to(DEV)
+            model.train()
+            out = model(g, x, rows=rows)
+            loss = ops.nll_sum(out, y[rows]) / rows.shape[0]
+            loss.backward()
+            results.append((out.detach().clone(), float(loss), [p.grad.clone() for p in model.parameters()], ops.ReluDropout._calls))
+        finally:
+            os.environ.pop("MGX_SAGE_FUSED_ACT", None)
+    (o1, l1, g1, c1), (o0, l0, g0, c0) = results
+    assert c1 == c0 == 2                                   # two activations, two positions in the random stream either way
+    assert torch.equal(o1, o0) and l1 == l0
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+
+
+def test_rows_gemm_relu_dropout_equals_gemm_then_relu_dropout():
+    be = sparse.backend_for(torch.zeros(1, device=DEV))
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    n, K, M = 66001, 128, 64
+    a = torch.randn(n, K, device=DEV, generator=gen)
+    w = torch.randn(M, K, device=DEV, generator=gen)
+    b = torch.randn(M, device=DEV, generator=gen)
+    wide = torch.zeros(n, 2 * M, device=DEV)
+    y, mask = be.rows_gemm_relu_dropout(a, w, True, b, 0.3, 12345, 777, out=wide[:, :M])
+    z = be.rows_gemm(a, w, b_transposed=True, bias=b)
+    y2, mask2 = be.relu_dropout_fwd(z, 0.3, 12345, 777)
+    assert torch.equal(y, y2) and torch.equal(mask, mask2) and float(wide[:, M:].abs().sum()) == 0.0
+    kept = float((mask2 > 0).float().mean())
+    assert 0.2 < kept < 0.9
