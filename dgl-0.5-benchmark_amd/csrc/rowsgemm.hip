@@ -40,7 +40,8 @@ template <int KS, int MT, bool V4, bool ACT>
 __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, int M, const float* __restrict__ A, int64_t lda,
                                                            const float* __restrict__ B, int64_t ldb, int b_transposed,
                                                            const float* __restrict__ bias, const float* __restrict__ row_scale,
-                                                           int scale_from, float* __restrict__ C, int64_t ldc, RowsGemmAct act) {
+                                                           int scale_from, float* __restrict__ C, int64_t ldc, RowsGemmAct act,
+                                                           float* __restrict__ C2, int64_t ldc2, int split_col) {
   __shared__ float Bl[KS * MT * 64];
   const int lane = threadIdx.x & (kWave - 1);
   const int c = lane % 16, q = lane / 16;
@@ -67,7 +68,10 @@ __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, i
   float bv[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) bv[mt] = (bias && rows_gemm_col(mt, c) < M) ? bias[rows_gemm_col(mt, c)] : 0.f;
-  const bool cvec = ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) && M % 4 == 0;  // float4 stores
+  // float4 stores; columns from split_col on (a multiple of 4) go to a matrix of their own (C2): the two halves of d[h | neigh] are
+  // then separate compact matrices -- the reversed aggregation gathers from one and accumulates into the other (rows that share
+  // 512-byte blocks with the rows being gathered cost it 2.60 against 2.38 ms)
+  const bool cvec = ldc % 4 == 0 && ((uintptr_t)C % 16 == 0) && M % 4 == 0 && (!C2 || (ldc2 % 4 == 0 && (uintptr_t)C2 % 16 == 0));
 
   const int64_t gw = (int64_t)blockIdx.x * kRgWaves + threadIdx.x / kWave;
   const int64_t stride = (int64_t)gridDim.x * kRgWaves * 16;
@@ -156,13 +160,14 @@ __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, i
             act.mask[i] = (uint8_t)((k0 ? 1 : 0) | (k1 ? 2 : 0) | (k2 ? 4 : 0) | (k3 ? 8 : 0));
           }
         } else if (row < n) {
+          float* dst = (C2 && m0 >= split_col) ? C2 + row * ldc2 + (m0 - split_col) : C + row * ldc + m0;
           if (cvec && m0 + 3 < M) {
             v4f o; o.x = v[0]; o.y = v[1]; o.z = v[2]; o.w = v[3];
-            *reinterpret_cast<v4f*>(C + row * ldc + m0) = o;
+            *reinterpret_cast<v4f*>(dst) = o;
           } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              if (m0 + t < M) C[row * ldc + m0 + t] = v[t];
+              if (m0 + t < M) dst[t] = v[t];
           }
         }
       }
@@ -172,24 +177,25 @@ __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, i
 
 template <int KS, int MT, bool V4>
 static void launch_rows_gemm(int64_t n, int K, int M, const float* A, int64_t lda, const float* B, int64_t ldb, int bt, const float* bias,
-                             const float* rs, int scale_from, float* C, int64_t ldc, const RowsGemmAct* act, hipStream_t s) {
+                             const float* rs, int scale_from, float* C, int64_t ldc, const RowsGemmAct* act, float* C2, int64_t ldc2,
+                             int split_col, hipStream_t s) {
   // waves: one per 16 rows up to 6 per SIMD of the chip (the stage of B is paid once per workgroup)
   int64_t blocks = (n + 16 * kRgWaves - 1) / (16 * kRgWaves);
   const int64_t cap = 256 * 3;
   if (blocks > cap) blocks = cap;
   if (act) {
     hipLaunchKernelGGL((rows_gemm_kernel<KS, MT, V4, true>), dim3((unsigned)blocks), dim3(kRgBlock), 0, s, n, K, M, A, lda, B, ldb, bt, bias,
-                       rs, scale_from, C, ldc, *act);
+                       rs, scale_from, C, ldc, *act, C2, ldc2, split_col);
   } else {
     hipLaunchKernelGGL((rows_gemm_kernel<KS, MT, V4, false>), dim3((unsigned)blocks), dim3(kRgBlock), 0, s, n, K, M, A, lda, B, ldb, bt, bias,
-                       rs, scale_from, C, ldc, RowsGemmAct{});
+                       rs, scale_from, C, ldc, RowsGemmAct{}, C2, ldc2, split_col);
   }
 }
 
 // shape -> kernel; false when none is built for it
 static bool rows_gemm_dispatch(bool dry, int64_t n, int64_t K, int64_t M, const float* a, int64_t lda, const float* b, int64_t ldb, int bt,
                                const float* bias, const float* rs, int64_t scale_from, float* c, int64_t ldc, const RowsGemmAct* act,
-                               hipStream_t s) {
+                               hipStream_t s, float* c2 = nullptr, int64_t ldc2 = 0, int64_t split_col = 0) {
   const bool v4 = K % 4 == 0 && lda % 4 == 0 && (dry || (uintptr_t)a % 16 == 0);
   const int mt = (int)((M + 63) / 64) * 4;  // column tiles in groups of four (64 columns)
   const int ks = v4 ? (int)((K + 15) / 16) * 4 : (int)((K + 3) / 4);
@@ -197,7 +203,8 @@ static bool rows_gemm_dispatch(bool dry, int64_t n, int64_t K, int64_t M, const 
   bool ok = false;
 #define MGX_RG(KS_, MT_, V4_)                                                                                                             \
   if (!ok && ks == KS_ && mt == MT_ && v4 == V4_) {                                                                                       \
-    if (!dry) launch_rows_gemm<KS_, MT_, V4_>(n, (int)K, (int)M, a, lda, b, ldb, bt, bias, rs, (int)scale_from, c, ldc, act, s);          \
+    if (!dry) launch_rows_gemm<KS_, MT_, V4_>(n, (int)K, (int)M, a, lda, b, ldb, bt, bias, rs, (int)scale_from, c, ldc, act, c2, ldc2,     \
+                                              (int)split_col, s);                                                                         \
     ok = true;                                                                                                                            \
   }
   // float4 form: K = 32 .. 208, M <= 64 / 128 -- the SAGE layers of the products model and of 64-wide models
@@ -213,15 +220,18 @@ static bool rows_gemm_dispatch(bool dry, int64_t n, int64_t K, int64_t M, const 
 
 extern "C" int32_t mgx_rows_gemm(int64_t n, int64_t K, int64_t M, const float* a, int64_t lda, const float* b, int64_t ldb,
                                  int32_t b_transposed, const float* bias, const float* row_scale, int64_t scale_from, float* c,
-                                 int64_t ldc, void* stream) {
+                                 int64_t ldc, float* c2, int64_t ldc2, int64_t split_col, void* stream) {
   using namespace mgx;
   MGX_ENTER();
   MGX_CHECK_ARG(n >= 0 && K >= 1 && M >= 1, "mgx_rows_gemm: bad sizes");
   if (n == 0) return MGX_OK;
   MGX_CHECK_ARG(a && b && c, "mgx_rows_gemm: NULL pointer");
-  MGX_CHECK_ARG(lda >= K && ldc >= M && ldb >= (b_transposed ? K : M), "mgx_rows_gemm: leading dimensions smaller than the operands");
+  MGX_CHECK_ARG(lda >= K && ldc >= (c2 ? split_col : M) && ldb >= (b_transposed ? K : M), "mgx_rows_gemm: leading dimensions smaller than the operands");
+  MGX_CHECK_ARG(!c2 || (split_col > 0 && split_col < M && split_col % 4 == 0 && ldc2 >= M - split_col),
+                "mgx_rows_gemm: a second output needs 0 < split_col < M, split_col % 4 == 0, ldc2 >= M - split_col");
   MGX_CHECK_ARG(scale_from >= 0 && scale_from <= M, "mgx_rows_gemm: scale_from outside [0, M]");
-  if (!rows_gemm_dispatch(false, n, K, M, a, lda, b, ldb, b_transposed, bias, row_scale, scale_from, c, ldc, nullptr, (hipStream_t)stream))
+  if (!rows_gemm_dispatch(false, n, K, M, a, lda, b, ldb, b_transposed, bias, row_scale, scale_from, c, ldc, nullptr, (hipStream_t)stream, c2, ldc2,
+                          split_col))
     MGX_UNSUPPORTED("mgx_rows_gemm: no kernel for K = %lld, M = %lld", (long long)K, (long long)M);
   MGX_CHECK_LAUNCH();
   return MGX_OK;

@@ -468,8 +468,7 @@ class DistSageMeanCatFn(torch.autograd.Function):
         K = cat.K
         dh = None
         if need[3]:
-            dcat = ops._rows_dgrad(be, dy, torch.cat([w_self, w_neigh], dim=1), plan.inv_deg, K)  # [n_own, 2K] = d[h | neigh / deg]
-            dn = dcat[:, K:]
+            dh_own, dn = ops._rows_dgrad(be, dy, torch.cat([w_self, w_neigh], dim=1), plan.inv_deg, K)  # d h, d neigh / deg: [n_own, K] each
             back = torch.empty((plan.send_idx.shape[0], K), dtype=dy.dtype, device=dy.device)
             g_halo = torch.empty((plan.n_halo, K), dtype=dy.dtype, device=dy.device)
             comm.mark("halo-row gradients")
@@ -477,7 +476,7 @@ class DistSageMeanCatFn(torch.autograd.Function):
                 be.spmm_copy_u_strided(plan.halo.csr(), "sum", dn, g_halo)
             work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
             comm.mark("owned-row reversed aggregation")
-            be.spmm_copy_u_strided(plan.loc.csr(), "sum", dn, dcat[:, :K], accumulate=True)
+            be.spmm_copy_u_strided(plan.loc.csr(), "sum", dn, dh_own, accumulate=True)
         # the parameter gradients need nothing from the peers: formed while the halo-row gradients travel (the scaling model,
         # profiles/r04_scale_model.txt, has the exchange at 2x the reversed aggregation it used to hide behind at P = 8)
         comm.mark("dense (inside the exchange window)")
@@ -490,8 +489,8 @@ class DistSageMeanCatFn(torch.autograd.Function):
             work.wait()
             comm.mark("return-add")
             if back.shape[0]:  # row v += the returned rows whose owner is v: copy_u over (owned row -> position in `back`)
-                be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dcat[:, :K], accumulate=True)
-            dh = dcat[:, :K]
+                be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dh_own, accumulate=True)
+            dh = dh_own
         comm.mark("dense")
         return None, None, None, dh, dws, dwn, db, None
 

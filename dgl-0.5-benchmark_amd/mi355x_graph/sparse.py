@@ -857,24 +857,30 @@ class HipBackend(object):
                                              max(b2d.stride(0), K), _ptr(o_t), out.stride(0), _ptr(ws), _stream(dev)))
         return out
 
-    def rows_gemm(self, a2d, b2d, b_transposed=False, bias=None, row_scale=None, scale_from=0, out=None):
+    def rows_gemm(self, a2d, b2d, b_transposed=False, bias=None, row_scale=None, scale_from=0, out=None, split_col=0):
         """a2d [n, K] (row-strided view allowed) x B -> [n, M]; B = b2d [K, M], or [M, K] when b_transposed (nn.Linear's layout);
-        + bias; columns >= scale_from times row_scale[r].  None when mgx_rows_gemm has no kernel for the shape (use a GEMM)."""
+        + bias; columns >= scale_from times row_scale[r].  split_col > 0 (a multiple of 4): TWO compact outputs, the columns before
+        and from split_col on, returned as a pair.  None when mgx_rows_gemm has no kernel for the shape (use a GEMM)."""
         dev = self._check_dev(a2d, b2d, bias, row_scale, out)
         n, K = a2d.shape
         M = b2d.shape[0] if b_transposed else b2d.shape[1]
         if (a2d.stride(1) != 1 or b2d.stride(1) != 1 or (b2d.shape[1] if b_transposed else b2d.shape[0]) != K
                 or a2d.dtype != torch.float32 or b2d.dtype != torch.float32):
             return None
-        if out is None:
+        out2 = None
+        if split_col:
+            out = torch.empty((n, split_col), dtype=torch.float32, device=dev)
+            out2 = torch.empty((n, M - split_col), dtype=torch.float32, device=dev)
+        elif out is None:
             out = torch.empty((n, M), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             st = _lib.lib().mgx_rows_gemm(n, K, M, _ptr(a2d), a2d.stride(0), _ptr(b2d), b2d.stride(0), 1 if b_transposed else 0,
-                                          _ptr(bias), _ptr(row_scale), int(scale_from), _ptr(out), out.stride(0), _stream(dev))
+                                          _ptr(bias), _ptr(row_scale), int(scale_from), _ptr(out), out.stride(0), _ptr(out2),
+                                          0 if out2 is None else out2.stride(0), int(split_col), _stream(dev))
         if st == _lib.ERR_UNSUPPORTED:
             return None
         _lib.check(st)
-        return out
+        return out if out2 is None else (out, out2)
 
     def rows_gemm_supported(self, K, M, lda):
         return bool(_lib.lib().mgx_rows_gemm_supported(int(K), int(M), int(lda)))

@@ -396,7 +396,8 @@ int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int64_t lda, co
  * summation order.  K x M padded to 16 must fit a 64 KB stage and be one of the built shapes, else MGX_ERR_UNSUPPORTED (use a GEMM). */
 int32_t mgx_rows_gemm(int64_t n, int64_t K, int64_t M, const float* a, int64_t lda, const float* b, int64_t ldb, int32_t b_transposed,
                       const float* bias /* [M] or NULL */, const float* row_scale /* [n] or NULL */, int64_t scale_from, float* c,
-                      int64_t ldc, void* stream);
+                      int64_t ldc, float* c2 /* NULL, or the matrix that receives the columns split_col .. M - 1 (as its columns 0 ..) */,
+                      int64_t ldc2, int64_t split_col /* a multiple of 4 */, void* stream);
 /* 1 when mgx_rows_gemm has a kernel for these sizes (lda: A's row stride in floats), else 0. */
 int32_t mgx_rows_gemm_supported(int64_t K, int64_t M, int64_t lda);
 /* The same product followed by relu and inverted dropout (main_dgl_product_sage.py:93-95) in the epilogue: y[r, :] (row stride ldy) and the

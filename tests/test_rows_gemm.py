@@ -52,6 +52,10 @@ def test_rows_gemm_matches_fp64(K, M, bt, lda_pad, n):
         ref, bound = reference(a, b, bt, bias if use_bias else None, rs if use_rs else None, scale_from)
         err = (out.double() - ref).abs()
         assert bool((err <= 1e-5 * bound + 1e-30).all()), (K, M, use_bias, use_rs, float((err / (bound + 1e-30)).max()))
+    if M % 8 == 0:   # two compact outputs: the columns before / from M / 2 on (the halves of d[h | neigh])
+        whole = be.rows_gemm(a, b, b_transposed=bt, bias=bias, row_scale=rs, scale_from=M // 2)
+        left, right = be.rows_gemm(a, b, b_transposed=bt, bias=bias, row_scale=rs, scale_from=M // 2, split_col=M // 2)
+        assert left.is_contiguous() and right.is_contiguous() and torch.equal(left, whole[:, :M // 2]) and torch.equal(right, whole[:, M // 2:])
     again = be.rows_gemm(a, b, b_transposed=bt, bias=bias, row_scale=rs, scale_from=0)
     assert torch.equal(again, be.rows_gemm(a, b, b_transposed=bt, bias=bias, row_scale=rs, scale_from=0))   # fixed summation order
 
