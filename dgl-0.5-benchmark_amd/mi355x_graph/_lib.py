@@ -81,6 +81,7 @@ SIGNATURES = {
     "mgx_column_affine": (_i32, [_i64, _i64, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),
     "mgx_xty_workspace": (_i64, [_i64, _i64]),
     "mgx_xty": (_i32, [_i64, _i64, _i64, _fp, _i64, _fp, _i64, _fp, _i64, _vp, _vp]),
+    "mgx_xty_colsum": (_i32, [_i64, _i64, _i64, _fp, _i64, _fp, _i64, _fp, _i64, _fp, _vp, _vp]),
     "mgx_rows_gemm": (_i32, [_i64, _i64, _i64, _fp, _i64, _fp, _i64, _i32, _fp, _fp, _i64, _fp, _i64, _fp, _i64, _i64, _vp]),
     "mgx_rows_gemm_supported": (_i32, [_i64, _i64, _i64]),
     "mgx_rows_gemm_relu_dropout": (_i32, [_i64, _i64, _i64, _fp, _i64, _fp, _i64, _i32, _fp, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64,

@@ -610,6 +610,15 @@ def _weight_grad(dy2, x2):
     return dy2.t() @ x2
 
 
+def _weight_bias_grad(dy2, x2):
+    """(dy^T x, column sums of dy): the weight and the bias gradient of a dense layer from ONE pass over dy where mgx_xty_colsum applies."""
+    be = sparse.backend_for(dy2)
+    if (x2.shape[0] >= be.XTY_MIN_ROWS and dy2.shape[1] <= be.XTY_MAX[0] and x2.shape[1] <= be.XTY_MAX[1]
+            and os.environ.get("MGX_LINEAR_XTY", "1") == "1" and os.environ.get("MGX_XTY_COLSUM", "1") == "1"):
+        return be.xty(dy2 if dy2.stride(1) == 1 else dy2.contiguous(), x2 if x2.stride(1) == 1 else x2.contiguous(), colsum=True)
+    return _weight_grad(dy2, x2), be.column_sum(dy2 if dy2.is_contiguous() else dy2.contiguous())
+
+
 class LinearSumFn(torch.autograd.Function):
     """y = x1 W1^T + x2 W2^T + b in two GEMMs, the second accumulating into the first's output (no separate add pass);
     gradients as LinearFn.  SAGEConv's `fc_self(h) + fc_neigh(h_neigh)` (main_dgl_product_sage.py:64)."""
@@ -833,11 +842,15 @@ class SageMeanCatFn(torch.autograd.Function):
             # else the GEMM and a streaming pass over that half -- never a per-edge factor
             dh, dn = _rows_dgrad(be, dy, torch.cat([w_self, w_neigh], dim=1), ctx.gidx.csc().inv_degrees(), K)
             be.spmm_copy_u_strided(ctx.gidx.csr(), "sum", dn, dh, accumulate=True)
-        dws = dwn = None
-        if need[3] or need[4]:
+        dws = dwn = db = None
+        if (need[3] or need[4]) and need[5]:
+            dw, db = _weight_bias_grad(dy, cat.buf)               # [out, 2K], [out]: one pass over dy
+            dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
+        elif need[3] or need[4]:
             dw = _weight_grad(dy, cat.buf)                        # [out, 2K]
             dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
-        db = be.column_sum(dy) if need[5] else None
+        elif need[5]:
+            db = be.column_sum(dy)
         return None, None, dh, dws, dwn, db, None
 
 

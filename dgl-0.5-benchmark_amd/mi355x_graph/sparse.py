@@ -828,24 +828,38 @@ class HipBackend(object):
     XTY_MAX = (256, 1024)     # the grid of tiles in one launch goes up to this output shape
     XTY_MIN_ROWS = 1 << 16    # shorter reductions stay with the GEMM library
 
-    def xty(self, a2d, b2d):
-        """a2d [n, M], b2d [n, K] -> a^T b [M, K] (the tall-skinny weight-gradient product)."""
+    def xty(self, a2d, b2d, colsum=False):
+        """a2d [n, M], b2d [n, K] -> a^T b [M, K] (the tall-skinny weight-gradient product).  colsum=True: (a^T b, column sums of a) --
+        the bias gradient from the same pass over a when the shape allows (mgx_xty_colsum), else by mgx_column_sum."""
         dev = self._check_dev(a2d, b2d)
         n, M = a2d.shape
         K = b2d.shape[1]
         if M > self.XTY_MAX[0] or K > self.XTY_MAX[1]:
             raise DGLError("mgx_xty: at most %d x %d outputs, got %d x %d" % (self.XTY_MAX + (M, K)))
         out = torch.empty((M, K), dtype=torch.float32, device=dev)
+        sums = torch.empty(M, dtype=torch.float32, device=dev) if colsum else None
+        have_sums = False
         L = _lib.lib()
         tm, tk = self.XTY_TILE
         ntiles = ((M + tm - 1) // tm) * ((K + tk - 1) // tk)
+
+        def one(a_t, b_t, o_t, ws, want_sums):
+            if want_sums:
+                st = L.mgx_xty_colsum(n, a_t.shape[1], b_t.shape[1], _ptr(a_t), max(a2d.stride(0), M), _ptr(b_t), max(b2d.stride(0), K),
+                                      _ptr(o_t), out.stride(0), _ptr(sums), _ptr(ws), _stream(dev))
+                if st != _lib.ERR_UNSUPPORTED:
+                    _lib.check(st)
+                    return True
+            _lib.check(L.mgx_xty(n, a_t.shape[1], b_t.shape[1], _ptr(a_t), max(a2d.stride(0), M), _ptr(b_t), max(b2d.stride(0), K),
+                                 _ptr(o_t), out.stride(0), _ptr(ws), _stream(dev)))
+            return False
+
         with torch.cuda.device(dev):
             if ntiles == 1 or ntiles >= 4:
                 # a single 64 x 128 tile, or the grid of tiles in ONE launch (operand rows shared through L2): measured
                 # 256 x 512 at n = 169 k 1.07 -> 0.56 ms, 128 x 602 at n = 233 k 0.78 -> 0.57 ms (experiments/exp_wgrad_shapes.py)
                 ws = torch.empty(max(L.mgx_xty_workspace(M, K), 4) // 4, dtype=torch.float32, device=dev)
-                _lib.check(L.mgx_xty(n, M, K, _ptr(a2d), max(a2d.stride(0), M), _ptr(b2d), max(b2d.stride(0), K), _ptr(out),
-                                     out.stride(0), _ptr(ws), _stream(dev)))
+                have_sums = one(a2d, b2d, out, ws, colsum and ntiles == 1)
             else:
                 # two or three tiles (the stacked 64 x 200 of the products layer): one launch per tile, each with the exact tile
                 # shape, is faster than the grid's padded 64 x 128 tiles (n = 2.45 M: 0.93 against 1.04 ms)
@@ -853,9 +867,11 @@ class HipBackend(object):
                 for m0 in range(0, M, tm):
                     for k0 in range(0, K, tk):
                         a_t, b_t, o_t = a2d[:, m0:m0 + tm], b2d[:, k0:k0 + tk], out[m0:m0 + tm, k0:k0 + tk]
-                        _lib.check(L.mgx_xty(n, a_t.shape[1], b_t.shape[1], _ptr(a_t), max(a2d.stride(0), M), _ptr(b_t),
-                                             max(b2d.stride(0), K), _ptr(o_t), out.stride(0), _ptr(ws), _stream(dev)))
-        return out
+                        if one(a_t, b_t, o_t, ws, colsum and M <= tm and k0 == 0):
+                            have_sums = True
+        if not colsum:
+            return out
+        return out, (sums if have_sums else self.column_sum(a2d if a2d.is_contiguous() else a2d.contiguous()))
 
     def rows_gemm(self, a2d, b2d, b_transposed=False, bias=None, row_scale=None, scale_from=0, out=None, split_col=0):
         """a2d [n, K] (row-strided view allowed) x B -> [n, M]; B = b2d [K, M], or [M, K] when b_transposed (nn.Linear's layout);

@@ -388,6 +388,11 @@ int32_t mgx_column_affine(int64_t n, int64_t C, const float* a, const float* b, 
 int64_t mgx_xty_workspace(int64_t M, int64_t K);
 int32_t mgx_xty(int64_t n, int64_t M, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldc,
                 void* workspace, void* stream);
+/* mgx_xty that also returns the column sums of a (colsum [M]; the bias gradient beside the weight gradient) from the same pass over a,
+ * as the product with one more column of ones.  One 64 x 128 tile, b read with 16-byte loads (K % 4 == 0, K >= 64, ldb % 4 == 0,
+ * 16-byte aligned), else MGX_ERR_UNSUPPORTED (mgx_xty + mgx_column_sum).  Same workspace. */
+int32_t mgx_xty_colsum(int64_t n, int64_t M, int64_t K, const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldc,
+                       float* colsum, void* workspace, void* stream);
 
 /* C[n, M] = A[n, K] x B (+ bias[M]) for A with millions of rows and small K, M -- the dense projections either side of an aggregation
  * (SAGEConv's fc_self / fc_neigh on [h | mean_agg(h)], main_dgl_product_sage.py:23-24,64, and the input gradient d[h | neigh] = dY x W).

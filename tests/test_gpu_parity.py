@@ -618,6 +618,27 @@ def test_xty_matches_fp64(n, M, K):
         sparse.backend_for(a).xty(torch.zeros(4, 257, device=DEV), torch.zeros(4, 8, device=DEV))
 
 
+@pytest.mark.parametrize("n,M,K", [(70001, 64, 128), (65537, 64, 200), (100000, 47, 128), (70000, 64, 64), (66000, 16, 100), (5000, 64, 128),
+                                    (70000, 64, 72), (70000, 128, 128), (0, 64, 128)])
+def test_xty_with_column_sums_matches_fp64(n, M, K):
+    """backend.xty(colsum=True): the weight gradient and, from the same pass where mgx_xty_colsum applies (else mgx_column_sum), the bias
+    gradient = column sums of the first operand; both against fp64, the product bit for bit the plain mgx_xty result."""
+    rng = np.random.default_rng(n + 7 * M + K)
+    a = T(rng.standard_normal((n, M)).astype(np.float32))
+    b = T(rng.standard_normal((n, K)).astype(np.float32))
+    be = sparse.backend_for(a)
+    got, sums = be.xty(a, b, colsum=True)
+    assert torch.equal(got, be.xty(a, b))
+    ref_s = a.double().sum(0)
+    bound = a.double().abs().sum(0)
+    assert sums.shape == (M,) and bool(((sums.double() - ref_s).abs() <= 1e-5 * bound + 1e-30).all())
+    again, sums2 = be.xty(a, b, colsum=True)
+    assert torch.equal(sums, sums2) and torch.equal(again, got)      # fixed summation order
+    wide = T(rng.standard_normal((n, M + 8)).astype(np.float32))      # a row-strided first operand
+    got_w, sums_w = be.xty(wide[:, :M], b, colsum=True)
+    assert bool(((sums_w.double() - wide[:, :M].double().sum(0)).abs() <= 1e-5 * wide[:, :M].double().abs().sum(0) + 1e-30).all())
+
+
 def test_linear_weight_grad_through_xty_matches_torch():
     from mi355x_graph.nn import Linear
     n = 70000  # >= XTY_MIN_ROWS: the weight gradient takes mgx_xty
