@@ -480,11 +480,15 @@ class DistSageMeanCatFn(torch.autograd.Function):
         # the parameter gradients need nothing from the peers: formed while the halo-row gradients travel (the scaling model,
         # profiles/r04_scale_model.txt, has the exchange at 2x the reversed aggregation it used to hide behind at P = 8)
         comm.mark("dense (inside the exchange window)")
-        dws = dwn = None
-        if need[4] or need[5]:
+        dws = dwn = db = None
+        if (need[4] or need[5]) and need[6]:
+            dw, db = ops._weight_bias_grad(dy, cat.buf)  # the bias gradient from the weight-gradient kernel's own pass over dy
+            dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
+        elif need[4] or need[5]:
             dw = ops._weight_grad(dy, cat.buf)
             dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
-        db = be.column_sum(dy) if need[6] else None
+        elif need[6]:
+            db = be.column_sum(dy)
         if need[3]:
             work.wait()
             comm.mark("return-add")
