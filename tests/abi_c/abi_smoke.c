@@ -28,7 +28,7 @@ int main(void) {
   const int n = 5, nnz = 8, D = 2;
   float X[10];
   for (int i = 0; i < 10; ++i) X[i] = (float)(i + 1); /* [[1,2],[3,4],[5,6],[7,8],[9,10]] */
-  if (mgx_abi_version() < 8) { printf("unexpected ABI version %d\n", mgx_abi_version()); return 1; }
+  if (mgx_abi_version() < 29) { printf("unexpected ABI version %d\n", mgx_abi_version()); return 1; }
 
   int32_t *d_src = dev_copy(src, sizeof src), *d_dst = dev_copy(dst, sizeof dst);
   float* d_X = dev_copy(X, sizeof X);
@@ -86,6 +86,89 @@ int main(void) {
         if (dst[k] == v) { s += a[k * D + j]; ++cnt; }
       if (cnt && fabsf(s - 1.f) > 1e-5f) { printf("softmax of node %d does not sum to 1: %f\n", v, s); return 7; }
     }
+
+  /* a two-part plan (mgx_spmm_plan::rest) from a plain-C caller: rows 0, 1, 2 (<= 2 edges) on the lane-group kernel, row 3 (4 edges) and
+   * the empty row 4 in `rest`; same result as above */
+  {
+    const int32_t h_row[3] = {0, 1, 2}, h_beg[3] = {0, 1, 2}, h_end[3] = {1, 2, 4};
+    const int32_t r_row[2] = {3, 4}, r_beg[2] = {4, 8}, r_end[2] = {8, 8};
+    mgx_spmm_plan rest, head;
+    memset(&rest, 0, sizeof rest);
+    memset(&head, 0, sizeof head);
+    rest.num_items = 2;
+    rest.item_row = (const int32_t*)dev_copy(r_row, sizeof r_row);
+    rest.item_beg = dev_copy(r_beg, sizeof r_beg);
+    rest.item_end = dev_copy(r_end, sizeof r_end);
+    rest.item_node = rest.item_row;
+    head.num_items = 3;
+    head.item_row = (const int32_t*)dev_copy(h_row, sizeof h_row);
+    head.item_beg = dev_copy(h_beg, sizeof h_beg);
+    head.item_end = dev_copy(h_end, sizeof h_end);
+    head.item_node = head.item_row;
+    head.rest = &rest;
+    float* d_out2 = dev_copy(NULL, n * 4 * 4);
+    float X4[20], out4[20];
+    for (int i = 0; i < n; ++i) { X4[4 * i] = X[2 * i]; X4[4 * i + 1] = X[2 * i + 1]; X4[4 * i + 2] = -X[2 * i]; X4[4 * i + 3] = 1.f; }
+    float* d_X4 = dev_copy(X4, sizeof X4);
+    CHECK_MGX(mgx_spmm_csr(&csr, &head, MGX_OP_COPY_LHS, MGX_REDUCE_MEAN, d_X4, NULL, 4, 0, 4, NULL, NULL, NULL, NULL, d_out2, NULL,
+                           NULL, NULL, MGX_SPMM_SHORT_ROWS, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(out4, d_out2, sizeof out4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i)
+      if (fabsf(out4[4 * i] - want[2 * i]) > 1e-6f || fabsf(out4[4 * i + 1] - want[2 * i + 1]) > 1e-6f ||
+          fabsf(out4[4 * i + 2] + want[2 * i]) > 1e-6f || fabsf(out4[4 * i + 3] - (i == 4 ? 0.f : 1.f)) > 1e-6f) {
+        printf("two-part plan mismatch at row %d (%s)\n", i, mgx_last_spmm_kernel());
+        return 9;
+      }
+    if (strcmp(mgx_last_spmm_kernel(), "rowgroup32") != 0) { printf("two-part plan took %s\n", mgx_last_spmm_kernel()); return 9; }
+  }
+
+  /* the dense helpers of a layer: C = A B + bias with the second half of the columns times a row factor, as two compact matrices;
+   * A^T B with the column sums of A */
+  {
+    enum { R = 40, K = 32, M = 64 };
+    static float A[R * K], B[K * M], bias[M], rs[R], C1[R * (M / 2)], C2[R * (M / 2)], W[K * M], sums[K];
+    for (int i = 0; i < R * K; ++i) A[i] = (float)((i * 7) % 11) - 5.f;
+    for (int i = 0; i < K * M; ++i) B[i] = (float)((i * 5) % 13) - 6.f;
+    for (int i = 0; i < M; ++i) bias[i] = (float)i;
+    for (int i = 0; i < R; ++i) rs[i] = 1.f / (float)(1 + i % 4);
+    float *d_A = dev_copy(A, sizeof A), *d_B = dev_copy(B, sizeof B), *d_b = dev_copy(bias, sizeof bias), *d_rs = dev_copy(rs, sizeof rs);
+    float *d_C1 = dev_copy(NULL, sizeof C1), *d_C2 = dev_copy(NULL, sizeof C2);
+    if (!mgx_rows_gemm_supported(K, M, K)) { printf("mgx_rows_gemm_supported(32, 64) is 0\n"); return 10; }
+    CHECK_MGX(mgx_rows_gemm(R, K, M, d_A, K, d_B, M, 0, d_b, d_rs, M / 2, d_C1, M / 2, d_C2, M / 2, M / 2, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(C1, d_C1, sizeof C1, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(C2, d_C2, sizeof C2, hipMemcpyDeviceToHost));
+    for (int r = 0; r < R; ++r)
+      for (int m = 0; m < M; ++m) {
+        float ref = bias[m];
+        for (int k = 0; k < K; ++k) ref += A[r * K + k] * B[k * M + m];   /* small integers: exact in fp32 whatever the order */
+        if (m >= M / 2) ref *= rs[r];
+        const float got = m < M / 2 ? C1[r * (M / 2) + m] : C2[r * (M / 2) + m - M / 2];
+        if (fabsf(got - ref) > 1e-4f * (1.f + fabsf(ref))) { printf("rows_gemm mismatch at (%d, %d): %f vs %f\n", r, m, got, ref); return 10; }
+      }
+    /* A^T [A | A] (K x 2K = 32 x 64) and the column sums of A */
+    static float AA[R * 2 * K];
+    for (int r = 0; r < R; ++r)
+      for (int k = 0; k < 2 * K; ++k) AA[r * 2 * K + k] = A[r * K + k % K];
+    float *d_AA = dev_copy(AA, sizeof AA), *d_W = dev_copy(NULL, sizeof W), *d_s = dev_copy(NULL, sizeof sums);
+    const int64_t xws = mgx_xty_workspace(K, 2 * K);
+    void* d_xws = dev_copy(NULL, (size_t)xws);
+    CHECK_MGX(mgx_xty_colsum(R, K, 2 * K, d_A, K, d_AA, 2 * K, d_W, 2 * K, d_s, d_xws, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(W, d_W, sizeof W, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(sums, d_s, sizeof sums, hipMemcpyDeviceToHost));
+    for (int i = 0; i < K; ++i) {
+      float cs = 0.f;
+      for (int r = 0; r < R; ++r) cs += A[r * K + i];
+      if (sums[i] != cs) { printf("xty_colsum: column sum %d is %f, expected %f\n", i, sums[i], cs); return 11; }
+      for (int j = 0; j < 2 * K; ++j) {
+        float ref = 0.f;
+        for (int r = 0; r < R; ++r) ref += A[r * K + i] * AA[r * 2 * K + j];
+        if (W[i * 2 * K + j] != ref) { printf("xty mismatch at (%d, %d)\n", i, j); return 11; }
+      }
+    }
+  }
 
   /* error path: bad argument must return a code and a message, not crash */
   if (mgx_spmm_csr(NULL, NULL, 0, 0, NULL, NULL, 1, 1, 1, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL) != MGX_ERR_INVALID_ARGUMENT ||
