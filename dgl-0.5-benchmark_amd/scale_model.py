@@ -9,10 +9,13 @@ work between collectives (HIP events) and the rows every exchange moves between 
 replays the ranks in lock step with each exchange priced at a stated per-link rate: slice q -> r on its own xGMI link, full
 duplex, startable when both ranks have posted.
 
-What the model does NOT contain: RCCL's copy kernels competing with the aggregation for CUs and HBM during the window, and
-host launch gaps of a rank whose host is slower than its device work (the emulation's hosts share one Python interpreter;
-the events only see the device).
+What the model does NOT contain: RCCL's copy kernels competing with the aggregation for CUs and HBM during the window.  What it DOES
+contain: the launch gaps of a rank whose host is slower than its device work -- a stretch is the time between two events on the
+rank's stream, idle gaps included; at P = 8 they are ~1 ms of a rank's 4.3 ms (docs/LOG_r04.md section 19; one Python thread per
+rank here as in a real run).
 """
+import os
+import tempfile
 import time
 
 import torch
@@ -71,8 +74,6 @@ def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, w
             # experiment (bench.py --tune-dense): PyTorch TunableOp picks the GEMMs of the per-rank shapes during the warm-up.  The
             # environment variable wins over torch.cuda.tunable.tuning_enable(); results go to a scratch file, never to the staged
             # copy of the committed selections.
-            import os
-            import tempfile
             torch.cuda.tunable.enable(True)
             torch.cuda.tunable.set_filename(os.path.join(tempfile.gettempdir(), "mgx_tunableop_emulated_%d.csv" % os.getpid()))
             torch.cuda.tunable.set_max_tuning_duration(10)
@@ -82,7 +83,6 @@ def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, w
             step()
         if tune_dense:
             ctx.barrier()
-            import os
             os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
         ctx.start_trace()  # one traced epoch thrown away: the first use of the timing events
         step()
