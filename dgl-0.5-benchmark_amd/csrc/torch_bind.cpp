@@ -17,6 +17,7 @@
 // natural row order.  Fake (meta) implementations and autograd formulas are registered from Python (mi355x_graph/torch_ops.py)
 // on these same ops.  Built by csrc/Makefile into libmi355x_graph_torch.so, loaded with torch.ops.load_library.
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -31,6 +32,14 @@ using at::Tensor;
 using c10::optional;
 
 void* stream_of(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+// Every op makes the device of its graph / feature tensors current for the duration of the call: allocations, the stream looked up by
+// stream_of() and the kernel launches inside the C ABI must all refer to THAT device, not to whichever one the calling thread last used
+// (several GPUs in one process; the ctypes route wraps its calls in `with torch.cuda.device(dev)` for the same reason).
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+#define MGX_DEVICE_GUARD(t, what)                                                                     \
+  TORCH_CHECK((t).is_cuda(), what, ": runs on MI355X (HIP) tensors only -- there is no CPU path");    \
+  const DeviceGuard device_guard_((t).device())
 
 void check_status(int32_t st, const char* what) {
   TORCH_CHECK(st == MGX_OK, what, ": ", mgx_last_error(), " (mgx status ", st, ")");
@@ -140,6 +149,7 @@ std::tuple<Tensor, Tensor, Tensor> gspmm(const Tensor& indptr, const Tensor& ind
                                          std::string op, std::string reduce, const optional<Tensor>& ufeat,
                                          const optional<Tensor>& efeat, int64_t plan_handle, int64_t flags) {
   const char* what = "mi355x_graph::gspmm";
+  MGX_DEVICE_GUARD(indptr, what);
   mgx_csr csr = make_csr(indptr, indices, eids, num_cols, what);
   int opc = op_code(op, what);
   const int red = reduce_code(reduce, what);
@@ -182,6 +192,7 @@ Tensor gsddmm(const Tensor& indptr, const Tensor& indices, const optional<Tensor
               const optional<Tensor>& lhs, const optional<Tensor>& rhs, std::string lhs_target, std::string rhs_target,
               int64_t plan_handle) {
   const char* what = "mi355x_graph::gsddmm";
+  MGX_DEVICE_GUARD(indptr, what);
   mgx_csr csr = make_csr(indptr, indices, eids, num_cols, what);
   const int opc = op_code(op, what);
   const int lt = target_code(lhs_target, what), rt = target_code(rhs_target, what);
@@ -226,6 +237,7 @@ Tensor gsddmm(const Tensor& indptr, const Tensor& indices, const optional<Tensor
 Tensor gsddmm_coo(const Tensor& src, const Tensor& dst, int64_t num_src, int64_t num_dst, std::string op, const optional<Tensor>& lhs,
                   const optional<Tensor>& rhs, std::string lhs_target, std::string rhs_target) {
   const char* what = "mi355x_graph::gsddmm_coo";
+  MGX_DEVICE_GUARD(src, what);
   TORCH_CHECK(src.is_cuda() && dst.is_cuda() && src.device() == dst.device(), what, ": runs on MI355X (HIP) tensors only");
   TORCH_CHECK(src.dim() == 1 && src.sizes() == dst.sizes() && src.scalar_type() == dst.scalar_type() && src.is_contiguous() &&
                   dst.is_contiguous(), what, ": src / dst must be matching contiguous 1-D index tensors");
@@ -278,6 +290,7 @@ Tensor softmax_ws(const mgx_spmm_plan* plan, int64_t H, const Tensor& like) {
 Tensor edge_softmax_fwd(const Tensor& indptr, const Tensor& indices, const optional<Tensor>& eids, int64_t num_cols, const Tensor& z,
                         int64_t plan_handle) {
   const char* what = "mi355x_graph::edge_softmax_fwd";
+  MGX_DEVICE_GUARD(indptr, what);
   mgx_csr csr = make_csr(indptr, indices, eids, num_cols, what);
   Tensor zc = as_f32(z, indptr, what);
   TORCH_CHECK(zc.dim() >= 1 && zc.size(0) == csr.nnz, what, ": logits must have nnz = ", csr.nnz, " rows");
@@ -293,6 +306,7 @@ Tensor edge_softmax_fwd(const Tensor& indptr, const Tensor& indices, const optio
 Tensor edge_softmax_bwd(const Tensor& indptr, const Tensor& indices, const optional<Tensor>& eids, int64_t num_cols, const Tensor& a,
                         const Tensor& da, int64_t plan_handle) {
   const char* what = "mi355x_graph::edge_softmax_bwd";
+  MGX_DEVICE_GUARD(indptr, what);
   mgx_csr csr = make_csr(indptr, indices, eids, num_cols, what);
   Tensor ac = as_f32(a, indptr, what), dac = as_f32(da, indptr, what);
   TORCH_CHECK(ac.sizes() == dac.sizes() && ac.dim() >= 1 && ac.size(0) == csr.nnz, what, ": a and da must both be [nnz, ...]");
@@ -308,6 +322,7 @@ Tensor edge_softmax_bwd(const Tensor& indptr, const Tensor& indices, const optio
 // ----------------------------------------------------------------------------- segment reduce
 Tensor segment_reduce(const Tensor& offsets, const Tensor& x, std::string reduce) {
   const char* what = "mi355x_graph::segment_reduce";
+  MGX_DEVICE_GUARD(x, what);
   TORCH_CHECK(x.is_cuda() && offsets.is_cuda() && offsets.device() == x.device(), what, ": runs on MI355X (HIP) tensors only");
   TORCH_CHECK(offsets.scalar_type() == at::kLong && offsets.dim() == 1 && offsets.numel() >= 1, what, ": offsets must be int64 [segments + 1]");
   Tensor xc = as_f32(x, offsets, what);
@@ -325,6 +340,7 @@ Tensor segment_reduce(const Tensor& offsets, const Tensor& x, std::string reduce
 // ----------------------------------------------------------------------------- formats (integer work, bit-exact)
 std::tuple<Tensor, Tensor, Tensor> coo_to_csr(const Tensor& row, const Tensor& col, int64_t num_rows, int64_t num_cols) {
   const char* what = "mi355x_graph::coo_to_csr";
+  MGX_DEVICE_GUARD(row, what);
   TORCH_CHECK(row.is_cuda() && col.is_cuda() && row.device() == col.device(), what, ": runs on MI355X (HIP) tensors only");
   TORCH_CHECK(row.dim() == 1 && row.sizes() == col.sizes() && row.scalar_type() == col.scalar_type(), what, ": row / col must match");
   const int bits = idx_bits(row, what);
@@ -343,6 +359,7 @@ std::tuple<Tensor, Tensor, Tensor> coo_to_csr(const Tensor& row, const Tensor& c
 
 std::tuple<Tensor, Tensor, Tensor> csr_transpose(const Tensor& indptr, const Tensor& indices, const optional<Tensor>& eids, int64_t num_cols) {
   const char* what = "mi355x_graph::csr_transpose";
+  MGX_DEVICE_GUARD(indptr, what);
   mgx_csr csr = make_csr(indptr, indices, eids, num_cols, what);
   Tensor ip = at::empty({num_cols + 1}, indptr.options()), ix = at::empty({csr.nnz}, indptr.options()), ei = at::empty({csr.nnz}, indptr.options());
   const int64_t ws_bytes = mgx_csr_transpose_workspace(num_cols, csr.nnz, csr.idx_bits);
@@ -354,6 +371,7 @@ std::tuple<Tensor, Tensor, Tensor> csr_transpose(const Tensor& indptr, const Ten
 
 Tensor in_degrees(const Tensor& indptr) {
   const char* what = "mi355x_graph::in_degrees";
+  MGX_DEVICE_GUARD(indptr, what);
   TORCH_CHECK(indptr.is_cuda(), what, " runs on MI355X (HIP) tensors");
   TORCH_CHECK(indptr.dim() == 1 && indptr.numel() >= 1 && indptr.is_contiguous(), what, ": indptr [rows + 1]");
   const int bits = idx_bits(indptr, what);

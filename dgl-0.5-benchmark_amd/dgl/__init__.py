@@ -14,10 +14,14 @@ from mi355x_graph.ops import edge_softmax  # noqa: F401
 __version__ = "0.6.1+mi355x"
 
 # The dense half of an unmodified reference model is torch.nn.Linear on 2.45 M-row matrices; PyTorch's own backward for it takes
-# 25 ms of a 46 ms products epoch (bias-gradient reduction 19 ms).  The drop-in import therefore routes tall fp32 device matrices through
-# mi355x_graph.utils.accelerate_linear() -- same forward, backward by this package's column-sum / X^T Y kernels.  MGX_ACCELERATE_LINEAR=0
-# leaves torch.nn.functional.linear alone; `import mi355x_graph` never touches it.
+# 25 ms of a 46 ms products epoch (bias-gradient reduction 19 ms).  mi355x_graph.utils.accelerate_linear() routes tall fp32 device
+# matrices through this package's column-sum / X^T Y kernels in the backward (same forward).  It replaces torch.nn.functional.linear
+# process-wide, so it is OPT-IN: a launcher calls it, or the user of an unmodified script sets MGX_ACCELERATE_LINEAR=1 -- the import
+# then says what it did, once, on stderr.  Without either, `import dgl` leaves PyTorch alone.
 import os as _os
-if _os.environ.get("MGX_ACCELERATE_LINEAR", "1") != "0":
+if _os.environ.get("MGX_ACCELERATE_LINEAR", "0") == "1":
+    import sys as _sys
     from mi355x_graph.utils import accelerate_linear as _accelerate_linear
-    _accelerate_linear(True)
+    if not _accelerate_linear(True):
+        _sys.stderr.write("dgl (mi355x_graph): MGX_ACCELERATE_LINEAR=1 -- torch.nn.functional.linear now takes this package's backward "
+                          "for fp32 device matrices of >= 65536 rows (mi355x_graph.utils.accelerate_linear(False) undoes it)\n")

@@ -130,6 +130,7 @@ class GraphSAGE(nn.Module):
                 self._input_cat = held = (weakref.ref(g), tuple(x.shape), c) if c is not None else None
             cat = None if held is None or not torch.is_grad_enabled() else held[2]
         for i, layer in enumerate(self.layers[:-1]):
+            nxt = None
             if not self.plain and not len(self.bns) and self.training and cat is not None and layer.fc_self.bias is None:
                 # layer + relu + dropout as one node: the GEMM's epilogue applies the activation and writes the next layer's left half
                 nxt = ops.cat_buffer_for(g, x, layer.fc_self.weight.shape[0])
@@ -144,7 +145,8 @@ class GraphSAGE(nn.Module):
             if self.plain:
                 x = self.dropout(F.relu(x))
             else:
-                cat = ops.cat_buffer_for(g, x, x.shape[1]) if self.training else None
+                # (a buffer allocated for the fused form above that did not apply is the one this layer's activation goes to)
+                cat = (nxt if nxt is not None and nxt.K == x.shape[1] else ops.cat_buffer_for(g, x, x.shape[1])) if self.training else None
                 # F.relu + dropout, one pass each way on the device, written into the next layer's left half
                 x = ops.relu_dropout(x, self.dropout.p, self.training, out=None if cat is None else cat.left)
                 if cat is not None and not cat.holds(x):

@@ -800,8 +800,13 @@ class SageMeanCatFn(torch.autograd.Function):
             seed = torch.initial_seed() & (2 ** 64 - 1)
             offset = (ReluDropout._calls * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
             ReluDropout._calls += 1
-            y, mask = be.rows_gemm_relu_dropout(cat.buf, torch.cat([w_self, w_neigh], dim=1), True, bias, float(p), seed, offset,
-                                                out=None if into is None else into.t)
+            wcat = torch.cat([w_self, w_neigh], dim=1)
+            fused = be.rows_gemm_relu_dropout(cat.buf, wcat, True, bias, float(p), seed, offset, out=None if into is None else into.t)
+            if fused is None:  # no fused kernel for this operand after all: the composition it stands for, same seed and offset (same bits)
+                y, mask = be.relu_dropout_fwd(_rows_linear(be, cat.buf, wcat, bias), float(p), seed, offset,
+                                              out=None if into is None else into.t)
+            else:
+                y, mask = fused
             ctx.save_for_backward(w_self, w_neigh, mask)
             ctx.p = float(p)
             return y

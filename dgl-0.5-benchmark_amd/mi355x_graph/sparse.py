@@ -916,9 +916,12 @@ class HipBackend(object):
             return None
         mask = torch.empty(n * M // 4, dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_rows_gemm_relu_dropout(n, K, M, _ptr(a2d), a2d.stride(0), _ptr(b2d), b2d.stride(0),
-                                                             1 if b_transposed else 0, _ptr(bias), ctypes.c_float(p), ctypes.c_uint64(seed),
-                                                             ctypes.c_uint64(offset), _ptr(y), y.stride(0), _ptr(mask), _stream(dev)))
+            st = _lib.lib().mgx_rows_gemm_relu_dropout(n, K, M, _ptr(a2d), a2d.stride(0), _ptr(b2d), b2d.stride(0),
+                                                       1 if b_transposed else 0, _ptr(bias), ctypes.c_float(p), ctypes.c_uint64(seed),
+                                                       ctypes.c_uint64(offset), _ptr(y), y.stride(0), _ptr(mask), _stream(dev))
+        if st == _lib.ERR_UNSUPPORTED:  # e.g. an operand that is only dword aligned: mgx_rows_gemm_supported() never sees the pointer
+            return None
+        _lib.check(st)
         return y, mask
 
     def column_sum(self, x2d):

@@ -66,19 +66,43 @@ def _op(name, fn):
     return _Native
 
 
+_plan_owners = weakref.WeakValueDictionary()  # handle -> the plan object whose c_struct() lives at that address
+
+
+def _handle_of(plan):
+    """A plan's handle = the address of its mgx_spmm_plan struct.  The struct (and the device tables it points to) is owned by the plan
+    object, the plan by its CsrView: whoever keeps a handle across calls must keep the owner too -- `plan_owner(handle)` gives it back
+    (an autograd node saves it on its ctx, see _softmax_setup), so a graph that lives for one step (a sampled block, a batch) cannot be
+    collected between the forward that took the handle and the backward that uses it."""
+    if plan is None:
+        return 0
+    handle = ctypes.addressof(plan.c_struct())
+    _plan_owners[handle] = plan
+    return handle
+
+
+def plan_owner(handle):
+    """The live plan object behind a handle handed out by plan_handle() / softmax_plan_handle() (None for 0); raises when the
+    owner is gone -- a handle that outlived its graph must never reach the C++ op, which would dereference freed host memory."""
+    if not handle:
+        return None
+    plan = _plan_owners.get(handle)
+    if plan is None:
+        raise DGLError("execution-plan handle %#x is stale: the graph (CsrView) that owned it has been released" % handle)
+    return plan
+
+
 def plan_handle(csr):
     """Address of the CSR's mgx_spmm_plan struct (kept alive by the CsrView), 0 when it has none or the ops are Python's."""
     if not NATIVE or not csr.indptr.is_cuda:
         return 0
-    plan = csr.plan()
-    return 0 if plan is None else ctypes.addressof(plan.c_struct())
+    return _handle_of(csr.plan())
 
 
 def softmax_plan_handle(csr):
     if not NATIVE or not csr.indptr.is_cuda:
         return 0
-    plan = csr.softmax_plan()
-    return 0 if plan is None else ctypes.addressof(plan.c_struct())
+    return _handle_of(csr.softmax_plan())
 
 
 def _key(indptr, indices):
@@ -237,6 +261,7 @@ def _softmax_setup(ctx, inputs, output):
     indptr, indices, eids, num_cols, z, plan = inputs
     ctx.save_for_backward(indptr, indices, eids, output)
     ctx.num_cols, ctx.plan = num_cols, plan
+    ctx.plan_owner = plan_owner(plan) if NATIVE else None  # the handle is an address: its owner lives as long as this node
 
 
 def _softmax_backward(ctx, grad):
@@ -334,7 +359,7 @@ def raw_gspmm(csr, op, reduce, X, Y, want_arg=False):
         ref = X if op == "copy_lhs" else Y
         plan, short = csr.spmm_plan_for(ref.numel() // max(int(ref.shape[0]), 1))
         if short:  # MGX_SPMM_SHORT_ROWS: one work item per lane group, over the schedule or its two-part form (CsrView.spmm_plan_for)
-            flags, handle = 2, (0 if plan is None else ctypes.addressof(plan.c_struct()))
+            flags, handle = 2, _handle_of(plan)
     if handle is None:
         handle = plan_handle(csr)
     try:

@@ -65,9 +65,14 @@ class GraphedStep(object):
 # stack (profiles/r03_plain_epoch_timeline.txt: one at::native::reduce_kernel = 42 % of the reference-module epoch) and the weight
 # gradient with a library GEMM of 1 ms where the tall-skinny product kernel takes 0.4.  accelerate_linear() swaps the function
 # torch.nn.Linear.forward calls for one whose BACKWARD uses this package's column-sum and X^T Y kernels; forward stays addmm.
-# Process-wide and reversible; switched on by the drop-in `import dgl` (MGX_ACCELERATE_LINEAR=0 opts out), never by `import
-# mi355x_graph`.  Anything it does not recognise (CPU, other dtypes, fewer than 65 536 rows, > 2 dims, autocast, torch.compile, a
-# stream capture, tensor subclasses) takes the original function.
+#
+# OPT-IN (round 5; it was the default of `import dgl` in round 4): replacing a function of another library process-wide is outside
+# DGL's surface, so nothing here runs unless the user asks for it -- `mi355x_graph.utils.accelerate_linear()` from a launcher, or
+# MGX_ACCELERATE_LINEAR=1 in the environment of an unmodified script (read by `import dgl`, which then says so on stderr once).
+# Reversible (accelerate_linear(False)).  Anything the replacement does not recognise takes PyTorch's function: CPU, other dtypes,
+# fewer than 65 536 rows, > 2 dims, autocast, torch.compile, a stream capture, an active torch.func transform (vmap / grad / jacrev),
+# tensor subclasses in ANY operand (DTensor / FSDP parameters, parametrizations).  Double backward through it raises
+# (once_differentiable), as for every autograd node of this package.
 _ORIGINAL_LINEAR = None
 LINEAR_MIN_ROWS = 1 << 16
 
@@ -78,10 +83,15 @@ def _tall_linear_fn():
 
     class TallLinearFn(torch.autograd.Function):
         @staticmethod
-        def forward(ctx, x, weight, bias):
-            ctx.save_for_backward(x, weight)
-            ctx.has_bias = bias is not None
+        def forward(x, weight, bias):
             return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+        @staticmethod
+        def setup_context(ctx, inputs, output):
+            x, weight, bias = inputs
+            # x is needed for the weight gradient only, the weight for the input gradient only
+            ctx.save_for_backward(x if weight.requires_grad else None, weight if x.requires_grad else None)
+            ctx.has_bias = bias is not None
 
         @staticmethod
         @torch.autograd.function.once_differentiable  # the kernels below are not differentiable: a double backward says so
@@ -92,7 +102,7 @@ def _tall_linear_fn():
             dx = g @ weight if ctx.needs_input_grad[0] else None
             dw = None
             if ctx.needs_input_grad[1]:
-                out_f, in_f = weight.shape
+                out_f, in_f = g.shape[1], x.shape[1]
                 if out_f <= be.XTY_MAX[0] and in_f <= be.XTY_MAX[1] and x.stride(1) == 1:
                     dw = be.xty(g, x)  # [out, in] = g^T x over the rows
                 else:
@@ -105,21 +115,38 @@ def _tall_linear_fn():
     return TallLinearFn
 
 
+def _functorch_active():
+    """True inside torch.func.vmap / grad / jacrev / functionalize: those need an autograd.Function with a vmap rule."""
+    import torch
+    try:
+        return torch._C._functorch.peek_interpreter_stack() is not None
+    except AttributeError:
+        return False
+
+
+def linear_accelerated():
+    """Whether torch.nn.functional.linear is currently this package's replacement."""
+    return _ORIGINAL_LINEAR is not None
+
+
 def accelerate_linear(enable=True):
     """Route torch.nn.functional.linear (hence every torch.nn.Linear) through TallLinearFn for tall fp32 device matrices.
-    accelerate_linear(False) restores PyTorch's function.  Returns the previous state."""
+    accelerate_linear(False) restores PyTorch's function.  Returns the previous state.  Never called implicitly: see above."""
     global _ORIGINAL_LINEAR
     import torch
     import torch.nn.functional as F
     was = _ORIGINAL_LINEAR is not None
     if enable and not was:
         original, fn = F.linear, _tall_linear_fn()
+        plain = (torch.Tensor, torch.nn.Parameter)
 
         def linear(input, weight, bias=None):  # noqa: A002 -- torch's own parameter names
-            if (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32 and weight.dtype == torch.float32
+            if (type(input) is torch.Tensor and input.is_cuda and input.dim() == 2 and input.dtype == torch.float32
+                    and type(weight) in plain and weight.dtype == torch.float32 and weight.dim() == 2
                     and input.shape[0] >= LINEAR_MIN_ROWS and torch.is_grad_enabled() and (input.requires_grad or weight.requires_grad)
-                    and (bias is None or bias.dtype == torch.float32) and not torch.cuda.is_current_stream_capturing()
-                    and not torch.is_autocast_enabled() and not torch.compiler.is_compiling() and type(input) is torch.Tensor):
+                    and (bias is None or (type(bias) in plain and bias.dtype == torch.float32))
+                    and not torch.cuda.is_current_stream_capturing() and not torch.is_autocast_enabled()
+                    and not torch.compiler.is_compiling() and not _functorch_active()):
                 return fn.apply(input, weight, bias)
             return original(input, weight, bias)
 

@@ -122,3 +122,48 @@ def test_autograd_layer_through_registered_ops(monkeypatch):
         out.square().sum().backward()
         res.append((out.detach().clone(), x.grad.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.gpu
+def test_plan_handle_keeps_its_owner_and_goes_stale_with_it():
+    """a plan travels through the dispatcher as an address; the autograd node of edge_softmax keeps the owner alive,
+    and a handle whose owner is gone is refused on the Python side instead of being dereferenced in C++."""
+    import gc
+    dev = torch.device("cuda:0")
+    src, dst = random_graph(300, 300, 4000, seed=3)
+    g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), 300, 300, idtype=torch.int32, device=dev)
+    csc = g._index.csc()
+    h = torch_ops.softmax_plan_handle(csc)
+    if h:
+        assert torch_ops.plan_owner(h) is csc.softmax_plan()
+    z = torch.randn(4000, 2, 1, device=dev, requires_grad=True)
+    a = torch.ops.mi355x_graph.edge_softmax_fwd(csc.indptr, csc.indices, csc.eids, csc.num_cols, z, h)
+    if h:
+        assert a.grad_fn is not None
+    del g, csc
+    gc.collect()
+    a.sum().backward()  # the node holds the plan: nothing was freed under it
+    assert z.grad is not None and bool(torch.isfinite(z.grad).all())
+    del a
+    gc.collect()
+    if h:
+        with pytest.raises(mg.DGLError):
+            torch_ops.plan_owner(h)
+
+
+@pytest.mark.gpu
+def test_ops_run_on_the_device_of_their_tensors_not_the_current_one():
+    """every op in csrc/torch_bind.cpp makes its tensors' device current for the call (several GPUs in one process)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs in one process")
+    dev = torch.device("cuda:1")
+    src, dst = random_graph(200, 200, 3000, seed=5)
+    g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), 200, 200, idtype=torch.int32, device=dev)
+    csc = g._index.csc()
+    x = torch.rand(200, 16, device=dev)
+    with torch.cuda.device(0):
+        out, _, _ = torch.ops.mi355x_graph.gspmm(csc.indptr, csc.indices, csc.eids, csc.num_cols, "copy_lhs", "sum", x, None)
+        deg = torch.ops.mi355x_graph.in_degrees(csc.indptr)
+    assert out.device == dev and deg.device == dev
+    ref = torch.zeros(200, 16, device=dev).index_add_(0, torch.from_numpy(dst).to(dev), x[torch.from_numpy(src).to(dev)])
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
