@@ -27,9 +27,13 @@ The JSON line also carries
                 package's -- timed right after the headline loop.  The headline (default) model computes the same function
                 with this package's dense-side forms: a SAGE layer as one autograd node and one GEMM on [h | neigh], fused
                 relu+dropout, the loss tail on the training rows only (DESIGN 6);
-  epoch_ms_plain_model_accelerated_linear   the same unmodified modules as `import dgl` runs them by default: torch.nn.Linear's
-                backward on tall matrices through this package's column-sum / X^T Y kernels (mi355x_graph.utils.accelerate_linear();
-                epoch_ms_plain_model is measured with it switched off = MGX_ACCELERATE_LINEAR=0);
+  value_reference_modules / ms_per_step_reference_modules   the same unmodified modules with the OPT-IN switch a user of an
+                unmodified script is told to set (MGX_ACCELERATE_LINEAR=1 == mi355x_graph.utils.accelerate_linear()): torch.nn.Linear's
+                backward on tall matrices through this package's column-sum / X^T Y kernels; `..._torch_linear` = nothing patched
+                (== epoch_ms_plain_model); `reference_modules` records which state produced which number;
+  secondary     the other BASELINE configs timed in this same run (dgl-0.5-benchmark_amd/secondary_bench.py): arxiv SAGE, the 2 x 8-head
+                and the script-default 3 x 1-head reddit GATs, molhiv GCN eager + captured -- ms_per_step, steps and the roofline
+                entry (SURVEY 8d bytes / live HIP-event mean) of each one's dominant hot-path call;
   cpu_baseline  the CPU oracle (OpenMP port of DGL's CPU algorithm) timed on the host cores on the g-SpMMs of one epoch
                 (rank 0, N = 1 only, bounded to ~30 s).
 """
@@ -265,6 +269,8 @@ def main():
     p.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic = null)")
     p.add_argument("--no-controls", action="store_true", help="skip the control graphs (roofline.controls)")
     p.add_argument("--no-plain", action="store_true", help="skip the plain-torch-module epoch (epoch_ms_plain_model)")
+    p.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE configs (the `secondary` block: arxiv SAGE, reddit GATs, molhiv)")
+    p.add_argument("--no-variants", action="store_true", help="skip the exact variants reported beside the headline (last layer on the loss rows, layer 1 projected first)")
     p.add_argument("--dropout", type=float, default=None, help="override the model's dropout (tests compare N = 1 and N > 1 at 0)")
     p.add_argument("--emulate-ranks", default=None, metavar="P[,P...]",
                    help="N = 1 only: run every rank of a P-way partition of the same graph one at a time on this GPU (mi355x_graph/"
@@ -276,7 +282,7 @@ def main():
                    help="experiment, with --emulate-ranks: PyTorch TunableOp chooses the dense GEMMs of the per-rank shapes in the warm-up")
     args = p.parse_args()
     if args.emulate_ranks is not None:
-        args.no_plain = args.no_controls = args.no_pmc = args.no_cpu_baseline = True
+        args.no_plain = args.no_controls = args.no_pmc = args.no_cpu_baseline = args.no_secondary = True
     elif not args.no_scale_model and args.gpus == 1:
         args.emulate_ranks = "2,4,8"
 
@@ -557,6 +563,11 @@ def main():
                    "schedule": os.environ.get("MGX_SCHEDULE", "auto"), "partition": part_stats,
                    "module_graph": "full_graph.GraphSAGE (default form): a SAGE layer as ONE GEMM on [h | mean_agg(h)], the same form on "
                                    "one GPU and on every rank of a partition (dist.DistSageMeanCatFn: halo exchange inside the layer)",
+                   "value_is": "`value` / `ms_per_step`: this package's own module graph (module_graph above) -- same function, loss and gradients as "
+                               "the reference's modules (tests/test_next_rows_gpu.py), all five aggregations over every edge.  "
+                               "`value_reference_modules` / `ms_per_step_reference_modules`: the reference's UNMODIFIED module graph "
+                               "(main_dgl_product_sage.py:15-99: torch.nn.Linear x 2 + add, F.relu, nn.Dropout, log_softmax over all nodes) with only "
+                               "update_all() from this package; see `reference_modules` for the torch.nn.functional.linear state of each number",
                    "dropout": cfg["dropout"],
                    "dense_gemm_selection": tunable.status()},
     }
@@ -573,6 +584,8 @@ def main():
         psteps = min(args.steps, 10)
         pel, ploss, _ = timed(make_step(pm, popt, None), psteps, min(args.warmup, 3), False)
         line["epoch_ms_plain_model"] = round(pel / psteps * 1e3, 3)
+        line["ms_per_step_reference_modules_torch_linear"] = round(pel / psteps * 1e3, 3)
+        line["value_reference_modules_torch_linear"] = agg_edges / (pel / psteps)
         line["plain_model"] = {"modules": "torch.nn.Linear, F.relu, nn.Dropout, fc_self(h) + fc_neigh(neigh) as two GEMMs and an "
                                           "add (main_dgl_product_sage.py:15-99); update_all() by this package",
                                "steps": psteps, "final_loss": ploss,
@@ -587,10 +600,21 @@ def main():
             popt = torch.optim.Adam(pm.parameters(), lr=cfg["lr"])
             pel2, ploss2, _ = timed(make_step(pm, popt, None), psteps, min(args.warmup, 3), False)
             line["epoch_ms_plain_model_accelerated_linear"] = round(pel2 / psteps * 1e3, 3)
-            line["plain_model"]["accelerated_linear"] = {"what": "what `import dgl` does by default (mi355x_graph.utils.accelerate_linear(); "
-                                                                 "MGX_ACCELERATE_LINEAR=0 opts out): same modules, same script; F.linear's "
+            line["plain_model"]["accelerated_linear"] = {"what": "OPT-IN since round 5 (MGX_ACCELERATE_LINEAR=1 or mi355x_graph.utils.accelerate_linear(); "
+                                                                 "`import dgl` alone leaves torch alone): same modules, same script; F.linear's "
                                                                  "backward on tall matrices by mgx_column_sum / mgx_xty",
                                                          "final_loss": ploss2}
+            line["ms_per_step_reference_modules"] = round(pel2 / psteps * 1e3, 3)
+            line["value_reference_modules"] = agg_edges / (pel2 / psteps)
+            line["reference_modules"] = {
+                "module_graph": "full_graph.GraphSAGE(plain=True) == main_dgl_product_sage.py:15-99 module for module; the step is main_dgl_product_sage.py:101-110",
+                "ms_per_step_reference_modules": {"linear": "MGX_ACCELERATE_LINEAR=1 (opt-in; what INTEGRATION.md tells the user of an unmodified script to "
+                                                            "set): torch.nn.functional.linear's BACKWARD on >= 65536-row fp32 matrices by mgx_xty / "
+                                                            "mgx_column_sum, forward untouched", "final_loss": ploss2, "steps": psteps},
+                "ms_per_step_reference_modules_torch_linear": {"linear": "nothing patched: `import dgl` as it is by default; PyTorch's own Linear backward "
+                                                                         "(19 ms of it one bias-gradient reduce_kernel, profiles/r03_plain_epoch_timeline.txt)",
+                                                               "final_loss": ploss, "steps": psteps},
+                "accelerate_linear_during_headline_loop": bool(was_accelerated)}
             del pm, popt
         finally:
             mutils.accelerate_linear(was_accelerated)
@@ -599,7 +623,7 @@ def main():
         # MGX_SAGE_SPARSE_LAST=1): same forward, same gradients -- the output gradient is zero outside the 8 % training rows, so the
         # dense gradients are taken on those rows and the reversed aggregation skips the rows that are zero by construction.  Off in
         # the headline (value / ms_per_step) so that every one of its five aggregations gathers every source row; reported beside it.
-        if os.environ.get("MGX_SAGE_SPARSE_LAST", "0") != "1":
+        if os.environ.get("MGX_SAGE_SPARSE_LAST", "0") != "1" and not args.no_variants:
             os.environ["MGX_SAGE_SPARSE_LAST"] = "1"
             try:
                 sm = make_model()
@@ -616,7 +640,7 @@ def main():
         # MGX_SAGE_L1_PROJECT_FIRST=1): mean_agg(x) W^T = mean_agg(x W^T), so the layer-1 aggregation runs at 64 columns instead of
         # 100; its weight gradient is taken against the constant mean_agg(x), aggregated once and kept.  Same loss and gradients
         # (test); still five aggregations over every edge per epoch.  NOT the headline: the headline keeps the reference's widths.
-        if os.environ.get("MGX_SAGE_L1_PROJECT_FIRST", "0") != "1":
+        if os.environ.get("MGX_SAGE_L1_PROJECT_FIRST", "0") != "1" and not args.no_variants:
             os.environ["MGX_SAGE_L1_PROJECT_FIRST"] = "1"
             try:
                 lm = make_model()
@@ -645,6 +669,14 @@ def main():
                 finally:
                     os.environ["MGX_SAGE_L1_PROJECT_FIRST"] = os.environ["MGX_SAGE_SPARSE_LAST"] = "0"
                 torch.cuda.empty_cache()
+
+    # ---- the other BASELINE configurations, driver-timed in this same run: arxiv SAGE, the 8-head and the
+    # script-default reddit GATs, molhiv GCN eager + captured -- each with ms_per_step and the roofline entry of its dominant call
+    if single and args.dataset == "products" and not args.no_secondary and args.scale == 1.0:
+        import secondary_bench
+        model = opt = None
+        torch.cuda.empty_cache()
+        line["secondary"] = secondary_bench.run(device, progress=lambda msg: print("[bench] " + msg, file=sys.stderr, flush=True))
 
     # ---- the 2 / 4 / 8-GPU curve as a MODEL measured on this one GPU: every rank of the partitioned program run here, one at a
     # time, exchanges priced per xGMI link (scale_model.py; never a measured multi-GPU number, and labelled so)

@@ -25,6 +25,29 @@ PROFILE = None  # set to a list by bench.py to collect per-launch HIP-event timi
 TILE_MIN_WIDTH = int(os.environ.get("MGX_TILE_MIN_WIDTH", 4))  # rows of 4 .. 20 columns take the 16-column tile pass, 24 .. 44 the 32-column one, wider the 64-column one
 
 
+class timed_call(object):
+    """`with timed_call(dev, kernel=..., **meta):` around ONE C-ABI call: when bench.py has set PROFILE to a list, HIP events on the
+    launch stream bracket the call and a record {kernel, meta..., start, end} is appended (the g-SpMM entry points below build
+    theirs inline, with the same keys).  Costs one attribute read otherwise."""
+    __slots__ = ("rec", "dev")
+
+    def __init__(self, dev, **meta):
+        self.rec, self.dev = (meta if PROFILE is not None else None), dev
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec["start"] = torch.cuda.Event(enable_timing=True)
+            self.rec["end"] = torch.cuda.Event(enable_timing=True)
+            self.rec["start"].record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None and exc[0] is None and PROFILE is not None:
+            self.rec["end"].record(torch.cuda.current_stream(self.dev))
+            PROFILE.append(self.rec)
+        return False
+
+
 def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -547,7 +570,8 @@ class HipBackend(object):
         dev = self._check_dev(L, R)
         out = torch.empty((nnz, out_len), dtype=torch.float32, device=dev)
         lib = _lib.lib()
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), timed_call(dev, kernel="sddmm", op=op, out_len=out_len, l_len=l_len, r_len=r_len, nnz=nnz,
+                                                n_src=graph_index.num_src, n_dst=graph_index.num_dst, targets=lhs_target + rhs_target):
             if graph_index.has_format("coo") or not graph_index.has_format("csc"):
                 src, dst = graph_index.coo()
                 self._check_dev(src, L, R)
@@ -642,7 +666,7 @@ class HipBackend(object):
             tp = tiles[0]
             ws = self._gat_ws([tp.base], H, F, dev)
             pack = self._gat_pack_ws(csc, H, F, dev)
-            with torch.cuda.device(dev):
+            with torch.cuda.device(dev), timed_call(dev, kernel="gat_fwd", form="tile", H=H, F=F, nnz=csc.nnz, n_src=csc.num_cols, n_dst=csc.num_rows):
                 _lib.check(_lib.lib().mgx_gat_tile_fwd(ctypes.byref(csc.c_struct()), self._plan_ptr(tp.base), ctypes.byref(tp.c_struct()),
                                                        H, F, _ptr(feat3d), _ptr(el2d), _ptr(er2d), ctypes.c_float(slope), ctypes.c_float(p),
                                                        ctypes.c_uint64(seed), _ptr(out), _ptr(nstat), _ptr(ws), _ptr(pack), _stream(dev)))
@@ -650,7 +674,7 @@ class HipBackend(object):
         plan = csc.plan()
         ws = self._gat_ws([plan], H, F, dev)
         pack = self._gat_pack_ws(csc, H, F, dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), timed_call(dev, kernel="gat_fwd", form="row", H=H, F=F, nnz=csc.nnz, n_src=csc.num_cols, n_dst=csc.num_rows):
             _lib.check(_lib.lib().mgx_gat_fused_fwd(ctypes.byref(csc.c_struct()), self._plan_ptr(plan), H, F, _ptr(feat3d), _ptr(el2d),
                                                     _ptr(attn_l), _ptr(er2d), ctypes.c_float(slope), ctypes.c_float(p), ctypes.c_uint64(seed),
                                                     _ptr(out), _ptr(nstat), _ptr(ws), _ptr(pack), _stream(dev)))
@@ -683,7 +707,8 @@ class HipBackend(object):
                 d_feat = d_el = None
             ws = self._gat_ws([t_dst.base, t_src.base], H, F, dev)
             pack = self._gat_pack_ws(csc, H, F, dev)
-            with torch.cuda.device(dev):
+            with torch.cuda.device(dev), timed_call(dev, kernel="gat_bwd", form="tile", H=H, F=F, nnz=csc.nnz, n_src=csc.num_cols, n_dst=csc.num_rows,
+                                                    source_walk=bool(need_src)):
                 _lib.check(_lib.lib().mgx_gat_tile_bwd(ctypes.byref(csc.c_struct()), self._plan_ptr(t_dst.base), ctypes.byref(t_dst.c_struct()),
                                                        ctypes.byref(csr.c_struct()), self._plan_ptr(t_src.base), ctypes.byref(t_src.c_struct()),
                                                        H, F, _ptr(feat3d), _ptr(el2d), ctypes.c_float(slope), ctypes.c_float(p),
@@ -693,7 +718,8 @@ class HipBackend(object):
         p_dst, p_src = csc.plan(), csr.plan()
         ws = self._gat_ws([p_dst, p_src], H, F, dev)
         pack = self._gat_pack_ws(csc, H, F, dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), timed_call(dev, kernel="gat_bwd", form="row", H=H, F=F, nnz=csc.nnz, n_src=csc.num_cols, n_dst=csc.num_rows,
+                                                source_walk=bool(need_src)):
             _lib.check(_lib.lib().mgx_gat_fused_bwd(ctypes.byref(csc.c_struct()), self._plan_ptr(p_dst), ctypes.byref(csr.c_struct()),
                                                     self._plan_ptr(p_src), H, F, _ptr(feat3d), _ptr(el2d), _ptr(attn_l), ctypes.c_float(slope),
                                                     ctypes.c_float(p), ctypes.c_uint64(seed), _ptr(out3d), _ptr(d_out3d), _ptr(nstat),
@@ -751,7 +777,7 @@ class HipBackend(object):
         n = offsets.shape[0] - 1
         out = torch.empty((n, x2d.shape[1]), dtype=torch.float32, device=dev)
         arg = torch.empty((n, x2d.shape[1]), dtype=torch.int64, device=dev) if want_arg else None
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), timed_call(dev, kernel="segment_reduce", reduce=reduce, segments=int(n), rows=int(x2d.shape[0]), D=int(x2d.shape[1])):
             _lib.check(_lib.lib().mgx_segment_reduce(n, _ptr(offsets), x2d.shape[1], REDUCE[reduce], _ptr(x2d), _ptr(out), _ptr(arg), _stream(dev)))
         return out, arg
 

@@ -363,7 +363,13 @@ def raw_gspmm(csr, op, reduce, X, Y, want_arg=False):
     if handle is None:
         handle = plan_handle(csr)
     try:
-        out, au, ae = torch.ops.mi355x_graph.gspmm(csr.indptr, csr.indices, csr.eids, csr.num_cols, op, reduce, X, Y, handle, flags)
+        if sparse.PROFILE is not None and csr.indptr.is_cuda:  # bench.py: the same record sparse.gspmm_raw's route appends
+            width = max(t.numel() // max(int(t.shape[0]), 1) for t in (X, Y) if t is not None)
+            with sparse.timed_call(csr.indptr.device, op=op, reduce=reduce, out_len=width, n_rows=csr.num_rows, n_cols=csr.num_cols,
+                                   nnz=csr.nnz, accumulate=False, route="torch.ops", short_rows=bool(flags)):
+                out, au, ae = torch.ops.mi355x_graph.gspmm(csr.indptr, csr.indices, csr.eids, csr.num_cols, op, reduce, X, Y, handle, flags)
+        else:
+            out, au, ae = torch.ops.mi355x_graph.gspmm(csr.indptr, csr.indices, csr.eids, csr.num_cols, op, reduce, X, Y, handle, flags)
     except DGLError:
         raise
     except RuntimeError as err:  # TORCH_CHECK in csrc/torch_bind.cpp: the operator surface raises DGLError (SURVEY 8b "Errors")
@@ -377,11 +383,16 @@ def raw_gsddmm(gidx, op, L, R, lhs_target="u", rhs_target="v"):
     if not NATIVE or (L is not None and R is not None and L.shape[1:] != R.shape[1:]) or (L if L is not None else R).dtype != torch.float32:
         return sparse.gsddmm_raw(gidx, op, L, R, lhs_target, rhs_target)
     try:
-        if gidx.has_format("coo") or not gidx.has_format("csc"):  # the same choice HipBackend.sddmm makes
-            src, dst = gidx.coo()
-            return torch.ops.mi355x_graph.gsddmm_coo(src, dst, gidx.num_src, gidx.num_dst, op, L, R, lhs_target, rhs_target)
-        csc = gidx.csc()
-        return torch.ops.mi355x_graph.gsddmm(csc.indptr, csc.indices, csc.eids, csc.num_cols, op, L, R, lhs_target, rhs_target, plan_handle(csc))
+        ref = L if L is not None else R
+        width = lambda x: 0 if x is None else x.numel() // max(int(x.shape[0]), 1)  # noqa: E731
+        with sparse.timed_call(ref.device, kernel="sddmm", op=op, out_len=(width(ref) // int(ref.shape[-1]) if op == "dot" else width(ref)),
+                               l_len=width(L), r_len=width(R), nnz=gidx.num_edges(), n_src=gidx.num_src, n_dst=gidx.num_dst,
+                               targets=lhs_target + rhs_target, route="torch.ops"):
+            if gidx.has_format("coo") or not gidx.has_format("csc"):  # the same choice HipBackend.sddmm makes
+                src, dst = gidx.coo()
+                return torch.ops.mi355x_graph.gsddmm_coo(src, dst, gidx.num_src, gidx.num_dst, op, L, R, lhs_target, rhs_target)
+            csc = gidx.csc()
+            return torch.ops.mi355x_graph.gsddmm(csc.indptr, csc.indices, csc.eids, csc.num_cols, op, L, R, lhs_target, rhs_target, plan_handle(csc))
     except DGLError:
         raise
     except RuntimeError as err:

@@ -1,0 +1,67 @@
+"""the D = 100 layer-1 aggregation as TWO launches over compact column blocks of the constant input --
+X[:, :64] (256-byte rows) and X[:, 64:100] (144-byte rows, 9 of 16 lanes) -- writing the two column ranges of one [N, 100] output,
+against the one launch over 400-byte rows (4.125 lines per edge).  Kill criterion: keep only if the pair is <= 4.0 ms against ~4.75.
+
+  python experiments/exp_d100_split.py > gpurun_out/r05_d100_split.txt
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "dgl-0.5-benchmark_amd"))
+import torch  # noqa: E402
+
+import dgl  # noqa: E402
+import kernel_controls as kc  # noqa: E402
+from mi355x_graph import _lib, sparse  # noqa: E402
+
+p = argparse.ArgumentParser()
+p.add_argument("--scale", type=float, default=1.0)
+p.add_argument("--reps", type=int, default=8)
+args = p.parse_args()
+dev = torch.device("cuda:0")
+n, (src, dst) = kc.control_edges("products", dev, args.scale)
+g = dgl.graph((src, dst), num_nodes=n).int().formats(["csc"]).to(dev)
+del src, dst
+csc = g._index.csc()
+be = sparse.backend_for(csc.indptr)
+print("# products graph x %g: N = %d, E = %d; copy_u/mean of a [N, 100] input" % (args.scale, n, csc.nnz))
+
+
+def timed(fn, reps=args.reps, discard=2):
+    ts = []
+    for i in range(reps + discard):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        b.synchronize()
+        if i >= discard:
+            ts.append(a.elapsed_time(b))
+    return sum(ts) / len(ts)
+
+
+x = torch.rand(n, 100, device=dev)
+ref = torch.empty(n, 100, device=dev)
+ms0 = timed(lambda: be.spmm_copy_u_strided(csc, "mean", x, ref))
+print("one launch, 400-byte rows:                         %.3f ms  (%s)" % (ms0, _lib.lib().mgx_last_spmm_kernel().decode()))
+for cut in (64, 48, 52, 32):
+    xa, xb = x[:, :cut].contiguous(), x[:, cut:].contiguous()
+    out = torch.empty(n, 100, device=dev)
+
+    def pair():
+        be.spmm_copy_u_strided(csc, "mean", xa, out[:, :cut])
+        be.spmm_copy_u_strided(csc, "mean", xb, out[:, cut:])
+    ms = timed(pair)
+    ma = timed(lambda: be.spmm_copy_u_strided(csc, "mean", xa, out[:, :cut]))
+    mb = timed(lambda: be.spmm_copy_u_strided(csc, "mean", xb, out[:, cut:]))
+    err = float((out - ref).abs().max() / ref.abs().max())
+    print("two launches, compact blocks of %2d + %2d columns:     %.3f ms  (%.3f + %.3f alone), max |diff| / max |ref| = %.1e"
+          % (cut, 100 - cut, ms, ma, mb, err))
+# padded to 128 columns = 4 whole lines per row (compact), for reference
+xp = torch.zeros(n, 128, device=dev)
+xp[:, :100] = x
+outp = torch.empty(n, 128, device=dev)
+print("one launch, rows padded to 128 columns (4 lines):    %.3f ms" % timed(lambda: be.spmm_copy_u_strided(csc, "mean", xp, outp)))
+print("# kill criterion (VERDICT r04 item 4): keep the split only if the pair is <= 4.0 ms")
