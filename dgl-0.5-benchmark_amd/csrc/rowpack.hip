@@ -1,0 +1,225 @@
+// rowpack.hip -- halo rows as bitmaps + packed values (round 5; the multi-GPU exchange of mi355x_graph/dist.py).
+//
+// The hidden layers of the reference's GraphSAGE feed relu + dropout(0.5) outputs into the next aggregation
+// (main_dgl_product_sage.py:93-96): ~75 % of a boundary row is exact zeros.  A row therefore crosses xGMI as a 64-bit mask per 64
+// columns plus its non-zero values (72 bytes on average instead of 256 at D = 64), and the gradient of a halo row comes back as
+// the values under that SAME mask only (64 bytes, no mask): the owner multiplies whatever arrives at a zero position by relu's /
+// dropout's zero anyway, so nothing that is dropped was ever used.  Exact in fp32: values are moved, never rounded.
+//
+// Bit order.  Lanes run along the feature dimension with 16-byte accesses as everywhere in this library: lane l of the G = min(16,
+// D / 4) lanes of a row block holds columns 4 l .. 4 l + 3 of a 64-column block.  Bit (c * G + l) of the block's mask stands for
+// column 4 l + c -- the order four wave ballots deliver -- and the packed values of a row are stored in increasing bit order,
+// block after block.  Pack and unpack agree on it; nobody else reads the packed form.
+//
+//   mgx_rows_pack_count    masks + per-row counts of x[idx[i], :] != 0
+//   mgx_rows_mask_count    per-row counts of given masks (the receiving side)
+//   mgx_rows_pack_values   values of x[idx[i], :] under given masks, row i from offsets[i] on
+//   mgx_rows_unpack        dense rows (zeros elsewhere) from masks + offsets + values
+// All streaming passes at one 16-byte access per lane; rows of 4 .. 256 columns, D % 4 == 0.
+#include "common.h"
+
+namespace mgx {
+namespace {
+
+constexpr int kMaxBlocks = 4;  // 64-column blocks per row: D <= 256
+
+// lanes per row block and rows per wave for a row width
+struct RowShape {
+  int G;        // lanes per 64-column block (16, or D / 4 rounded up to a power of two when D < 64)
+  int nblk;     // ceil(D / 64)
+};
+static inline RowShape row_shape(int64_t D) {
+  RowShape s;
+  s.nblk = (int)((D + 63) / 64);
+  int g = 1;
+  while (g * 4 < D && g < 16) g <<= 1;
+  s.G = g;
+  return s;
+}
+
+// 16 c + l bit of the wave-wide ballots belongs to (row group `sub`, lane l, component c): the mask of MY row group's block
+template <int G>
+__device__ __forceinline__ uint64_t group_mask(const uint64_t (&b)[4], int sub) {
+  constexpr uint64_t ones = G >= 64 ? ~0ull : ((1ull << G) - 1ull);
+  uint64_t m = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) m |= ((b[c] >> (sub * G)) & ones) << (c * G);
+  return m;
+}
+
+// MODE 0: masks + counts from x != 0.   MODE 1: values of x under given masks.
+template <typename Idx, int G, int MODE>
+__global__ __launch_bounds__(kBlock) void rows_pack_kernel(int64_t n, const Idx* __restrict__ idx, int D, int nblk, const float* __restrict__ x,
+                                                           int64_t ldx, uint64_t* __restrict__ masks, int32_t* __restrict__ counts,
+                                                           const int64_t* __restrict__ offsets, float* __restrict__ values) {
+  constexpr int RPW = kWave / G;  // rows per wave-instruction
+  const int lane = threadIdx.x & (kWave - 1);
+  const int l = lane % G, sub = lane / G;
+  const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t base = wave_id * RPW; base < n; base += n_waves * RPW) {  // wave-uniform trip count (ballots inside)
+    const int64_t i = base + sub;
+    const bool live = i < n;
+    const int64_t r = live ? (idx ? (int64_t)idx[i] : i) : 0;
+    int total = 0;
+    int64_t off = (MODE == 1 && live) ? offsets[i] : 0;
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int c0 = blk * 64 + l * 4;
+      const bool have = live && c0 < D;
+      v4f v = (v4f)(0.f);
+      if (have) v = *reinterpret_cast<const v4f*>(x + r * ldx + c0);
+      if (MODE == 0) {
+        uint64_t b[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) b[c] = __ballot(have && v[c] != 0.f);
+        const uint64_t m = group_mask<G>(b, sub);
+        if (live && l == 0) masks[i * nblk + blk] = m;
+        total += __popcll(m);
+      } else {
+        const uint64_t m = live ? masks[i * nblk + blk] : 0ull;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int bit = c * G + l;
+          if ((m >> bit) & 1ull) values[off + __popcll(m & ((1ull << bit) - 1ull))] = v[c];
+        }
+        off += __popcll(m);
+      }
+    }
+    if (MODE == 0 && live && l == 0) counts[i] = total;
+  }
+}
+
+template <int G>
+__global__ __launch_bounds__(kBlock) void rows_unpack_kernel(int64_t n, int D, int nblk, const uint64_t* __restrict__ masks,
+                                                             const int64_t* __restrict__ offsets, const float* __restrict__ values,
+                                                             float* __restrict__ out, int64_t ldo) {
+  constexpr int RPW = kWave / G;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int l = lane % G, sub = lane / G;
+  const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t base = wave_id * RPW; base < n; base += n_waves * RPW) {
+    const int64_t i = base + sub;
+    if (i >= n) continue;
+    int64_t off = offsets[i];
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int c0 = blk * 64 + l * 4;
+      const uint64_t m = masks[i * nblk + blk];
+      if (c0 < D) {
+        v4f v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int bit = c * G + l;
+          v[c] = ((m >> bit) & 1ull) ? values[off + __popcll(m & ((1ull << bit) - 1ull))] : 0.f;
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(out + i * ldo + c0));
+      }
+      off += __popcll(m);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void rows_mask_count_kernel(int64_t n, int nblk, const uint64_t* __restrict__ masks, int32_t* __restrict__ counts) {
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    int t = 0;
+    for (int b = 0; b < nblk; ++b) t += __popcll(masks[i * nblk + b]);
+    counts[i] = t;
+  }
+}
+
+static int64_t stream_blocks(int64_t n, int rows_per_wave) {
+  int64_t blocks = (n + (int64_t)rows_per_wave * kWavesPerBlock - 1) / ((int64_t)rows_per_wave * kWavesPerBlock);
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  return blocks < 1 ? 1 : blocks;
+}
+
+static int32_t check_shape(const char* what, int64_t n, int64_t D, int64_t ld, const void* p) {
+  MGX_CHECK_ARG(n >= 0 && D > 0 && ld >= D, "%s: negative sizes or a row stride below D", what);
+  if (D % 4 || D > 64 * kMaxBlocks || ld % 4 || (uintptr_t)p % 16)
+    MGX_UNSUPPORTED("%s: rows of 4 .. %d columns with D %% 4 == 0, strides in multiples of 4 floats, 16-byte aligned pointers", what, 64 * kMaxBlocks);
+  return MGX_OK;
+}
+
+template <typename Idx, int MODE>
+static int32_t pack_launch(int64_t n, const void* idx, int64_t D, const float* x, int64_t ldx, uint64_t* masks, int32_t* counts,
+                           const int64_t* offsets, float* values, hipStream_t s) {
+  const RowShape sh = row_shape(D);
+  const dim3 grid((unsigned)stream_blocks(n, kWave / sh.G)), block(kBlock);
+#define MGX_PK(GG) hipLaunchKernelGGL((rows_pack_kernel<Idx, GG, MODE>), grid, block, 0, s, n, (const Idx*)idx, (int)D, sh.nblk, x, ldx, masks, counts, offsets, values)
+  switch (sh.G) {
+    case 1: MGX_PK(1); break;
+    case 2: MGX_PK(2); break;
+    case 4: MGX_PK(4); break;
+    case 8: MGX_PK(8); break;
+    default: MGX_PK(16); break;
+  }
+#undef MGX_PK
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+}  // namespace
+}  // namespace mgx
+
+extern "C" int64_t mgx_rows_mask_words(int64_t D) { return D > 0 ? (D + 63) / 64 : 0; }
+
+extern "C" int32_t mgx_rows_pack_count(int64_t n, const void* idx, int32_t idx_bits, int64_t D, const float* x, int64_t x_stride,
+                                       uint64_t* masks, int32_t* counts, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(idx == nullptr || idx_bits == 32 || idx_bits == 64, "mgx_rows_pack_count: idx_bits must be 32 or 64");
+  if (int32_t st = check_shape("mgx_rows_pack_count", n, D, x_stride, x)) return st;
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(x && masks && counts, "mgx_rows_pack_count: NULL pointer");
+  if (idx && idx_bits == 64) return pack_launch<int64_t, 0>(n, idx, D, x, x_stride, masks, counts, nullptr, nullptr, (hipStream_t)stream);
+  return pack_launch<int32_t, 0>(n, idx, D, x, x_stride, masks, counts, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int32_t mgx_rows_mask_count(int64_t n, int64_t D, const uint64_t* masks, int32_t* counts, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(n >= 0 && D > 0, "mgx_rows_mask_count: negative sizes");
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(masks && counts, "mgx_rows_mask_count: NULL pointer");
+  int64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(rows_mask_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, n, (int)((D + 63) / 64), masks, counts);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_rows_pack_values(int64_t n, const void* idx, int32_t idx_bits, int64_t D, const float* x, int64_t x_stride,
+                                        const uint64_t* masks, const int64_t* offsets, float* values, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(idx == nullptr || idx_bits == 32 || idx_bits == 64, "mgx_rows_pack_values: idx_bits must be 32 or 64");
+  if (int32_t st = check_shape("mgx_rows_pack_values", n, D, x_stride, x)) return st;
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(x && masks && offsets && values, "mgx_rows_pack_values: NULL pointer");
+  uint64_t* m = const_cast<uint64_t*>(masks);
+  if (idx && idx_bits == 64) return pack_launch<int64_t, 1>(n, idx, D, x, x_stride, m, nullptr, offsets, values, (hipStream_t)stream);
+  return pack_launch<int32_t, 1>(n, idx, D, x, x_stride, m, nullptr, offsets, values, (hipStream_t)stream);
+}
+
+extern "C" int32_t mgx_rows_unpack(int64_t n, int64_t D, const uint64_t* masks, const int64_t* offsets, const float* values, float* out,
+                                   int64_t out_stride, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  if (int32_t st = check_shape("mgx_rows_unpack", n, D, out_stride, out)) return st;
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(masks && offsets && out, "mgx_rows_unpack: NULL pointer");  // values may be NULL when every mask is empty
+  const RowShape sh = row_shape(D);
+  const dim3 grid((unsigned)stream_blocks(n, kWave / sh.G)), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+#define MGX_UP(GG) hipLaunchKernelGGL((rows_unpack_kernel<GG>), grid, block, 0, s, n, (int)D, sh.nblk, masks, offsets, values, out, out_stride)
+  switch (sh.G) {
+    case 1: MGX_UP(1); break;
+    case 2: MGX_UP(2); break;
+    case 4: MGX_UP(4); break;
+    case 8: MGX_UP(8); break;
+    default: MGX_UP(16); break;
+  }
+#undef MGX_UP
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}

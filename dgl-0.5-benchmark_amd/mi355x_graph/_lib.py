@@ -51,6 +51,11 @@ SIGNATURES = {
     "mgx_spmm_copy_u_masked": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _vp, _fp, _fp, _fp, _i32, _vp]),
     "mgx_spmm_copy_u_strided": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _i64, _fp, _fp, _i64, _fp, _i32, _vp]),
     "mgx_spmm_tile_copy_u": (_i32, [_csr_p, _vp, _vp, _i32, _fp, _i64, _i64, _fp, _fp, _i64, _fp, _i32, _vp]),
+    "mgx_rows_mask_words": (_i64, [_i64]),
+    "mgx_rows_pack_count": (_i32, [_i64, _vp, _i32, _i64, _fp, _i64, _vp, _vp, _vp]),
+    "mgx_rows_mask_count": (_i32, [_i64, _i64, _vp, _vp, _vp]),
+    "mgx_rows_pack_values": (_i32, [_i64, _vp, _i32, _i64, _fp, _i64, _vp, _vp, _fp, _vp]),
+    "mgx_rows_unpack": (_i32, [_i64, _i64, _vp, _vp, _fp, _fp, _i64, _vp]),
     "mgx_sddmm_coo": (_i32, [_i64, _i64, _i64, _vp, _vp, _i32, _i32, _fp, _fp, _i32, _i32, _i64, _i64, _i64, _i64,
                              _vp, _vp, _fp, _vp]),
     "mgx_sddmm_csr": (_i32, [_csr_p, _vp, _i32, _fp, _fp, _i32, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _fp, _vp]),

@@ -318,17 +318,19 @@ class _Comm(object):
         else:
             dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group)
 
-    def all_to_all_async(self, out, inp, out_splits, in_splits):
+    def all_to_all_async(self, out, inp, out_splits, in_splits, count=True, tag="rows"):
         """Returns a handle whose wait() orders the CURRENT stream after the exchange (RCCL runs it on the
-        process group's own stream, so kernels launched in between overlap with it)."""
+        process group's own stream, so kernels launched in between overlap with it).  count=False: the second message of ONE
+        logical halo exchange (SparseHalo's values after its bitmaps) -- n_exchanges counts exchanges, not messages."""
         emu = emulate.current()
         if emu is not None:
-            self.n_exchanges += 1
-            return emu.all_to_all_async(out, inp, out_splits, in_splits)
+            self.n_exchanges += 1 if count else 0
+            return emu.all_to_all_async(out, inp, out_splits, in_splits, tag=tag)
         if dist.get_backend(self.group) == "gloo":
             self.all_to_all(out, inp, out_splits, in_splits)
+            self.n_exchanges -= 0 if count else 1
             return _Done()
-        self.n_exchanges += 1
+        self.n_exchanges += 1 if count else 0
         work = dist.all_to_all_single(out, inp, out_splits, in_splits, group=self.group, async_op=True)
         if self.trace is None or not out.is_cuda:
             return work
@@ -356,6 +358,128 @@ class _TimedWork(object):
         return ok
 
 
+# ----------------------------------------------------------------------------- sparse halo exchange (round 5)
+SPARSE_HALO = os.environ.get("MGX_SPARSE_HALO", "1") == "1"
+SPARSE_EXCHANGES = [0, 0]  # forward / backward exchanges that took the packed form in this process (tests, bench.py's report)
+
+
+def structural_zeros(t):
+    """True when the caller marked `t` as the output of relu (+ dropout): its zeros are structural -- whoever produced it multiplies
+    the gradient arriving at a zero position by zero (ops.relu_dropout tags its result; torch.relu outputs can be tagged with
+    mark_structural_zeros).  Only then may the halo exchange drop those gradient entries."""
+    return bool(getattr(t, "_mgx_structural_zeros", False))
+
+
+def mark_structural_zeros(t):
+    t._mgx_structural_zeros = True
+    return t
+
+
+def _bounds(splits, device):
+    out, off = [0], 0
+    for c in splits:
+        off += int(c)
+        out.append(off)
+    return torch.tensor(out, dtype=torch.int64, device=device)
+
+
+def _exclusive_scan(counts):
+    off = torch.zeros(counts.shape[0] + 1, dtype=torch.int64, device=counts.device)
+    if counts.shape[0]:
+        torch.cumsum(counts, 0, dtype=torch.int64, out=off[1:])
+    return off
+
+
+class SparseHalo(object):
+    """One layer's halo exchange with the boundary rows as bitmaps + packed non-zeros (csrc/rowpack.hip), both directions:
+
+      forward   masks of the boundary rows -> all_to_all #1 (sizes known: rows x mask words); the value counts per peer are read
+                back ONCE (the only host synchronisation: all_to_all_single takes host sizes) -> values -> all_to_all #2 (async);
+                finish(): dense halo rows for the aggregation kernel, zeros restored
+      backward  the gradient of a halo row travels as the values under the SAME mask (no mask, no size exchange: both sides
+                kept the forward's); finish_back(): dense [send rows, D], zeros elsewhere, for the one copy_u over return_csr
+
+    Valid for inputs whose zeros are structural (see structural_zeros): a gradient entry at a zero position is multiplied by relu's /
+    dropout's zero at the owner, so dropping it changes no result.  Exact: values are moved, never rounded.  At D = 64 and 75 % zeros a
+    row is 8 + 64 bytes forward and 64 bytes back instead of 256 each way."""
+
+    def __init__(self, comm, plan, be, D):
+        self.comm, self.plan, self.be, self.D = comm, plan, be, int(D)
+        dev = plan.send_idx.device
+        if getattr(plan, "_sparse_bounds", None) is None:
+            plan._sparse_bounds = (_bounds(plan.send_splits, dev), _bounds(plan.recv_splits, dev))
+        self.work = self.bwork = None
+
+    def post(self, h):
+        plan, be, comm = self.plan, self.be, self.comm
+        SPARSE_EXCHANGES[0] += 1
+        W = (self.D + 63) // 64
+        idx = plan.send_idx if plan.send_idx.numel() else None
+        if idx is None:
+            self.smask = torch.empty((0, W), dtype=torch.int64, device=h.device)
+            scnt = torch.empty(0, dtype=torch.int32, device=h.device)
+        else:
+            self.smask, scnt = be.rows_pack_count(h, idx)
+        self.rmask = torch.empty((plan.n_halo, W), dtype=torch.int64, device=h.device)
+        w1 = comm.all_to_all_async(self.rmask, self.smask, plan.recv_splits, plan.send_splits, tag="bitmaps")
+        self.soff = _exclusive_scan(scnt)
+        w1.wait()
+        self.roff = _exclusive_scan(be.rows_mask_count(self.rmask, self.D) if plan.n_halo else scnt[:0])
+        sb, rb = plan._sparse_bounds
+        host = torch.cat([self.soff[sb], self.roff[rb]]).cpu().tolist()  # the one host read of the exchange
+        k = len(plan.send_splits) + 1
+        self.s_splits = [host[i + 1] - host[i] for i in range(k - 1)]
+        self.r_splits = [host[k + i + 1] - host[k + i] for i in range(k - 1)]
+        self.total_s, self.total_r = host[k - 1], host[2 * k - 1]
+        svals = (be.rows_pack_values(h, idx, self.smask, self.soff, self.total_s) if idx is not None
+                 else torch.empty(0, dtype=torch.float32, device=h.device))
+        self.rvals = torch.empty(self.total_r, dtype=torch.float32, device=h.device)
+        self._sent = svals  # alive until the exchange has completed
+        self.work = comm.all_to_all_async(self.rvals, svals, self.r_splits, self.s_splits, count=False, tag="values")
+        return self
+
+    def finish(self):
+        """The received halo rows, dense [n_halo, D]."""
+        self.work.wait()
+        self._sent = None
+        out = torch.empty((self.plan.n_halo, self.D), dtype=torch.float32, device=self.rmask.device)
+        if self.plan.n_halo:
+            self.be.rows_unpack(self.rmask, self.roff, self.rvals, self.D, out=out)
+        self.rvals = None
+        return out
+
+    def bytes_forward(self):
+        return 8 * int(self.rmask.numel()) + 4 * self.total_r
+
+    def post_back(self, g_halo):
+        SPARSE_EXCHANGES[1] += 1
+        gv = (self.be.rows_pack_values(g_halo, None, self.rmask, self.roff, self.total_r) if self.plan.n_halo
+              else torch.empty(0, dtype=torch.float32, device=g_halo.device))
+        self.bvals = torch.empty(self.total_s, dtype=torch.float32, device=g_halo.device)
+        self._sent = gv
+        self.bwork = self.comm.all_to_all_async(self.bvals, gv, self.s_splits, self.r_splits, tag="gradient values")
+        return self
+
+    def finish_back(self):
+        """The returned gradient rows, dense [send rows, D] in send_idx order (zeros where the forward row was zero)."""
+        self.bwork.wait()
+        self._sent = None
+        n = int(self.plan.send_idx.shape[0])
+        out = torch.empty((n, self.D), dtype=torch.float32, device=self.bvals.device)
+        if n:
+            self.be.rows_unpack(self.smask, self.soff, self.bvals, self.D, out=out)
+        self.bvals = None
+        return out
+
+
+def sparse_halo_applies(h, plan):
+    """Every rank takes the same decision: the tag is set by the program, the width by the model."""
+    if not SPARSE_HALO or not structural_zeros(h) or h.dim() != 2 or h.dtype != torch.float32:
+        return False
+    be = sparse.backend_for(h)
+    return hasattr(be, "rows_pack_count") and be.rows_pack_supported(h)
+
+
 class DistCopyU(torch.autograd.Function):
     """update_all(copy_u, sum|mean) on a partition with the exchange hidden behind the local work:
 
@@ -371,11 +495,15 @@ class DistCopyU(torch.autograd.Function):
     miss together.  The aggregation itself always runs."""
 
     @staticmethod
-    def forward(ctx, x, plan, comm, reduce, static_cache=None):
+    def forward(ctx, x, plan, comm, reduce, static_cache=None, sparse_exchange=False):
         x = x.contiguous()
         feat = tuple(x.shape[1:])
+        halo_x = None
         if static_cache is not None and static_cache.get("recv") is not None and static_cache.get("version") == x._version:
             recv, work = static_cache["recv"], _Done()
+        elif sparse_exchange and static_cache is None:
+            halo_x = SparseHalo(comm, plan, sparse.backend_for(x), x.shape[1]).post(x)
+            recv, work = None, None
         else:
             send = sparse.gather_rows_raw(x, plan.send_idx)
             recv = torch.empty((plan.n_halo,) + feat, dtype=x.dtype, device=x.device)
@@ -386,10 +514,13 @@ class DistCopyU(torch.autograd.Function):
         # dense_out: the halo aggregation below accumulates into `out` through the raw kernel (a line-padded view would be
         # written at the wrong offsets)
         out, _, _ = sparse.gspmm_raw(plan.loc.csc(), "copy_lhs", "sum", x, None, dst_scale=scale, dense_out=True)
-        work.wait()
+        if halo_x is not None:
+            recv = halo_x.finish()
+        else:
+            work.wait()
         if plan.n_halo:
             sparse.gspmm_raw(plan.halo.csc(), "copy_lhs", "sum", recv, None, dst_scale=scale, accumulate_into=out)
-        ctx.plan, ctx.comm, ctx.reduce = plan, comm, reduce
+        ctx.plan, ctx.comm, ctx.reduce, ctx.halo_x = plan, comm, reduce, halo_x
         return out
 
     @staticmethod
@@ -400,16 +531,23 @@ class DistCopyU(torch.autograd.Function):
         if ctx.reduce == "mean":
             dZ = dZ * plan.inv_deg.view((-1,) + (1,) * (dZ.dim() - 1))
         feat = tuple(dZ.shape[1:])
-        back = torch.empty((plan.send_idx.shape[0],) + feat, dtype=dZ.dtype, device=dZ.device)
         if plan.n_halo:
             g_halo = sparse.gspmm_grad_raw(plan.halo.csr(), dZ)
         else:
             g_halo = torch.empty((0,) + feat, dtype=dZ.dtype, device=dZ.device)
-        work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
+        halo_x = ctx.halo_x
+        if halo_x is not None:
+            halo_x.post_back(g_halo.contiguous())
+        else:
+            back = torch.empty((plan.send_idx.shape[0],) + feat, dtype=dZ.dtype, device=dZ.device)
+            work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
         gx = sparse.gspmm_grad_raw(plan.loc.csr(), dZ, dense_out=True)  # add_returned_rows accumulates into it
-        work.wait()
+        if halo_x is not None:
+            back = halo_x.finish_back()
+        else:
+            work.wait()
         plan.add_returned_rows(gx, back)
-        return gx, None, None, None, None
+        return gx, None, None, None, None, None
 
 
 class DistSageMeanCatFn(torch.autograd.Function):
@@ -424,16 +562,23 @@ class DistSageMeanCatFn(torch.autograd.Function):
     `static_cache`: DistGraph.set_static_input's declaration for the layer-1 input (its halo rows stay resident)."""
 
     @staticmethod
-    def forward(ctx, plan, comm, cat, h, w_self, w_neigh, bias, static_cache):
+    def forward(ctx, plan, comm, cat, h, w_self, w_neigh, bias, static_cache, sparse_exchange=False):
         be = sparse.backend_for(h)
         comm.mark("pack")
+        sparse_exchange = sparse_exchange and static_cache is None  # (decided by the caller on the tensor it holds: DistGraph.sage_mean_layer)
+        halo_x = None
         if static_cache is not None and static_cache.get("recv") is not None and static_cache.get("version") == h._version:
             recv, work = static_cache["recv"], _Done()
         else:
-            # boundary rows packed straight out of the (row-strided) left half of the layer's buffer: mgx_gather_rows_strided
-            send = be.gather_rows(h, plan.send_idx) if plan.send_idx.numel() else h.new_empty((0, h.shape[1]))
-            recv = torch.empty((plan.n_halo, h.shape[1]), dtype=h.dtype, device=h.device)
-            work = comm.all_to_all_async(recv, send, plan.recv_splits, plan.send_splits)
+            if sparse_exchange:
+                # relu + dropout output: the rows travel as bitmaps + non-zeros, their gradients come back under the same bitmaps
+                halo_x = SparseHalo(comm, plan, be, h.shape[1]).post(h)
+                recv, work = None, halo_x.work
+            else:
+                # boundary rows packed straight out of the (row-strided) left half of the layer's buffer: mgx_gather_rows_strided
+                send = be.gather_rows(h, plan.send_idx) if plan.send_idx.numel() else h.new_empty((0, h.shape[1]))
+                recv = torch.empty((plan.n_halo, h.shape[1]), dtype=h.dtype, device=h.device)
+                work = comm.all_to_all_async(recv, send, plan.recv_splits, plan.send_splits)
             if static_cache is not None:
                 static_cache["version"], static_cache["recv"] = h._version, recv
         if not cat.holds(h):  # the layer-1 input lives elsewhere: copied into the left half unless it is the same unmodified tensor
@@ -444,11 +589,16 @@ class DistSageMeanCatFn(torch.autograd.Function):
         cat.generation += 1
         comm.mark("owned-source aggregation")
         be.spmm_copy_u_strided(plan.loc.csc(), "sum", cat.left, cat.right, dst_scale=plan.inv_deg)
-        work.wait()
+        if halo_x is not None:
+            comm.mark("unpack")
+            recv = halo_x.finish()
+        else:
+            work.wait()
         comm.mark("halo-source aggregation")
         if plan.n_halo:
             be.spmm_copy_u_strided(plan.halo.csc(), "sum", recv, cat.right, accumulate=True, dst_scale=plan.inv_deg)
         ctx.plan, ctx.comm, ctx.cat, ctx.generation = plan, comm, cat, cat.generation
+        ctx.halo_x = halo_x
         ctx.save_for_backward(w_self, w_neigh)
         comm.mark("dense")
         from . import ops
@@ -469,12 +619,17 @@ class DistSageMeanCatFn(torch.autograd.Function):
         dh = None
         if need[3]:
             dh_own, dn = ops._rows_dgrad(be, dy, torch.cat([w_self, w_neigh], dim=1), plan.inv_deg, K)  # d h, d neigh / deg: [n_own, K] each
-            back = torch.empty((plan.send_idx.shape[0], K), dtype=dy.dtype, device=dy.device)
+            halo_x = ctx.halo_x
             g_halo = torch.empty((plan.n_halo, K), dtype=dy.dtype, device=dy.device)
             comm.mark("halo-row gradients")
             if plan.n_halo:
                 be.spmm_copy_u_strided(plan.halo.csr(), "sum", dn, g_halo)
-            work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
+            if halo_x is not None:  # the values under the forward's bitmaps only: what lies elsewhere meets relu's / dropout's zero at the owner
+                comm.mark("pack")
+                halo_x.post_back(g_halo)
+            else:
+                back = torch.empty((plan.send_idx.shape[0], K), dtype=dy.dtype, device=dy.device)
+                work = comm.all_to_all_async(back, g_halo, plan.send_splits, plan.recv_splits)
             comm.mark("owned-row reversed aggregation")
             be.spmm_copy_u_strided(plan.loc.csr(), "sum", dn, dh_own, accumulate=True)
         # the parameter gradients need nothing from the peers: formed while the halo-row gradients travel (the scaling model,
@@ -490,13 +645,17 @@ class DistSageMeanCatFn(torch.autograd.Function):
         elif need[6]:
             db = be.column_sum(dy)
         if need[3]:
-            work.wait()
+            if halo_x is not None:
+                comm.mark("unpack")
+                back = halo_x.finish_back()
+            else:
+                work.wait()
             comm.mark("return-add")
             if back.shape[0]:  # row v += the returned rows whose owner is v: copy_u over (owned row -> position in `back`)
                 be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dh_own, accumulate=True)
             dh = dh_own
         comm.mark("dense")
-        return None, None, None, dh, dws, dwn, db, None
+        return None, None, None, dh, dws, dwn, db, None, None
 
 
 class DistSageProjectFirstFn(torch.autograd.Function):
@@ -682,7 +841,8 @@ class DistGraph(DGLGraph):
                 and apply_node_func is None):
             x = self._src_frame[message_func.in_field]
             static = self._static_halo if self._static_halo.get("tensor") is x else None  # declared by set_static_input
-            self._dst_frame[reduce_func.out_field] = DistCopyU.apply(x, self._plan, self._comm, reduce_func.name, static)
+            self._dst_frame[reduce_func.out_field] = DistCopyU.apply(x, self._plan, self._comm, reduce_func.name, static,
+                                                                     static is None and sparse_halo_applies(x, self._plan))
             return
         blk = self._local(self._u_fields(message_func))
         core.update_all(blk, message_func, reduce_func, apply_node_func)
@@ -717,7 +877,7 @@ class DistGraph(DGLGraph):
         if plan.return_csr().num_cols * h.shape[1] * 4 >= (1 << 32) or (plan.n_own + plan.n_halo) * 2 * h.shape[1] * 4 >= (1 << 32):
             return None
         static = self._static_halo if self._static_halo.get("tensor") is h else None
-        return DistSageMeanCatFn.apply(plan, self._comm, cat, h, w_self, w_neigh, bias, static)
+        return DistSageMeanCatFn.apply(plan, self._comm, cat, h, w_self, w_neigh, bias, static, static is None and sparse_halo_applies(h, plan))
 
 
 # ----------------------------------------------------------------------------- training helpers

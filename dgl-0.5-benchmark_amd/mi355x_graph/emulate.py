@@ -144,11 +144,13 @@ class EmuRank(object):
             self._open = self._now()
 
     # ---- collectives (the signatures dist._Comm / dist.all_reduce / dist.broadcast use)
-    def all_to_all_async(self, out, inp, out_splits, in_splits):
+    def all_to_all_async(self, out, inp, out_splits, in_splits, tag="rows"):
+        """tag: what the message carries -- "rows" (dense boundary rows), "bitmaps" / "values" (the two messages of a packed forward
+        exchange, dist.SparseHalo), "gradient values" -- for the byte accounting of the scaling model."""
         self.n_exchanges += 1
         rank = self.rank
         info = {"recv_rows": list(out_splits), "row_bytes": int(out[0].numel() * out.element_size()) if out.shape[0] else
-                int(inp[0].numel() * inp.element_size()) if inp.shape[0] else 0}
+                int(inp[0].numel() * inp.element_size()) if inp.shape[0] else 0, "tag": tag}
         seq = self._post("all_to_all", (inp, list(in_splits)), info)
 
         def finish(payloads):

@@ -541,11 +541,19 @@ def relu_dropout(x, p=0.5, training=True, out=None):
     if (not training or p <= 0.0 or p >= 1.0 or x.dtype != torch.float32 or x.device.type != "cuda" or x.numel() % 4
             or x.device.type not in sparse._BACKENDS
             or (capture_path() and (x.dim() != 2 or x.shape[1] % 4 or x.stride(1) != 1 or x.stride(0) % 4))):
-        return torch.nn.functional.dropout(torch.relu(x), p, training)
+        return _structural_zeros(torch.nn.functional.dropout(torch.relu(x), p, training))
     if out is not None and (x.dim() != 2 or x.shape[1] % 4 or out.shape != x.shape or out.stride(1) != 1 or out.stride(0) % 4
                             or out.requires_grad):
         out = None
-    return ReluDropout.apply(x, p, None if out is None else _Into(out))
+    return _structural_zeros(ReluDropout.apply(x, p, None if out is None else _Into(out)))
+
+
+def _structural_zeros(y):
+    """Tag a relu (+ dropout) output: its zeros are structural -- this node's backward multiplies whatever gradient arrives at a zero
+    position by zero -- which lets a partition's halo exchange send the row as bitmap + non-zeros and take back only the gradient
+    entries under that bitmap (dist.SparseHalo).  A plain attribute on the tensor object: it does not survive further ops."""
+    y._mgx_structural_zeros = True
+    return y
 
 
 class _Into(object):

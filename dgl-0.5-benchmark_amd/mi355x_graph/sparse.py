@@ -976,6 +976,53 @@ class HipBackend(object):
                                                        _ptr(eid), _stream(dev)))
         return src, eid, counts
 
+    # ---- halo rows as bitmaps + packed values (csrc/rowpack.hip; dist.SparseHalo)
+    ROWPACK_MAX_D = 256
+
+    def rows_pack_supported(self, x2d):
+        return (x2d.dim() == 2 and x2d.dtype == torch.float32 and x2d.stride(1) == 1 and x2d.shape[1] % 4 == 0
+                and 4 <= x2d.shape[1] <= self.ROWPACK_MAX_D and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0)
+
+    def rows_pack_count(self, x2d, idx):
+        """(masks [n, ceil(D / 64)] int64 bit patterns of x2d[idx[i], :] != 0, counts [n] int32); idx None = every row in order."""
+        dev = self._check_dev(x2d, idx)
+        n = int(x2d.shape[0] if idx is None else idx.shape[0])
+        D = int(x2d.shape[1])
+        masks = torch.empty((n, (D + 63) // 64), dtype=torch.int64, device=dev)
+        counts = torch.empty(n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_rows_pack_count(n, _ptr(idx), 0 if idx is None else (32 if idx.dtype == torch.int32 else 64), D, _ptr(x2d),
+                                                      x2d.stride(0), _ptr(masks), _ptr(counts), _stream(dev)))
+        return masks, counts
+
+    def rows_mask_count(self, masks, D):
+        dev = self._check_dev(masks)
+        counts = torch.empty(masks.shape[0], dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_rows_mask_count(masks.shape[0], int(D), _ptr(masks), _ptr(counts), _stream(dev)))
+        return counts
+
+    def rows_pack_values(self, x2d, idx, masks, offsets, total):
+        """The values of x2d[idx[i], :] under masks[i], row i from offsets[i] on, as one [total] vector."""
+        dev = self._check_dev(x2d, idx, masks, offsets)
+        values = torch.empty(int(total), dtype=torch.float32, device=dev)
+        n = int(masks.shape[0])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_rows_pack_values(n, _ptr(idx), 0 if idx is None else (32 if idx.dtype == torch.int32 else 64),
+                                                       int(x2d.shape[1]), _ptr(x2d), x2d.stride(0), _ptr(masks), _ptr(offsets), _ptr(values),
+                                                       _stream(dev)))
+        return values
+
+    def rows_unpack(self, masks, offsets, values, D, out=None):
+        """Dense [n, D] rows: values under the masks, zeros elsewhere."""
+        dev = self._check_dev(masks, offsets, values, out)
+        n = int(masks.shape[0])
+        if out is None:
+            out = torch.empty((n, int(D)), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_rows_unpack(n, int(D), _ptr(masks), _ptr(offsets), _ptr(values), _ptr(out), out.stride(0), _stream(dev)))
+        return out
+
     def gather_rows(self, x2d, idx):
         """out[i] = x2d[idx[i]]; x2d may be a row-strided view (stride(1) == 1) when D and the stride are multiples of 4."""
         dev = self._check_dev(x2d, idx)

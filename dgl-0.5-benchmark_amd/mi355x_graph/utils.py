@@ -100,15 +100,18 @@ def _tall_linear_fn():
             g = g.contiguous()
             be = sparse.backend_for(g)
             dx = g @ weight if ctx.needs_input_grad[0] else None
-            dw = None
+            dw = db = None
+            want_db = ctx.has_bias and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
                 out_f, in_f = g.shape[1], x.shape[1]
                 if out_f <= be.XTY_MAX[0] and in_f <= be.XTY_MAX[1] and x.stride(1) == 1:
-                    dw = be.xty(g, x)  # [out, in] = g^T x over the rows
+                    if want_db:  # the bias gradient from the weight-gradient kernel's own pass over g (mgx_xty_colsum), else two kernels
+                        dw, db = be.xty(g, x, colsum=True)
+                    else:
+                        dw = be.xty(g, x)  # [out, in] = g^T x over the rows
                 else:
                     dw = g.t() @ x
-            db = None
-            if ctx.has_bias and ctx.needs_input_grad[2]:
+            if want_db and db is None:
                 db = be.column_sum(g) if g.shape[1] <= be.COLUMN_SUM_MAX else g.sum(0)
             return dx, dw, db
 

@@ -126,15 +126,29 @@ def summarize(res, P, D, pstats, n, num_edges):
                          "compute_ms": round(sum(by_label.values()), 4),
                          "compute_ms_by_stretch": {k: round(v, 4) for k, v in sorted(by_label.items())},
                          "overlap_window_ms_per_exchange": window_ms})
-    # halo byte matrix of ONE hidden-width exchange: [receiver][sender]
+    # halo byte matrix of ONE hidden-width exchange sent as DENSE rows: [receiver][sender] -- the reference point
     matrix = [[rows * D * 4 for rows in r["recv_splits"]] for r in res]
+    # ... and what every message of the epoch really carried (dist.SparseHalo sends relu + dropout outputs as bitmaps + non-zeros and
+    # takes their gradients back under the same bitmaps): per all_to_all stage, in program order
+    a2a_idx = [k for k, st in enumerate(ranks[0]) if st["kind"] == "all_to_all"]
+    messages = []
+    for k in a2a_idx:
+        mk = [[ranks[r][k]["info"]["recv_rows"][q] * ranks[r][k]["info"]["row_bytes"] for q in range(P)] for r in range(P)]
+        messages.append({"tag": ranks[0][k]["info"].get("tag", "rows"), "max_pair_bytes": max(max(row) for row in mk),
+                         "max_recv_bytes": max(sum(row) for row in mk), "total_bytes": sum(sum(row) for row in mk), "matrix": mk})
     pair_max = max(max(row) for row in matrix)
-    a2a = [st for st in ranks[0] if st["kind"] == "all_to_all"]
+    a2a = [ranks[0][k] for k in a2a_idx if ranks[0][k]["info"].get("tag", "rows") != "values"]  # logical exchanges (a packed forward one = 2 messages)
+    dense_total = sum(sum(row) for row in matrix) * len(a2a)
+    sent_total = sum(m["total_bytes"] for m in messages)
     own = [r["n_own"] for r in res]
     edges = [r["local_edges"] for r in res]
     out = {"ranks": P, "edge_cut_pct": round(100.0 * sum(r["halo_edges"] for r in res) / max(num_edges, 1), 2),
            "num_clusters": pstats.get("num_clusters"), "final_loss": res[0]["loss"],
            "exchanges_per_epoch": len(a2a),
+           "messages_per_epoch": [{k: v for k, v in m.items() if k != "matrix"} for m in messages],
+           "message_bytes_matrices": [m["matrix"] for m in messages],
+           "halo_bytes_per_epoch": {"sent": sent_total, "as_dense_rows": dense_total,
+                                    "ratio": round(sent_total / dense_total, 4) if dense_total else None},
            "per_rank": per_rank,
            "halo_bytes_matrix_D%d" % D: matrix,
            "max_pair_bytes_per_exchange": pair_max,
@@ -190,7 +204,20 @@ def report(models, one_gpu_ms=None, header=""):
         lines.append("   halo MB per exchange, receiver (row) x sender (column), %s:" % key[len("halo_bytes_matrix_"):])
         for row in m[key]:
             lines.append("      " + " ".join("%7.2f" % (b / 1e6) for b in row) + "   | recv %8.2f" % (sum(row) / 1e6))
-        lines.append("   max pair %.2f MB, max received by one rank %.2f MB per exchange" % (m["max_pair_bytes_per_exchange"] / 1e6, m["max_recv_bytes_per_exchange"] / 1e6))
+        lines.append("   as dense rows: max pair %.2f MB, max received by one rank %.2f MB per exchange" % (m["max_pair_bytes_per_exchange"] / 1e6, m["max_recv_bytes_per_exchange"] / 1e6))
+        if m.get("messages_per_epoch"):
+            lines.append("   messages of one epoch as sent (program order; a packed forward exchange = bitmaps + values, its gradients = values only):")
+            for i, msg in enumerate(m["messages_per_epoch"]):
+                lines.append("      #%d %-16s total %8.2f MB   max pair %7.2f MB   max received by one rank %8.2f MB"
+                             % (i, msg["tag"], msg["total_bytes"] / 1e6, msg["max_pair_bytes"] / 1e6, msg["max_recv_bytes"] / 1e6))
+            hb = m["halo_bytes_per_epoch"]
+            lines.append("   bytes on the links per epoch: %.1f MB sent against %.1f MB as dense rows = %.3f"
+                         % (hb["sent"] / 1e6, hb["as_dense_rows"] / 1e6, hb["ratio"] or 0.0))
+            for i, mk in enumerate(m.get("message_bytes_matrices", [])):
+                if m["messages_per_epoch"][i]["tag"] in ("values", "gradient values") and i <= 2:
+                    lines.append("   MB of message #%d (%s), receiver (row) x sender (column):" % (i, m["messages_per_epoch"][i]["tag"]))
+                    for row in mk:
+                        lines.append("      " + " ".join("%7.2f" % (b / 1e6) for b in row) + "   | recv %8.2f" % (sum(row) / 1e6))
         lines.append("   predicted epoch, ms:")
         for k, v in m["predicted"].items():
             if "epoch_ms_not_overlapped" in v:

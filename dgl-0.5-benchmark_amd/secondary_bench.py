@@ -52,22 +52,27 @@ def _bytes_sddmm(r):
 
 
 def _family(r):
+    """Calls of one kernel family at one width -- whatever the graph (the batches of molhiv differ in size from step to step)."""
     k = r.get("kernel", "spmm")
     if k == "spmm":
-        return ("g-SpMM %s/%s" % (r["op"], r["reduce"]), r["out_len"], r["n_rows"], r["nnz"])
+        return ("g-SpMM %s/%s" % (r["op"], r["reduce"]), r["out_len"])
     if k in ("gat_fwd", "gat_bwd"):
-        return ("fused GAT block %s (%s form)" % ("forward" if k == "gat_fwd" else "backward", r["form"]), r["H"] * r["F"], r["n_dst"], r["nnz"],
-                r["H"], r.get("source_walk", True))
+        return ("fused GAT block %s (%s form), H=%d%s" % ("forward" if k == "gat_fwd" else "backward", r["form"], r["H"],
+                                                           "" if r.get("source_walk", True) else ", no source walk"), r["H"] * r["F"])
     if k == "sddmm":
-        return ("g-SDDMM %s (%s)" % (r["op"], r["targets"]), r["out_len"], r["n_dst"], r["nnz"], r["l_len"], r["r_len"])
-    return (k,)
+        return ("g-SDDMM %s (%s)" % (r["op"], r["targets"]), r["out_len"])
+    return (k, 0)
+
+
+_BYTES = {"spmm": _bytes_spmm, "gat_fwd": _bytes_gat, "gat_bwd": _bytes_gat, "sddmm": _bytes_sddmm}
 
 
 def dominant_roofline(records, steps):
-    """The hot-path call family with the largest summed device time in the timed steps -> a `roofline` object."""
+    """The hot-path call family with the largest summed device time in the profiled steps -> a `roofline` object: SURVEY 8d's
+    algorithmic bytes summed over its launches / their summed duration (== bytes per launch / mean duration on one graph)."""
     fams = {}
     for r in records:
-        if r.get("kernel") == "segment_reduce" or r.get("variant") == "row-sparse":
+        if r.get("kernel", "spmm") not in _BYTES or r.get("variant") == "row-sparse":
             continue
         fams.setdefault(_family(r), []).append(r)
     if not fams:
@@ -75,22 +80,22 @@ def dominant_roofline(records, steps):
     tot = {k: sum(x["start"].elapsed_time(x["end"]) for x in v) for k, v in fams.items()}
     key = max(tot, key=tot.get)
     sel = fams[key]
-    r0 = sel[0]
-    kind = r0.get("kernel", "spmm")
-    algo = {"spmm": _bytes_spmm, "gat_fwd": _bytes_gat, "gat_bwd": _bytes_gat, "sddmm": _bytes_sddmm}[kind](r0)
-    avg_ms = tot[key] / len(sel)
-    achieved = algo / (avg_ms * 1e-3) / 1e9
+    algo_sum = sum(_BYTES[x.get("kernel", "spmm")](x) for x in sel)
+    achieved = algo_sum / (tot[key] * 1e-3) / 1e9
     all_ms = sum(tot.values())
-    return {"bound": "hbm", "kernel": "%s, D=%d, rows=%d, E=%d" % (key[0], key[1], key[2], key[3]),
+    rows = [x.get("n_rows", x.get("n_dst")) for x in sel]
+    return {"bound": "hbm", "kernel": "%s, D=%d" % key, "rows": int(sum(rows) / len(rows)), "nnz": int(sum(x["nnz"] for x in sel) / len(sel)),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-            "algorithmic_bytes_per_launch": int(algo), "avg_launch_ms": round(avg_ms, 4), "launches_timed": len(sel),
+            "algorithmic_bytes_per_launch": int(algo_sum / len(sel)), "avg_launch_ms": round(tot[key] / len(sel), 4), "launches_timed": len(sel),
             "launches_per_step": round(len(sel) / max(steps, 1), 2),
             "share_of_hot_path_device_time": round(tot[key] / all_ms, 3) if all_ms > 0 else None,
             "hot_path_ms_per_step": round(all_ms / max(steps, 1), 4)}
 
 
-def _timed(step, steps, warmup, sync=None):
-    """Warm-up, then `steps` steps between two device synchronisations with HIP-event records of every hot-path call."""
+def _timed(step, steps, warmup, sync=None, profile_steps=None):
+    """Warm-up, then `steps` steps between two device synchronisations -- the number reported -- and AFTER them `profile_steps` more
+    steps with HIP events around every hot-path call (sparse.PROFILE) for the roofline entry: the events cost host time, which a
+    launch-bound loop (molhiv eager: ~300 launches per batch) would show in its step time."""
     from mi355x_graph import sparse
     sync = sync or torch.cuda.synchronize
     for _ in range(warmup):
@@ -99,30 +104,36 @@ def _timed(step, steps, warmup, sync=None):
     gc.collect()
     was = gc.isenabled()
     gc.disable()
-    sparse.PROFILE = []
     try:
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         sync()
         elapsed = time.perf_counter() - t0
+        n_prof = steps if profile_steps is None else profile_steps
+        sparse.PROFILE = []
+        try:
+            for _ in range(n_prof):
+                step()
+            sync()
+        finally:
+            records, sparse.PROFILE = sparse.PROFILE, None
     finally:
-        records, sparse.PROFILE = sparse.PROFILE, None
         if was:
             gc.enable()
-    return elapsed / steps * 1e3, records
+    return elapsed / steps * 1e3, records, n_prof
 
 
 def sage_arxiv(device, steps=30, warmup=5):
     """configs[1]: 3-layer GraphSAGE, hidden 256, BatchNorm, on the bidirected arxiv shape (main_dgl_arxiv_sage.py:141-148,162)."""
     import full_graph
     cfg, data, g, model, train_idx, opt = full_graph.build_sage("arxiv", device)
-    ms, recs = _timed(lambda: full_graph.sage_train_step(model, g, data.features, data.labels, train_idx, opt), steps, warmup)
+    ms, recs, n_prof = _timed(lambda: full_graph.sage_train_step(model, g, data.features, data.labels, train_idx, opt), steps, warmup, profile_steps=5)
     return {"workload": "configs[1]: 3-layer GraphSAGE (hidden 256, BatchNorm) full-graph on the ogbn-arxiv shape, bidirected "
                         "(N=%d, E=%d)" % (g.number_of_nodes(), g.number_of_edges()),
             "reference": "main_dgl_arxiv_sage.py:141-148", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup,
             "value_edges_per_s": full_graph.spmm_edges_per_epoch(cfg["num_layers"], g.number_of_edges()) / (ms * 1e-3),
-            "roofline": dominant_roofline(recs, steps)}
+            "roofline": dominant_roofline(recs, n_prof)}
 
 
 def _gat(device, dataset, layers, heads, hidden, dropout, steps, warmup, label, ref):
@@ -136,10 +147,11 @@ def _gat(device, dataset, layers, heads, hidden, dropout, steps, warmup, label, 
                            feat_drop=dropout, attn_drop=dropout).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=0.003, weight_decay=2.4e-5)
     loss_fcn = nn.CrossEntropyLoss()
-    ms, recs = _timed(lambda: full_graph.gat_train_step(model, data.features, data.labels, data.train_mask, opt, loss_fcn), steps, warmup)
+    ms, recs, n_prof = _timed(lambda: full_graph.gat_train_step(model, data.features, data.labels, data.train_mask, opt, loss_fcn), steps, warmup,
+                              profile_steps=4)
     return {"workload": "%s (N=%d, E=%d incl. self loops, in=%d, hidden=%d, heads=%d, %d layers, dropout %g)"
                         % (label, g.number_of_nodes(), g.number_of_edges(), data.features.shape[1], hidden, heads, layers, dropout),
-            "reference": ref, "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup, "roofline": dominant_roofline(recs, steps)}
+            "reference": ref, "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup, "roofline": dominant_roofline(recs, n_prof)}
 
 
 def gat8_reddit_small(device, steps=20, warmup=4):
@@ -170,8 +182,8 @@ def gcn_molhiv(device, epochs=2, num_graphs=32901, batch_size=256):
     torch.manual_seed(0)
     model = gc_.GCN(256, 1, 5, 0.5).to(device)
     opt = torch.optim.Adam(model.parameters(), lr=0.001)
-    ms, recs = _timed(lambda: gc_.train_epoch(model, device, loader, opt, loss_fn), epochs, 1)
-    out["eager"] = {"ms_per_step": round(ms, 2), "roofline": dominant_roofline(recs, epochs),
+    ms, recs, n_prof = _timed(lambda: gc_.train_epoch(model, device, loader, opt, loss_fn), epochs, 1, profile_steps=1)
+    out["eager"] = {"ms_per_step": round(ms, 2), "roofline": dominant_roofline(recs, n_prof),
                     "note": "host-bound: ~300 launches per batch (profiles/r02_molhiv_kernel_stats.txt)"}
     del model, opt
     torch.manual_seed(0)
@@ -183,7 +195,7 @@ def gcn_molhiv(device, epochs=2, num_graphs=32901, batch_size=256):
     def graphed_epoch():
         gc_.train_epoch_graphed(trainer, loader)
         torch.cuda.synchronize()
-    ms2, _ = _timed(graphed_epoch, epochs, 1)
+    ms2, _, _ = _timed(graphed_epoch, epochs, 1, profile_steps=0)
     out["captured"] = {"ms_per_step": round(ms2, 2), "static_batch_shape": [int(n_pad), int(e_pad)],
                        "replayed": trainer.stats["replayed"], "oversize_batches_split": trainer.stats["split"],
                        "note": "one HIP graph of the padded batch step replayed per batch (graph_classification.GraphedBatchTrainer); "

@@ -475,6 +475,21 @@ int32_t mgx_gather_rows_strided(int64_t n, const void* idx, int32_t idx_bits, in
 int32_t mgx_scatter_add_rows(int64_t n, const void* idx, int32_t idx_bits, int64_t D,
                              const float* in, float* x, void* stream);
 
+/* Halo rows as bitmaps + packed values (round 5, csrc/rowpack.hip): the exchange of relu + dropout outputs, ~75 % exact zeros
+ * (main_dgl_product_sage.py:93-96), moves a 64-bit mask per 64 columns + the non-zero values forward and the values under the SAME
+ * mask back.  masks: [n, mgx_rows_mask_words(D)] uint64; bit (c * G + l) of a block's word = column 64 * block + 4 l + c, G = min(16,
+ * pow2 >= D / 4); a row's values are stored in increasing bit order, block after block, from offsets[i] on (the caller's exclusive
+ * scan of `counts`).  idx: row ids of x (NULL = identity).  D % 4 == 0, D <= 256, strides multiples of 4, 16-byte aligned, else
+ * MGX_ERR_UNSUPPORTED.  Values are moved, never rounded: unpack(pack(x)) == x bit for bit. */
+int64_t mgx_rows_mask_words(int64_t D);
+int32_t mgx_rows_pack_count(int64_t n, const void* idx, int32_t idx_bits, int64_t D, const float* x, int64_t x_stride,
+                            uint64_t* masks, int32_t* counts /* [n] non-zeros per row */, void* stream);
+int32_t mgx_rows_mask_count(int64_t n, int64_t D, const uint64_t* masks, int32_t* counts, void* stream);
+int32_t mgx_rows_pack_values(int64_t n, const void* idx, int32_t idx_bits, int64_t D, const float* x, int64_t x_stride,
+                             const uint64_t* masks, const int64_t* offsets /* [n] */, float* values, void* stream);
+int32_t mgx_rows_unpack(int64_t n, int64_t D, const uint64_t* masks, const int64_t* offsets, const float* values,
+                        float* out /* [n, D] rows out_stride apart; zeros where the mask is clear */, int64_t out_stride, void* stream);
+
 /* ------------------------------------------------------------------ neighbor sampling
  * Replaces the CPU-side sampling of dgl.dataloading.MultiLayerNeighborSampler / dgl.sampling.sample_neighbors
  * (end_to_end/sampling/node-classification/reddit/ns-sage-dgl.py:132-141): for every seed v (a row of the in-CSR)

@@ -28,7 +28,7 @@ int main(void) {
   const int n = 5, nnz = 8, D = 2;
   float X[10];
   for (int i = 0; i < 10; ++i) X[i] = (float)(i + 1); /* [[1,2],[3,4],[5,6],[7,8],[9,10]] */
-  if (mgx_abi_version() < 29) { printf("unexpected ABI version %d\n", mgx_abi_version()); return 1; }
+  if (mgx_abi_version() < 30) { printf("unexpected ABI version %d\n", mgx_abi_version()); return 1; }
 
   int32_t *d_src = dev_copy(src, sizeof src), *d_dst = dev_copy(dst, sizeof dst);
   float* d_X = dev_copy(X, sizeof X);

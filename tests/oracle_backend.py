@@ -157,6 +157,47 @@ class OracleBackend(object):
     def segment_reduce(self, offsets, x2d, reduce, want_arg):
         return torch.from_numpy(orc.segment_reduce(_np(offsets), _np(x2d), reduce)), None
 
+    # ---- halo rows as bitmaps + packed values (the contract of csrc/rowpack.hip, any bit order that pack and unpack share: here column order)
+    @staticmethod
+    def rows_pack_supported(x2d):
+        return x2d.dim() == 2 and x2d.dtype == torch.float32 and x2d.shape[1] % 4 == 0 and 4 <= x2d.shape[1] <= 256
+
+    @staticmethod
+    def _bits(D):
+        W = (D + 63) // 64
+        return W, (torch.ones((), dtype=torch.int64) << (torch.arange(W * 64) % 64)).view(W, 64)
+
+    def rows_pack_count(self, x2d, idx):
+        x = x2d if idx is None else x2d[idx.long()]
+        D = x.shape[1]
+        W, bit = self._bits(D)
+        nz = torch.zeros((x.shape[0], W * 64), dtype=torch.bool)
+        nz[:, :D] = x != 0
+        masks = (nz.view(-1, W, 64).to(torch.int64) * bit).sum(-1)
+        return masks, nz.sum(1).to(torch.int32)
+
+    def _flags(self, masks, D):
+        W, bit = self._bits(D)
+        return ((masks.view(-1, W, 1) & bit) != 0).view(masks.shape[0], W * 64)[:, :D]
+
+    def rows_mask_count(self, masks, D):
+        return self._flags(masks, D).sum(1).to(torch.int32)
+
+    def rows_pack_values(self, x2d, idx, masks, offsets, total):
+        x = x2d if idx is None else x2d[idx.long()]
+        vals = x[self._flags(masks, x.shape[1])]
+        assert vals.numel() == int(total)
+        return vals.contiguous()
+
+    def rows_unpack(self, masks, offsets, values, D, out=None):
+        flags = self._flags(masks, D)
+        dense = torch.zeros((masks.shape[0], D), dtype=torch.float32)
+        dense[flags] = values
+        if out is None:
+            return dense
+        out.copy_(dense)
+        return out
+
     def gather_rows(self, x2d, idx):
         return x2d[idx.long()].contiguous()
 

@@ -118,6 +118,9 @@ def _worker(rank, world, port, q, device="cpu", batch_norm=False, ring=False):
     loss.backward()
     assert all(prm.grad.data_ptr() >= bucket.flat.data_ptr() for prm in model.parameters())  # still the views
     bucket.all_reduce()
+    # the hidden layers' inputs are relu outputs (tagged by ops.relu_dropout): their halo rows crossed as bitmaps + non-zeros and
+    # their gradients came back under the same bitmaps (dist.SparseHalo) -- the layer-1 input is dense and static
+    assert mdist.SPARSE_EXCHANGES == [len(model.layers) - 1] * 2, mdist.SPARSE_EXCHANGES
     lsum = loss.detach().cpu().clone()
     dist.all_reduce(lsum)
     q.put((rank, own.cpu().numpy(), out.detach().cpu().numpy(), float(lsum),

@@ -247,11 +247,15 @@ def test_every_rank_of_a_partition_on_the_hip_path_matches_one_gpu(world):
         return own, out, losses, [p.grad.clone() for p in model.parameters()], plan
 
     mdist.DistSageMeanCatFn.forward = staticmethod(counting)
+    packed0 = list(mdist.SPARSE_EXCHANGES)
     try:
         res = emulate.EmuWorld(world, dev).run(body)
     finally:
         mdist.DistSageMeanCatFn.forward = staticmethod(orig)
     assert taken["cat"] == world * 3 * 3   # every layer of every rank took the one-GEMM layer with the exchange inside
+    # the two hidden layers' inputs are relu(+dropout) outputs: their halo rows crossed as bitmaps + non-zeros in all three forward
+    # passes of every rank, their gradients came back under the same bitmaps in both backward passes (dist.SparseHalo, csrc/rowpack.hip)
+    assert [a - b for a, b in zip(mdist.SPARSE_EXCHANGES, packed0)] == [world * 2 * 3, world * 2 * 2]
 
     got = torch.full_like(ref_out, float("nan"))
     for own, out, losses, grads, plan in res:

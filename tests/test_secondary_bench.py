@@ -30,6 +30,7 @@ def test_dominant_call_and_survey_8d_bytes():
     algo = 4 * (N + 1) + 4 * E + 4 * N * D + 4 * N * D  # SURVEY 8d worked number: 356.8 MB
     assert r["algorithmic_bytes_per_launch"] == algo and abs(algo / 1e6 - 356.1) < 1.0
     assert r["launches_timed"] == 6 and r["launches_per_step"] == 2.0 and abs(r["avg_launch_ms"] - 0.25) < 1e-9
+    assert r["rows"] == N and r["nnz"] == E and "D=256" in r["kernel"]
     assert abs(r["achieved"] - algo / 0.25e-3 / 1e9) < 0.1 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-4
     assert abs(r["share_of_hot_path_device_time"] - 1.5 / 1.65) < 1e-3
 
@@ -45,3 +46,13 @@ def test_gat_and_sddmm_and_copy_e_formulas():
     assert sb._bytes_sddmm({"nnz": E, "n_src": n, "n_dst": n, "l_len": 64, "r_len": 64, "out_len": 64, "targets": "uv"}) == 8 * E + 8 * n * 64 + 4 * E * 64
     assert sb._bytes_spmm({"op": "copy_rhs", "n_rows": n, "n_cols": n, "nnz": E, "out_len": 256}) == 4 * (n + 1) + 4 * E + 4 * E * 256 + 4 * n * 256
     assert sb.dominant_roofline([], 1) is None
+
+
+def test_batches_of_different_sizes_fall_into_one_family():
+    """molhiv: every batch is another graph; the family is (kernel, op, width) and the bytes are summed launch by launch."""
+    recs = [_rec(0.01, op="copy_rhs", reduce="sum", out_len=256, n_rows=6000 + 10 * i, n_cols=6000 + 10 * i, nnz=13000 + 7 * i, accumulate=False)
+            for i in range(10)]
+    r = sb.dominant_roofline(recs, steps=1)
+    want = sum(sb._bytes_spmm(x) for x in recs)
+    assert r["launches_timed"] == 10 and r["algorithmic_bytes_per_launch"] == want // 10
+    assert abs(r["achieved"] - want / 0.1e-3 / 1e9) < 0.1
