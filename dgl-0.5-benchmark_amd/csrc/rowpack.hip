@@ -223,3 +223,70 @@ extern "C" int32_t mgx_rows_unpack(int64_t n, int64_t D, const uint64_t* masks, 
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// mgx_rows_unpack_add_csr: out[v, :] += sum over the entries p of row v of a CSR of unpack(masks[p], values[offsets[p] ..]) -- the
+// returned halo-row gradients added into their owners straight from the packed form (dist.SparseHalo.finish_back + the copy_u over
+// return_csr it fed: one dense [send rows, D] matrix written and read less per backward exchange).  A lane group owns an output row and
+// walks its entries in CSR order (= peer order: deterministic), rows without entries are left alone.
+namespace mgx {
+namespace {
+template <int G>
+__global__ __launch_bounds__(kBlock) void rows_unpack_add_csr_kernel(int64_t n, const int32_t* __restrict__ indptr, const int32_t* __restrict__ pos,
+                                                                     int D, int nblk, const uint64_t* __restrict__ masks,
+                                                                     const int64_t* __restrict__ offsets, const float* __restrict__ values,
+                                                                     float* __restrict__ out, int64_t ldo) {
+  constexpr int RPW = kWave / G;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int l = lane % G, sub = lane / G;
+  const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+  for (int64_t base = wave_id * RPW; base < n; base += n_waves * RPW) {
+    const int64_t v = base + sub;
+    if (v >= n) continue;
+    const int32_t beg = indptr[v], end = indptr[v + 1];
+    if (beg == end) continue;
+    for (int blk = 0; blk < nblk; ++blk) {
+      const int c0 = blk * 64 + l * 4;
+      if (c0 >= D) continue;
+      v4f acc = *reinterpret_cast<const v4f*>(out + v * ldo + c0);
+      for (int32_t q = beg; q < end; ++q) {
+        const int64_t p = pos[q];
+        int64_t off = offsets[p];
+        for (int b = 0; b < blk; ++b) off += __popcll(masks[p * nblk + b]);
+        const uint64_t m = masks[p * nblk + blk];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int bit = c * G + l;
+          if ((m >> bit) & 1ull) acc[c] += values[off + __popcll(m & ((1ull << bit) - 1ull))];
+        }
+      }
+      *reinterpret_cast<v4f*>(out + v * ldo + c0) = acc;
+    }
+  }
+}
+}  // namespace
+}  // namespace mgx
+
+extern "C" int32_t mgx_rows_unpack_add_csr(int64_t n, const int32_t* indptr, const int32_t* positions, int64_t D, const uint64_t* masks,
+                                           const int64_t* offsets, const float* values, float* out, int64_t out_stride, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  if (int32_t st = check_shape("mgx_rows_unpack_add_csr", n, D, out_stride, out)) return st;
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(indptr && masks && offsets && out, "mgx_rows_unpack_add_csr: NULL pointer");
+  const RowShape sh = row_shape(D);
+  const dim3 grid((unsigned)stream_blocks(n, kWave / sh.G)), block(kBlock);
+  hipStream_t s = (hipStream_t)stream;
+#define MGX_UA(GG) hipLaunchKernelGGL((rows_unpack_add_csr_kernel<GG>), grid, block, 0, s, n, indptr, positions, (int)D, sh.nblk, masks, offsets, values, out, out_stride)
+  switch (sh.G) {
+    case 1: MGX_UA(1); break;
+    case 2: MGX_UA(2); break;
+    case 4: MGX_UA(4); break;
+    case 8: MGX_UA(8); break;
+    default: MGX_UA(16); break;
+  }
+#undef MGX_UA
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}

@@ -27,6 +27,7 @@ struct SddmmArgs {
   // COO form
   const Idx* src;
   const Idx* dst;
+  const Idx* perm;  // optional (lean COO walk only): output row of the q-th WALKED edge -- an edge list walked in another order than its ids
   // CSR form (in-CSR: row = dst) + optional schedule
   const Idx* indptr;
   const Idx* indices;
@@ -191,7 +192,10 @@ __global__ __launch_bounds__(kBlock) void sddmm_coo_kernel(const SddmmArgs<Idx> 
 // `base (SGPR pair) + offset (one VGPR)` -- no 64-bit multiply per gather -- the output row of edge j of a chunk is
 // `chunk base (SGPR pair) + j * rowbytes`, and the gathers of step k+1 are issued before step k is combined and stored.
 // OPS: 0 = both operands, 1 = lhs only (copy_lhs), 2 = rhs only (copy_rhs).
-template <int VEC, int G, int OPS>
+// PERM (round 5): the edge list is walked in an order of its own -- the in-CSR's, i.e. sorted by destination, where one operand row of
+// consecutive edges is the same row and the other has the g-SpMM's locality -- and `perm[q]` names the output row (the edge id) of the
+// q-th walked edge: whole output rows are scattered instead of streamed (profiles/r05_sddmm_perm.txt).
+template <int VEC, int G, int OPS, bool PERM = false>
 __global__ __launch_bounds__(kBlock) void sddmm_coo32_kernel(const SddmmArgs<int32_t> a) {
   typedef typename VecT<VEC>::type V;
   constexpr int NB = kWave / G;
@@ -213,21 +217,25 @@ __global__ __launch_bounds__(kBlock) void sddmm_coo32_kernel(const SddmmArgs<int
   const char* __restrict__ Lb = reinterpret_cast<const char*>(a.L);
   const char* __restrict__ Rb = reinterpret_cast<const char*>(a.R);
   const int op = a.op;
-  auto load_ids = [&](int64_t base, uint32_t& lo, uint32_t& ro) {
+  auto load_ids = [&](int64_t base, uint32_t& lo, uint32_t& ro, int32_t& po) {
     const int64_t q = base + lane;
     const bool in = lane < chunk && q < a.nnz;
     const int32_t mu = (need_u && in) ? __builtin_nontemporal_load(&a.src[q]) : 0;  // id streams: read once
     const int32_t mv = (need_v && in) ? __builtin_nontemporal_load(&a.dst[q]) : 0;
     lo = (uint32_t)(lu ? mu : mv) * rowbytes;
     ro = (uint32_t)(ru ? mu : mv) * rowbytes;
+    po = (PERM && in) ? __builtin_nontemporal_load(&a.perm[q]) : 0;
   };
   uint32_t lo, ro;
-  load_ids(e0, lo, ro);
+  int32_t po;
+  load_ids(e0, lo, ro, po);
+  char* __restrict__ outb = reinterpret_cast<char*>(a.out);
   for (int c = 0; c < nchunks; ++c) {
     const int64_t base = e0 + (int64_t)c * chunk;
     if (base >= a.nnz) break;  // wave-uniform
     uint32_t nlo = 0, nro = 0;
-    if (c + 1 < nchunks) load_ids(base + chunk, nlo, nro);
+    int32_t npo = 0;
+    if (c + 1 < nchunks) load_ids(base + chunk, nlo, nro, npo);
     const int cnt = (int)((a.nnz - base) < chunk ? (a.nnz - base) : chunk);
     char* __restrict__ ob = reinterpret_cast<char*>(a.out + base * a.out_len);
     auto issue = [&](int k, V (&lv)[U], V (&rv)[U]) {
@@ -245,7 +253,13 @@ __global__ __launch_bounds__(kBlock) void sddmm_coo32_kernel(const SddmmArgs<int
         const int j = k + u * NB + sub;
         if (j < cnt && kactive) {
           const V val = OPS == 1 ? lv[u] : (OPS == 2 ? rv[u] : sddmm_op<V>(op, lv[u], rv[u]));
-          V* o = reinterpret_cast<V*>(ob + ((uint32_t)j * rowbytes + kc4));
+          V* o;
+          if (PERM) {  // the edge's own output row: 64-bit offset (E x D x 4 bytes may pass 4 GiB)
+            const uint32_t pe = (uint32_t)__builtin_amdgcn_ds_bpermute(j * 4, po);
+            o = reinterpret_cast<V*>(outb + ((uint64_t)pe * rowbytes + kc4));
+          } else {
+            o = reinterpret_cast<V*>(ob + ((uint32_t)j * rowbytes + kc4));
+          }
           // rows of >= 32 bytes: the E x D output is written once and not re-read here -- stream it past L2
           if (VEC * G >= 8) __builtin_nontemporal_store(val, o);
           else *o = val;
@@ -267,6 +281,7 @@ __global__ __launch_bounds__(kBlock) void sddmm_coo32_kernel(const SddmmArgs<int
     }
     lo = nlo;
     ro = nro;
+    po = npo;
   }
 }
 
@@ -470,6 +485,12 @@ static bool launch_coo32(const SddmmArgs<int32_t>& a, dim3 grid, hipStream_t s) 
   if (a.L && (rows_of(a.lhs_target) <= 0 || rows_of(a.lhs_target) * a.out_len * 4 >= lim)) return false;
   if (a.R && (rows_of(a.rhs_target) <= 0 || rows_of(a.rhs_target) * a.out_len * 4 >= lim)) return false;
   if (a.nnz >= (int64_t(1) << 31)) return false;
+  if (a.perm) {
+    if (a.L && a.R) hipLaunchKernelGGL((sddmm_coo32_kernel<VEC, G, 0, true>), grid, dim3(kBlock), 0, s, a);
+    else if (a.L) hipLaunchKernelGGL((sddmm_coo32_kernel<VEC, G, 1, true>), grid, dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((sddmm_coo32_kernel<VEC, G, 2, true>), grid, dim3(kBlock), 0, s, a);
+    return true;
+  }
   if (a.L && a.R) hipLaunchKernelGGL((sddmm_coo32_kernel<VEC, G, 0>), grid, dim3(kBlock), 0, s, a);
   else if (a.L) hipLaunchKernelGGL((sddmm_coo32_kernel<VEC, G, 1>), grid, dim3(kBlock), 0, s, a);
   else hipLaunchKernelGGL((sddmm_coo32_kernel<VEC, G, 2>), grid, dim3(kBlock), 0, s, a);
@@ -573,8 +594,9 @@ static int32_t check_common(int32_t op, const float* lhs, const float* rhs, int3
 template <typename Idx>
 static int32_t run_coo(int64_t num_src, int64_t num_dst, int64_t nnz, const void* src, const void* dst, int32_t op, const float* lhs, const float* rhs,
                        int32_t lt, int32_t rt, int64_t l_len, int64_t r_len, int64_t out_len, int64_t reduce_size,
-                       const int64_t* l_off, const int64_t* r_off, float* out, hipStream_t s) {
+                       const int64_t* l_off, const int64_t* r_off, float* out, hipStream_t s, const void* perm = nullptr) {
   SddmmArgs<Idx> a{};
+  a.perm = (const Idx*)perm;
   a.src = (const Idx*)src; a.dst = (const Idx*)dst; a.nnz = nnz; a.L = lhs; a.R = rhs;
   a.n_cols = num_src; a.n_rows = num_dst;  // rows of a U- / V-target operand (the lean kernel's 32-bit offsets)
   a.l_off = l_off; a.r_off = r_off; a.out = out; a.l_len = l_len; a.r_len = r_len; a.out_len = out_len;
@@ -619,6 +641,28 @@ extern "C" int32_t mgx_sddmm_coo(int64_t num_src, int64_t num_dst, int64_t nnz, 
                             l_off, r_off, out, (hipStream_t)stream);
   return run_coo<int64_t>(num_src, num_dst, nnz, src, dst, op, lhs, rhs, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size,
                           l_off, r_off, out, (hipStream_t)stream);
+}
+
+// The lean COO walk over an edge list in ANOTHER order than the edge ids (perm[q] = edge id = output row of the q-th walked edge).
+// Only what sddmm_coo32_kernel takes: int32 ids, an element-wise op on node-target operands as wide as the output, 32-bit byte offsets.
+extern "C" int32_t mgx_sddmm_coo_perm(int64_t num_src, int64_t num_dst, int64_t nnz, const void* src, const void* dst, const void* perm,
+                                      int32_t idx_bits, int32_t op, const float* lhs, const float* rhs, int32_t lhs_target,
+                                      int32_t rhs_target, int64_t feat_len, float* out, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(nnz >= 0 && feat_len >= 0, "mgx_sddmm_coo_perm: negative sizes");
+  MGX_CHECK_ARG(nnz == 0 || (src && dst && perm), "mgx_sddmm_coo_perm: src / dst / perm is NULL");
+  int32_t st = check_common(op, lhs, rhs, lhs_target, rhs_target, feat_len, feat_len, feat_len, out, nnz);
+  if (st != MGX_OK) return st;
+  const int64_t lim = int64_t(1) << 32;
+  auto rows_of = [&](int t) -> int64_t { return t == MGX_TARGET_U ? num_src : (t == MGX_TARGET_V ? num_dst : -1); };
+  const bool need_l = op != MGX_OP_COPY_RHS, need_r = op != MGX_OP_COPY_LHS;
+  if (idx_bits != 32 || op == MGX_OP_DOT || nnz >= (int64_t(1) << 31) || MGX_ENV_FLAG("MGX_SDDMM_V1") ||
+      (need_l && (rows_of(lhs_target) <= 0 || rows_of(lhs_target) * feat_len * 4 >= lim)) ||
+      (need_r && (rows_of(rhs_target) <= 0 || rows_of(rhs_target) * feat_len * 4 >= lim)))
+    MGX_UNSUPPORTED("mgx_sddmm_coo_perm: int32 ids, an element-wise op on u / v operands below 4 GiB only (use mgx_sddmm_coo)");
+  return run_coo<int32_t>(num_src, num_dst, nnz, src, dst, op, lhs, rhs, lhs_target, rhs_target, feat_len, feat_len, feat_len, 1, nullptr,
+                          nullptr, out, (hipStream_t)stream, perm);
 }
 
 extern "C" int32_t mgx_sddmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t op, const float* lhs,

@@ -56,8 +56,10 @@ SIGNATURES = {
     "mgx_rows_mask_count": (_i32, [_i64, _i64, _vp, _vp, _vp]),
     "mgx_rows_pack_values": (_i32, [_i64, _vp, _i32, _i64, _fp, _i64, _vp, _vp, _fp, _vp]),
     "mgx_rows_unpack": (_i32, [_i64, _i64, _vp, _vp, _fp, _fp, _i64, _vp]),
+    "mgx_rows_unpack_add_csr": (_i32, [_i64, _vp, _vp, _i64, _vp, _vp, _fp, _fp, _i64, _vp]),
     "mgx_sddmm_coo": (_i32, [_i64, _i64, _i64, _vp, _vp, _i32, _i32, _fp, _fp, _i32, _i32, _i64, _i64, _i64, _i64,
                              _vp, _vp, _fp, _vp]),
+    "mgx_sddmm_coo_perm": (_i32, [_i64, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _fp, _fp, _i32, _i32, _i64, _fp, _vp]),
     "mgx_sddmm_csr": (_i32, [_csr_p, _vp, _i32, _fp, _fp, _i32, _i32, _i64, _i64, _i64, _i64, _vp, _vp, _fp, _vp]),
     "mgx_edge_softmax_fwd": (_i32, [_csr_p, _vp, _i64, _fp, _fp, _fp, _vp]),
     "mgx_edge_softmax_bwd": (_i32, [_csr_p, _vp, _i64, _fp, _fp, _fp, _fp, _vp]),

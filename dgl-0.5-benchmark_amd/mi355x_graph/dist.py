@@ -460,6 +460,21 @@ class SparseHalo(object):
         self.bwork = self.comm.all_to_all_async(self.bvals, gv, self.s_splits, self.r_splits, tag="gradient values")
         return self
 
+    def finish_back_into(self, dh):
+        """dh[v] += the returned gradient rows of owned row v (peer order), straight from the packed form when the backend has the fused
+        kernel (mgx_rows_unpack_add_csr); else through the dense rows and the plan's copy_u over return_csr."""
+        plan, be = self.plan, self.be
+        if not hasattr(be, "rows_unpack_add_csr") or plan.return_csr().idx_bits != 32 or not plan.send_idx.numel():
+            back = self.finish_back()
+            if back.shape[0]:
+                be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dh, accumulate=True)
+            return dh
+        self.bwork.wait()
+        self._sent = None
+        be.rows_unpack_add_csr(plan.return_csr(), self.smask, self.soff, self.bvals, dh)
+        self.bvals = None
+        return dh
+
     def finish_back(self):
         """The returned gradient rows, dense [send rows, D] in send_idx order (zeros where the forward row was zero)."""
         self.bwork.wait()
@@ -646,13 +661,13 @@ class DistSageMeanCatFn(torch.autograd.Function):
             db = be.column_sum(dy)
         if need[3]:
             if halo_x is not None:
-                comm.mark("unpack")
-                back = halo_x.finish_back()
+                comm.mark("return-add")
+                halo_x.finish_back_into(dh_own)  # packed values -> their owners' rows, one kernel
             else:
                 work.wait()
-            comm.mark("return-add")
-            if back.shape[0]:  # row v += the returned rows whose owner is v: copy_u over (owned row -> position in `back`)
-                be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dh_own, accumulate=True)
+                comm.mark("return-add")
+                if back.shape[0]:  # row v += the returned rows whose owner is v: copy_u over (owned row -> position in `back`)
+                    be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dh_own, accumulate=True)
             dh = dh_own
         comm.mark("dense")
         return None, None, None, dh, dws, dwn, db, None, None

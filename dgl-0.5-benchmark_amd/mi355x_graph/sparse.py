@@ -67,7 +67,7 @@ class CsrView(object):
     """An immutable CSR over torch tensors (in-CSR: rows = destination nodes)."""
 
     __slots__ = ("__weakref__", "num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan", "_sm_plan",
-                 "_row_order", "dst_is_src_prefix", "_tile_plan", "_short", "short_hint")
+                 "_row_order", "dst_is_src_prefix", "_tile_plan", "_short", "short_hint", "_rows")
 
     def __init__(self, num_rows, num_cols, indptr, indices, eids):
         self.num_rows, self.num_cols = int(num_rows), int(num_cols)
@@ -82,6 +82,7 @@ class CsrView(object):
         self.short_hint = None  # the owner's word on short rows where reading the lengths back is impossible (graph capture) or not
                                 # worth it (a sampled block): True / False, or the average row length (see _short_choice)
         self._row_order = (None, None)  # (row order, kind) computed with the first plan
+        self._rows = None  # row id of every stored position (the expanded indptr), built on first use by the permuted g-SDDMM walk
         self.dst_is_src_prefix = False  # block graphs whose destination nodes are the first source nodes
 
     @property
@@ -102,6 +103,13 @@ class CsrView(object):
                              self.indices.data_ptr() if self.indices.numel() else None,
                              None if self.eids is None else self.eids.data_ptr(), self.idx_bits, 0)
         return self._c
+
+    def row_of_position(self):
+        """[nnz] the row of every stored entry: with `indices` and `eids` the CSR as an edge list in ITS order (sorted by row)."""
+        if self._rows is None:
+            ids = torch.arange(self.num_rows, dtype=self.indptr.dtype, device=self.indptr.device)
+            self._rows = torch.repeat_interleave(ids, (self.indptr[1:] - self.indptr[:-1]).long(), output_size=self.nnz)
+        return self._rows
 
     def degrees(self):
         if self._deg is None:
@@ -570,6 +578,18 @@ class HipBackend(object):
         dev = self._check_dev(L, R)
         out = torch.empty((nnz, out_len), dtype=torch.float32, device=dev)
         lib = _lib.lib()
+        if self._sddmm_in_csr_order(graph_index, op, L, R, lhs_target, rhs_target, l_len, r_len, out_len, l_off, r_off):
+            # the edge list in the in-CSR's order (sorted by destination) with the edge id as the output row: sddmm_coo32_kernel<PERM>
+            csc = graph_index.csc()
+            with torch.cuda.device(dev), timed_call(dev, kernel="sddmm", op=op, out_len=out_len, l_len=l_len, r_len=r_len, nnz=nnz,
+                                                    n_src=graph_index.num_src, n_dst=graph_index.num_dst, targets=lhs_target + rhs_target,
+                                                    walk="csr order"):
+                st = lib.mgx_sddmm_coo_perm(graph_index.num_src, graph_index.num_dst, nnz, _ptr(csc.indices), _ptr(csc.row_of_position()),
+                                            _ptr(csc.eids), 32, OP[op], _ptr(L), _ptr(R), TARGET[lhs_target], TARGET[rhs_target], out_len,
+                                            _ptr(out), _stream(dev))
+            if st != _lib.ERR_UNSUPPORTED:
+                _lib.check(st)
+                return out
         with torch.cuda.device(dev), timed_call(dev, kernel="sddmm", op=op, out_len=out_len, l_len=l_len, r_len=r_len, nnz=nnz,
                                                 n_src=graph_index.num_src, n_dst=graph_index.num_dst, targets=lhs_target + rhs_target):
             if graph_index.has_format("coo") or not graph_index.has_format("csc"):
@@ -589,6 +609,37 @@ class HipBackend(object):
                     OP[op], _ptr(L), _ptr(R), TARGET[lhs_target], TARGET[rhs_target],
                     l_len, r_len, out_len, reduce_size, _ptr(l_off), _ptr(r_off), _ptr(out), _stream(dev)))
         return out
+
+    SDDMM_PERM_MIN_EDGES = 1 << 20
+
+    @staticmethod
+    def _sddmm_in_csr_order(gidx, op, L, R, lt, rt, l_len, r_len, out_len, l_off, r_off):
+        """Walk the in-CSR's order with the edge id as the output row (mgx_sddmm_coo_perm) instead of the edge list's own order?
+        MGX_SDDMM_WALK = coo | csr | auto (default).  auto: a big graph that holds an in-CSR whose edge ids are NOT its positions, an
+        element-wise op on u / v operands as wide as the output -- and an edge list that is not already sorted by an endpoint (checked
+        once per graph; a sorted list has the same locality AND streams its output, profiles/r03_sddmm_edge_order.txt)."""
+        mode = os.environ.get("MGX_SDDMM_WALK", "auto")
+        if (mode == "coo" or not gidx.has_format("csc") or op == "dot" or l_off is not None or r_off is not None or out_len < 4
+                or (L is not None and (lt not in "uv" or l_len != out_len)) or (R is not None and (rt not in "uv" or r_len != out_len))):
+            return False
+        csc = gidx.csc()
+        if csc.eids is None or csc.idx_bits != 32 or not csc.indptr.is_cuda:
+            return False
+        if mode == "csr":
+            return True
+        if getattr(gidx, "ephemeral", False) or csc.nnz < HipBackend.SDDMM_PERM_MIN_EDGES:
+            return False
+        if not gidx.has_format("coo"):
+            return True  # no edge list to walk: the lean kernel over the CSR's order replaces the generic CSR body
+        order = getattr(gidx, "_coo_sorted", None)
+        if order is None:
+            src, dst = gidx.coo()
+            order = bool(((dst[1:] >= dst[:-1]).all() | (src[1:] >= src[:-1]).all()).item()) if dst.numel() > 1 else True
+            try:
+                gidx._coo_sorted = order
+            except AttributeError:
+                pass
+        return not order
 
     def edge_softmax_fwd(self, csr, z2d):
         dev = self._check_dev(csr.indptr, z2d)
@@ -1021,6 +1072,16 @@ class HipBackend(object):
             out = torch.empty((n, int(D)), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mgx_rows_unpack(n, int(D), _ptr(masks), _ptr(offsets), _ptr(values), _ptr(out), out.stride(0), _stream(dev)))
+        return out
+
+    def rows_unpack_add_csr(self, csr, masks, offsets, values, out):
+        """out[v] += the packed rows at the positions listed in row v of `csr` (int32), in CSR order; out row-strided."""
+        dev = self._check_dev(csr.indptr, masks, offsets, values, out)
+        if csr.idx_bits != 32:
+            raise DGLError("rows_unpack_add_csr: int32 CSR only")
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_rows_unpack_add_csr(csr.num_rows, _ptr(csr.indptr), _ptr(csr.indices), int(out.shape[1]), _ptr(masks),
+                                                          _ptr(offsets), _ptr(values), _ptr(out), out.stride(0), _stream(dev)))
         return out
 
     def gather_rows(self, x2d, idx):

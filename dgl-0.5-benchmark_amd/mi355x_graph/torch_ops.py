@@ -382,9 +382,11 @@ def raw_gsddmm(gidx, op, L, R, lhs_target="u", rhs_target="v"):
     operands that need broadcasting (offset tables) stay on the direct path."""
     if not NATIVE or (L is not None and R is not None and L.shape[1:] != R.shape[1:]) or (L if L is not None else R).dtype != torch.float32:
         return sparse.gsddmm_raw(gidx, op, L, R, lhs_target, rhs_target)
+    ref = L if L is not None else R
+    width = lambda x: 0 if x is None else x.numel() // max(int(x.shape[0]), 1)  # noqa: E731
+    if ref.is_cuda and sparse.HipBackend._sddmm_in_csr_order(gidx, op, L, R, lhs_target, rhs_target, width(L), width(R), width(ref), None, None):
+        return sparse.gsddmm_raw(gidx, op, L, R, lhs_target, rhs_target)  # the walk in the in-CSR's order (mgx_sddmm_coo_perm): direct route
     try:
-        ref = L if L is not None else R
-        width = lambda x: 0 if x is None else x.numel() // max(int(x.shape[0]), 1)  # noqa: E731
         with sparse.timed_call(ref.device, kernel="sddmm", op=op, out_len=(width(ref) // int(ref.shape[-1]) if op == "dot" else width(ref)),
                                l_len=width(L), r_len=width(R), nnz=gidx.num_edges(), n_src=gidx.num_src, n_dst=gidx.num_dst,
                                targets=lhs_target + rhs_target, route="torch.ops"):

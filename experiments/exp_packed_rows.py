@@ -29,7 +29,8 @@ if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.joi
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-shared",
                            "-o", so, os.path.join(src_dir, "packed_proto.hip")])
 proto = ctypes.CDLL(so)
-proto.packed_spmm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 8 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+# (mode, unroll, grid, item_row, item_beg, item_end, xcd_start, indices, slots, dense, ld, out, ldo, partial, rpb, mean, stream)
+proto.packed_spmm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int64] + [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                               ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 proto.packed_pack.argtypes = [ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 

@@ -255,6 +255,14 @@ int32_t mgx_sddmm_coo(int64_t num_src, int64_t num_dst, int64_t nnz,
                       const int64_t* l_off, const int64_t* r_off,
                       float* out, void* stream);
 
+/* The same walk over an edge list kept in ANOTHER order than the edge ids (round 5): src / dst give the q-th WALKED edge, perm[q] its
+ * edge id = the output row.  For graphs that hold an in-CSR beside (or instead of) their COO: walked in the CSR's order -- sorted by
+ * destination -- one operand row of consecutive edges is the same row and the other has the g-SpMM's locality, whole output rows are
+ * scattered by edge id.  int32 ids, element-wise op (no DOT) on u / v operands [rows, feat_len] below 4 GiB each, else
+ * MGX_ERR_UNSUPPORTED (call mgx_sddmm_coo / mgx_sddmm_csr).  Same values as mgx_sddmm_coo bit for bit. */
+int32_t mgx_sddmm_coo_perm(int64_t num_src, int64_t num_dst, int64_t nnz, const void* src, const void* dst, const void* perm,
+                           int32_t idx_bits, int32_t op, const float* lhs, const float* rhs, int32_t lhs_target, int32_t rhs_target,
+                           int64_t feat_len, float* out, void* stream);
 /* CSR form (graphs restricted to formats(['csr','csc']), main_dgl_product_sage.py:158): walks
  * the in-CSR, t(e)=V is the row, t(e)=U is indices[p], output still addressed by edge id. */
 int32_t mgx_sddmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */,
@@ -489,6 +497,10 @@ int32_t mgx_rows_pack_values(int64_t n, const void* idx, int32_t idx_bits, int64
                              const uint64_t* masks, const int64_t* offsets /* [n] */, float* values, void* stream);
 int32_t mgx_rows_unpack(int64_t n, int64_t D, const uint64_t* masks, const int64_t* offsets, const float* values,
                         float* out /* [n, D] rows out_stride apart; zeros where the mask is clear */, int64_t out_stride, void* stream);
+/* out[v, :] += sum over the entries p = positions[q], q in [indptr[v], indptr[v+1]), of the packed row p (int32 CSR over the n output rows;
+ * entries added in CSR order: deterministic): the returned halo-row gradients added into their owners without a dense intermediate. */
+int32_t mgx_rows_unpack_add_csr(int64_t n, const int32_t* indptr, const int32_t* positions, int64_t D, const uint64_t* masks,
+                                const int64_t* offsets, const float* values, float* out, int64_t out_stride, void* stream);
 
 /* ------------------------------------------------------------------ neighbor sampling
  * Replaces the CPU-side sampling of dgl.dataloading.MultiLayerNeighborSampler / dgl.sampling.sample_neighbors

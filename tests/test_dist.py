@@ -287,11 +287,14 @@ def test_rccl_api_path_single_rank():
         model = build_model().to(dev)
         mdist.broadcast_parameters(model)
         g._comm.trace = []  # bench.py's measurement of the exposed exchange: events around every wait() on the RCCL work handle
+        packed0 = mdist.SPARSE_EXCHANGES[0]
         out = model(g, feats)
         loss = F.nll_loss(out[train], labels[train])
         loss.backward()
         torch.cuda.synchronize()
-        assert len(g._comm.trace) == g._comm.n_exchanges > 0
+        # one traced message per exchange, two (bitmaps, then values) for a forward exchange in the packed form (dist.SparseHalo)
+        assert len(g._comm.trace) == g._comm.n_exchanges + (mdist.SPARSE_EXCHANGES[0] - packed0) > 0
+        assert mdist.SPARSE_EXCHANGES[0] - packed0 == len(model.layers) - 1
         assert all(a.elapsed_time(b) >= 0.0 and nb == 0 for a, b, nb in g._comm.trace)  # one rank: nothing to receive
         g._comm.trace = None
         mdist.allreduce_gradients(model)

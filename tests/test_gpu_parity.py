@@ -207,6 +207,37 @@ def test_gsddmm(oracle, shape, op, fmt):
         assert np.array_equal(out.cpu().numpy(), ref)  # one rounding per element: bit-exact
 
 
+@pytest.mark.parametrize("op,targets", [("add", "uv"), ("sub", "vu"), ("mul", "uu"), ("div", "vv"), ("copy_lhs", "uv"), ("copy_rhs", "uv"),
+                                        ("copy_lhs", "vu")])
+@pytest.mark.parametrize("shape", [(300, 400, 5000, 64), (300, 300, 4097, 4), (257, 513, 9000, 100), (64, 64, 600, 256)])
+def test_gsddmm_walked_in_csr_order(oracle, shape, op, targets, monkeypatch):
+    """Round 5: a graph that holds its COO AND an in-CSR -- the lean kernel over the CSR's order, whole output rows
+    scattered by edge id (mgx_sddmm_coo_perm) -- against the oracle and against the walk in edge-id order, bit for bit."""
+    from mi355x_graph import sparse
+    n_src, n_dst, nnz, D = shape
+    src, dst = random_graph(n_src, n_dst, nnz, seed=D + 11)
+    rng = np.random.default_rng(D + 1)
+    feats = {"u": rng.random((n_src, D), dtype=np.float32) + 0.25, "v": rng.random((n_dst, D), dtype=np.float32) + 0.5}
+    Lh, Rh = feats[targets[0]], feats[targets[1]]
+    g = mk(n_src, n_dst, src, dst)
+    g._index.csc()   # materialised beside the edge list, as after any update_all() on the graph
+    assert g._index.has_format("coo") and g._index.has_format("csc")
+    monkeypatch.setenv("MGX_SDDMM_WALK", "csr")
+    sparse.PROFILE = []
+    try:
+        out = ops.gsddmm(g, op, T(Lh), T(Rh), targets[0], targets[1])
+    finally:
+        recs, sparse.PROFILE = sparse.PROFILE, None
+    assert [r.get("walk") for r in recs if r.get("kernel") == "sddmm"] == ["csr order"]   # the permuted walk really ran
+    monkeypatch.setenv("MGX_SDDMM_WALK", "coo")
+    plain = ops.gsddmm(g, op, T(Lh), T(Rh), targets[0], targets[1])
+    assert torch.equal(out, plain)
+    assert np.array_equal(out.cpu().numpy(), oracle.sddmm(src, dst, op, Lh, Rh, targets[0], targets[1]))
+    # default (auto): a small graph keeps the edge list's own order
+    monkeypatch.delenv("MGX_SDDMM_WALK")
+    assert not sparse.HipBackend._sddmm_in_csr_order(g._index, op, T(Lh), T(Rh), targets[0], targets[1], D, D, D, None, None)
+
+
 def test_gsddmm_targets_and_heads(oracle):
     n, nnz, H, F = 500, 7000, 4, 8
     src, dst = random_graph(n, n, nnz, seed=9)

@@ -80,6 +80,40 @@ def test_pack_and_unpack_follow_the_contract(D):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [16, 64, 100])
+def test_packed_rows_added_into_their_owners(D):
+    """mgx_rows_unpack_add_csr == unpack to dense rows, then add them into their owners in CSR order (what dist.SparseHalo's backward
+    did in two steps): same order of addition, so bit for bit."""
+    dev = torch.device("cuda:0")
+    be = sparse.backend_for(torch.empty(1, device=dev))
+    rng = np.random.default_rng(100 + D)
+    n_own, n_sent = 400, 1300
+    owner = np.sort(rng.integers(0, n_own, n_sent)).astype(np.int32)          # several returned rows per owner, some owners none
+    owner[owner % 7 == 3] += 1
+    owner = np.sort(np.clip(owner, 0, n_own - 1))
+    pos = np.arange(n_sent)
+    rng.shuffle(pos)                                                             # the rows of one owner lie anywhere in the packed buffer
+    x = (rng.standard_normal((n_sent, D)) * (rng.random((n_sent, D)) < 0.25)).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev)
+    masks, counts = be.rows_pack_count(xt, None)
+    off = torch.zeros(n_sent + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, dtype=torch.int64, out=off[1:])
+    vals = be.rows_pack_values(xt, None, masks, off, int(off[-1]))
+    csr = sparse.coo_to_csr(n_own, n_sent, torch.from_numpy(owner).to(dev), torch.from_numpy(pos.astype(np.int32)).to(dev))
+    base = rng.standard_normal((n_own, D + 4)).astype(np.float32)
+    out = torch.from_numpy(base).to(dev)
+    be.rows_unpack_add_csr(csr, masks, off, vals, out[:, :D])
+    want = base.copy()
+    ip, ix = csr.indptr.cpu().numpy(), csr.indices.cpu().numpy()
+    for v in range(n_own):
+        for q in range(ip[v], ip[v + 1]):
+            want[v, :D] = want[v, :D] + x[ix[q]]
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, D:], base[:, D:])
+    assert np.array_equal(got[:, :D], want[:, :D])
+
+
+@pytest.mark.gpu
 def test_empty_and_unsupported_shapes():
     dev = torch.device("cuda:0")
     be = sparse.backend_for(torch.empty(1, device=dev))
