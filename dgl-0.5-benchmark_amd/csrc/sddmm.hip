@@ -251,11 +251,12 @@ __global__ __launch_bounds__(kBlock) void sddmm_coo32_kernel(const SddmmArgs<int
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int j = k + u * NB + sub;
+        // (the cross-lane read stays OUTSIDE the branch below: ds_bpermute returns nothing useful from a lane that is switched off)
+        const uint32_t pe = PERM ? (uint32_t)__builtin_amdgcn_ds_bpermute((j < cnt ? j : 0) * 4, po) : 0u;
         if (j < cnt && kactive) {
           const V val = OPS == 1 ? lv[u] : (OPS == 2 ? rv[u] : sddmm_op<V>(op, lv[u], rv[u]));
           V* o;
           if (PERM) {  // the edge's own output row: 64-bit offset (E x D x 4 bytes may pass 4 GiB)
-            const uint32_t pe = (uint32_t)__builtin_amdgcn_ds_bpermute(j * 4, po);
             o = reinterpret_cast<V*>(outb + ((uint64_t)pe * rowbytes + kc4));
           } else {
             o = reinterpret_cast<V*>(ob + ((uint32_t)j * rowbytes + kc4));

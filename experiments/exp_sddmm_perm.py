@@ -58,7 +58,11 @@ for name in ("reddit", "reddit-small", "proteins"):
         t0, _, _ = kb.time_op(coo)
         t1, _, _ = kb.time_op(perm)
         t2, _, _ = kb.time_op(old)
-        assert torch.equal(out0, out1) and torch.equal(out0, out2)
+        same1, same2 = torch.equal(out0, out1), torch.equal(out0, out2)
+        if not (same1 and same2):
+            bad = (out0 != out1).any(1)
+            print("!! D = %d: csr-order walk %s (%d rows differ, first %s), old csr body %s" % (D, "same" if same1 else "DIFFERS", int(bad.sum()),
+                  bad.nonzero()[:4].flatten().tolist(), "same" if same2 else "DIFFERS"))
         b = kb.sddmm_bytes(n_src, n_dst, nnz, D, "add")
         print("%5d %12.3f %12.3f %12.3f   %.3f / %.3f" % (D, t0 * 1e3, t1 * 1e3, t2 * 1e3, b / t0 / 8e12, b / t1 / 8e12))
         del u, v, out0, out1, out2
