@@ -15,8 +15,8 @@ constexpr int kBlock = 256;        // 4 waves / workgroup: one per SIMD
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with its own 4 MiB L2
 
-// A/B switches of measured alternatives (README: "A/B toggles") are read ONCE per process, not on every launch.
-#define MGX_ENV_FLAG(name) ([]() -> bool { static const bool v = getenv(name) != nullptr; return v; }())
+// (The C library reads NO environment variables: every choice between kernels is made from the arguments of a call.  The A/B switches
+// of rounds 1 - 4 went with the variants that lost -- docs/LOG_r0*.md has their numbers.)
 
 void set_error(const char* fmt, ...);
 void note_spmm_kernel(const char* name);  // mgx_last_spmm_kernel(): which kernel family a g-SpMM call was routed to

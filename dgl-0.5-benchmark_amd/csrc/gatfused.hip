@@ -496,13 +496,7 @@ static bool gat_launch(const GatArgs& a, bool drop, hipStream_t s) {
   }
 }
 
-static int gat_rows_per_block() {
-  static const char* e = getenv("MGX_ROWS_PER_BLOCK");  // read once per process
-  int x = e ? atoi(e) : 16;
-  if (x < 4) x = 4;
-  if (x > 1024) x = 1024;
-  return x / 4 * 4;
-}
+static int gat_rows_per_block() { return 16; }  // work items per workgroup: the g-SpMM's measured choice (spmm.hip)
 
 static int32_t gat_check(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, int64_t F, int64_t gathered_rows, float p,
                          const char* who) {
@@ -592,7 +586,6 @@ extern "C" int64_t mgx_gat_fused_workspace(const mgx_spmm_plan* plan, int64_t H,
 
 extern "C" int64_t mgx_gat_fused_pack_workspace(int64_t num_src, int64_t num_dst, int64_t H, int64_t F) {
   using namespace mgx;
-  if (getenv("MGX_GAT_NO_PACK") != nullptr) return 0;  // A/B switch
   const int la = gat_pack_ld(H * F, H), lb = gat_pack_ld(H * F, 4 * H);
   const int64_t rows = num_src > num_dst ? num_src : num_dst;
   const int64_t ld = la > lb ? la : lb;
@@ -601,10 +594,9 @@ extern "C" int64_t mgx_gat_fused_pack_workspace(int64_t num_src, int64_t num_dst
 }
 
 static bool gat_el_in_kernel(int64_t H, int64_t F, const float* attn_l) {
-  static const bool off = getenv("MGX_GAT_EL_GATHER") != nullptr;  // A/B switch: always gather el
   // heads of up to 16 columns only: the reduction over a head's lanes costs log2(F / 4) lane swaps per edge -- measured: 8 x 16
   // (reddit-small, BASELINE config 3) epoch 5.61 -> 5.51 ms, but 4 x 64 (arxiv) 2.79 -> 2.89 ms with the swaps of 16-lane heads
-  return attn_l != nullptr && !off && H > 1 && F % 4 == 0 && F >= 8 && F <= 16 && H * F >= 64 && (uintptr_t)attn_l % 16 == 0;
+  return attn_l != nullptr && H > 1 && F % 4 == 0 && F >= 8 && F <= 16 && H * F >= 64 && (uintptr_t)attn_l % 16 == 0;
 }
 
 extern "C" int32_t mgx_gat_fused_fwd(const mgx_csr* csr, const mgx_spmm_plan* plan, int64_t H, int64_t F, const float* feat,

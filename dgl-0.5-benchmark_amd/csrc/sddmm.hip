@@ -452,7 +452,7 @@ static bool try_headdot(const SddmmArgs<int32_t>& a, hipStream_t s) {
   const bool ragged = RS % 4 != 0;
   const int64_t lph = RS / 4;
   if (ragged) {
-    if (a.out_len != 1 || D <= 4 || D > 64 || (uintptr_t)a.L % 4 || (uintptr_t)a.R % 4 || MGX_ENV_FLAG("MGX_SPMM_NO_RAGGED")) return false;
+    if (a.out_len != 1 || D <= 4 || D > 64 || (uintptr_t)a.L % 4 || (uintptr_t)a.R % 4) return false;
   } else {
     if ((lph & (lph - 1)) != 0 || lph > 16) return false;
     if ((uintptr_t)a.L % 16 || (uintptr_t)a.R % 16) return false;
@@ -474,13 +474,13 @@ static bool try_headdot(const SddmmArgs<int32_t>& a, hipStream_t s) {
 }
 template <typename Idx> static bool try_headdot_any(const SddmmArgs<Idx>&, hipStream_t) { return false; }
 template <> bool try_headdot_any<int32_t>(const SddmmArgs<int32_t>& a, hipStream_t s) {
-  return !MGX_ENV_FLAG("MGX_SDDMM_GENERIC_DOT") && try_headdot(a, s);
+  return try_headdot(a, s);
 }
 
 // int32 COO graphs with element-wise DIRECT operands on node targets, each addressable with 32-bit byte offsets
 template <int VEC, int G, bool ELIGIBLE>
 static bool launch_coo32(const SddmmArgs<int32_t>& a, dim3 grid, hipStream_t s) {
-  if (!ELIGIBLE || MGX_ENV_FLAG("MGX_SDDMM_V1")) return false;  // A/B switch
+  if (!ELIGIBLE) return false;
   auto rows_of = [&](int t) -> int64_t { return t == MGX_TARGET_U ? a.n_cols : (t == MGX_TARGET_V ? a.n_rows : -1); };
   const int64_t lim = int64_t(1) << 32;
   if (a.L && (rows_of(a.lhs_target) <= 0 || rows_of(a.lhs_target) * a.out_len * 4 >= lim)) return false;
@@ -658,7 +658,7 @@ extern "C" int32_t mgx_sddmm_coo_perm(int64_t num_src, int64_t num_dst, int64_t 
   const int64_t lim = int64_t(1) << 32;
   auto rows_of = [&](int t) -> int64_t { return t == MGX_TARGET_U ? num_src : (t == MGX_TARGET_V ? num_dst : -1); };
   const bool need_l = op != MGX_OP_COPY_RHS, need_r = op != MGX_OP_COPY_LHS;
-  if (idx_bits != 32 || op == MGX_OP_DOT || nnz >= (int64_t(1) << 31) || MGX_ENV_FLAG("MGX_SDDMM_V1") ||
+  if (idx_bits != 32 || op == MGX_OP_DOT || nnz >= (int64_t(1) << 31) ||
       (need_l && (rows_of(lhs_target) <= 0 || rows_of(lhs_target) * feat_len * 4 >= lim)) ||
       (need_r && (rows_of(rhs_target) <= 0 || rows_of(rhs_target) * feat_len * 4 >= lim)))
     MGX_UNSUPPORTED("mgx_sddmm_coo_perm: int32 ids, an element-wise op on u / v operands below 4 GiB only (use mgx_sddmm_coo)");

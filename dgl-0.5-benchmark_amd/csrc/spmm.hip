@@ -62,14 +62,9 @@ struct SpmmFastArgs {
 
 // Work items per workgroup.  Workgroups are dispatched in blockIdx order, so a SMALL value makes
 // the rows in flight on one XCD a tight window of the schedule (256 resident groups x rpb rows)
-// and balances skewed rows better; 16 measured best on MI355X (64: +5..50 %, 256: +20..150 %).
-static int rows_per_block_setting() {
-  static const char* e = getenv("MGX_ROWS_PER_BLOCK");  // read once per process
-  int x = e ? atoi(e) : 16;
-  if (x < 4) x = 4;
-  if (x > 1024) x = 1024;
-  return x / 4 * 4;
-}
+// and balances skewed rows better; 16 measured best on MI355X (64: +5..50 %, 256: +20..150 %; re-checked
+// under two-part plans: profiles/r04_rest_launch_sweep.txt).
+constexpr int kItemsPerBlock = 16;
 
 template <int G, bool SPLIT>
 struct Unroll {
@@ -322,16 +317,9 @@ __global__ __launch_bounds__(kBlock) void spmm_rowwave_kernel(const SpmmFastArgs
 // RAGGED (VEC = 4, D % 4 != 0, e.g. the 41-class output layer of the reddit GAT): rows are still gathered 16 bytes per lane
 // (dword-aligned accesses); the lane that owns the last 1-3 columns loads the LAST FOUR floats of the row instead -- no
 // read past the row, its own columns are the tail components of that window -- and only the epilogue distinguishes it.
+// (8 waves per SIMD -- 64 VGPRs, two spilled -- was measured and changes nothing: profiles/r02_spmm_variants.txt.)
 template <int VEC, int G, int MODE, int WMODE, bool LANEMASK, bool RAGGED = false, bool MASKED = false>
-#ifndef MGX_RW32_WAVES  // -DMGX_RW32_WAVES=8: the occupancy experiment of profiles/r02_spmm_variants.txt (64 VGPRs, spills)
-#define MGX_RW32_WAVES 0
-#endif
-#if MGX_RW32_WAVES > 0
-#define MGX_RW32_BOUNDS __launch_bounds__(kBlock, MGX_RW32_WAVES)
-#else
-#define MGX_RW32_BOUNDS __launch_bounds__(kBlock)
-#endif
-__global__ MGX_RW32_BOUNDS void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
+__global__ __launch_bounds__(kBlock) void spmm_rowwave32_kernel(const SpmmFastArgs<int32_t> a) {
   typedef typename VecT<VEC>::type VA;
   typedef VA VU __attribute__((aligned(4)));  // RAGGED: gathers / stores are only dword-aligned
   typedef typename std::conditional<RAGGED, VU, VA>::type V;
@@ -710,15 +698,12 @@ static bool launch_rowgroup32(SpmmFastArgs<int32_t> a, int64_t nnz, hipStream_t 
   // the arxiv-shaped graph (6.9 in-edges on average, power-law tail, a 13 k-edge hub = 52 consecutive 256-edge chunks) TWICE AS SLOW
   // at D = 4 .. 32 (81 -> 180 us) while uniform short rows gain 2 - 3.5x (profiles/r04_rowgroup.txt, r04_rowgroup_skew.txt); the host
   // layer decides per CSR and lane-group count from the item lengths (mi355x_graph/sparse.py: CsrView.short_rows).
-  // MGX_ROWGROUP=0 never, =1 whenever eligible (A/B runs).
-  static const int env = getenv("MGX_ROWGROUP") ? atoi(getenv("MGX_ROWGROUP")) : -1;
   constexpr int NB = kWave / G;
   if constexpr (NB < 2 || VEC != 4 || MODE == MODE_MUL_EDGE) {
     return false;
   } else {
-    if (env == 0 || a.ragged || a.src_scale || a.src_bits || a.D % 4 != 0) return false;
-    if (a.src_rows * (int64_t)a.lds * 4 >= (int64_t(1) << 32) || MGX_ENV_FLAG("MGX_SPMM_V1")) return false;
-    if (env != 1 && !a.short_rows) return false;
+    if (!a.short_rows || a.ragged || a.src_scale || a.src_bits || a.D % 4 != 0) return false;
+    if (a.src_rows * (int64_t)a.lds * 4 >= (int64_t(1) << 32)) return false;
     (void)nnz;
     note_spmm_kernel("rowgroup32");
     a.rpb = 2 * kWavesPerBlock * NB;  // two batches per wave: the second's ids travel under the first's gathers
@@ -861,7 +846,6 @@ __global__ __launch_bounds__(kBlock) void spmm_generic_kernel(const SpmmGenericA
 // int32 graphs whose gathered matrix is addressable with 32-bit byte offsets take the lean kernel
 template <int VEC, int G, int MODE>
 static bool launch_rowwave32(const SpmmFastArgs<int32_t>& a, int64_t src_rows, dim3 grid, hipStream_t s) {
-  if (MGX_ENV_FLAG("MGX_SPMM_V1")) return false;  // A/B switch
   if (src_rows * (int64_t)a.lds * 4 >= (int64_t(1) << 32)) return false;
   if (a.ragged) {  // VEC == 4, D % 4 != 0, one weight per edge at most (launch_fast checked eligibility)
     if (VEC == 4 && MODE != MODE_COPY_RHS) {
@@ -894,9 +878,9 @@ template <typename Idx, int VEC, int G, int MODE>
 static void launch_fast_g(SpmmFastArgs<Idx> a, bool split, int64_t nnz, hipStream_t s) {
   constexpr int NB = kWave / G;
   if (a.ragged) split = true;  // only the lean row-per-wave kernel implements the ragged 16-byte tail window
-  if (a.lds != a.D || a.ldo != a.D) split = true;  // ... and row strides (spmm_fast_kernel ignores lds / ldo; MGX_SPLIT_FACTOR A/B runs)
+  if (a.lds != a.D || a.ldo != a.D) split = true;  // ... and row strides (spmm_fast_kernel ignores lds / ldo)
   if (launch_rowgroup32<VEC, G, MODE>(a, nnz, s)) return;  // short rows: one item per lane group (lean, int32)
-  a.rpb = rows_per_block_setting();
+  a.rpb = kItemsPerBlock;
   if (!split && a.rpb < kWavesPerBlock * NB) a.rpb = kWavesPerBlock * NB;  // one item per lane group
   a.nblocks = round_up((a.n_items + a.rpb - 1) / a.rpb, kXcds);
   dim3 grid((unsigned)a.nblocks, (unsigned)((a.D + G * VEC - 1) / (G * VEC)));
@@ -920,21 +904,17 @@ static void launch_fast_v(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s
   // D = 256; products-shaped 10.37 -> 9.91 ms at D = 256 (experiments/exp_wide_ragged.py).  The index stream is re-read per
   // pass (4 bytes per edge against 512 gathered).  A second pass that owns only a few columns costs most of a full one
   // (reddit-shaped, D = 132 / 144 / 160 / 192: one 64-lane pass 4.24 / 4.07 / 4.12 / 5.08 ms, 32 + remainder 5.64 / 5.26 / 4.88 /
-  // 4.96 ms), so rows of 33..44 lanes keep the single 64-lane pass.  MGX_SPMM_G=<lanes> overrides (A/B runs; 64 = old rule).
-  static const int env_g = getenv("MGX_SPMM_G") ? atoi(getenv("MGX_SPMM_G")) : 0;
+  // 4.96 ms), so rows of 33..44 lanes keep the single 64-lane pass.
   const double avg_deg = a.n_rows > 0 ? (double)nnz / (double)a.n_rows : 0.0;
-  if (MODE == MODE_COPY_LHS) {
-    if (env_g > 0) { if (env_g < G && !a.ragged) G = env_g; }
-    else if (G > 32 && lanes > 44 && avg_deg >= 24.0) G = 32;  // short rows: the per-row cost of a second pass outweighs it
-  }                                                            // (arxiv-shaped, 6.9 in-edges per node, D = 256: 0.202 -> 0.221 ms)
+  // short rows: the per-row cost of a second pass outweighs it (arxiv-shaped, 6.9 in-edges per node, D = 256: 0.202 -> 0.221 ms)
+  if (MODE == MODE_COPY_LHS && G > 32 && lanes > 44 && avg_deg >= 24.0) G = 32;
   const int NB = kWave / G;
   // One row per wave (lane groups share the row's edges) or one row per lane group.  The lean int32 kernel is faster
   // than the row-per-group kernel at every degree measured (arxiv-shaped, avg in-degree 6.9: D = 64 187 -> 108 us, D = 8
   // 148 -> 82 us; cora / pubmed 40-54 -> 22-26 us), so it is always taken when eligible; the 64-bit kernels keep the old
-  // rule (rows long enough to feed all NB lane groups).  MGX_SPLIT_FACTOR overrides the factor for A/B runs.
-  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) && !MGX_ENV_FLAG("MGX_SPMM_V1");
-  static const double env_factor = getenv("MGX_SPLIT_FACTOR") ? atof(getenv("MGX_SPLIT_FACTOR")) : -1.0;
-  const double split_factor = env_factor >= 0.0 ? env_factor : (lean ? 0.0 : 2.0);
+  // rule (rows long enough to feed all NB lane groups).
+  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32);
+  const double split_factor = lean ? 0.0 : 2.0;
   const bool split = (NB == 1) || (avg_deg >= split_factor * NB);
   switch (G) {
     case 1: launch_fast_g<Idx, VEC, 1, MODE>(a, split, nnz, s); break;
@@ -954,8 +934,8 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
   // MODE_MUL_EDGE needs every lane's VEC features inside one head: F % VEC == 0.
   const int vec_ok = (MODE == MODE_MUL_EDGE) ? a.F : a.D;
   // odd widths (41 classes): 16-byte gathers with a ragged last lane, lean int32 kernel only, one head
-  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) && !MGX_ENV_FLAG("MGX_SPMM_V1");
-  if (lean && MODE != MODE_COPY_RHS && a.D % 4 != 0 && a.D > 4 && (a.D <= 256 || MODE == MODE_COPY_LHS) && a.H == 1 && !MGX_ENV_FLAG("MGX_SPMM_NO_RAGGED") &&
+  const bool lean = sizeof(Idx) == 4 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32);
+  if (lean && MODE != MODE_COPY_RHS && a.D % 4 != 0 && a.D > 4 && (a.D <= 256 || MODE == MODE_COPY_LHS) && a.H == 1 &&
       (uintptr_t)a.src % 4 == 0) {
     SpmmFastArgs<Idx> b = a;
     b.ragged = 1;
@@ -1043,7 +1023,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
       if (a.lds != a.D || a.ldo != a.D) {  // strided rows: the lean row-per-wave kernel with 16-byte lanes only
         const bool ok = sizeof(Idx) == 4 && a.D % 4 == 0 && a.lds % 4 == 0 && a.ldo % 4 == 0 && a.lds >= a.D && a.ldo >= a.D &&
                         (uintptr_t)U % 16 == 0 && (uintptr_t)out % 16 == 0 && a.src_rows * (int64_t)a.lds * 4 < (int64_t(1) << 32) &&
-                        !MGX_ENV_FLAG("MGX_SPMM_V1") && !src_bits;
+                        !src_bits;
         if (!ok) MGX_UNSUPPORTED("mgx_spmm_copy_u_strided: needs int32 ids, D and both strides multiples of 4, 16-byte aligned "
                                  "pointers and a gathered matrix under 4 GiB");
       }

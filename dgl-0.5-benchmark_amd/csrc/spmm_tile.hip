@@ -55,37 +55,12 @@ struct TileArgs {
   int num_tiles, tiles_per_xcd;
   int D, lds, ldo;  // columns, row strides (floats) of x and out
   int mean, accum;
-#ifdef MGX_TILE_STAMPS
-  unsigned long long* stamps;  // diagnostic build only: [num_tiles][16 waves][8] cycles (barrier wait, work, direct, total, ...)
-#endif
 };
 
-#ifdef MGX_TILE_STAMPS
-static unsigned long long* g_tile_stamps = nullptr;
-#define MGX_STAMP() __builtin_amdgcn_s_memtime()
-#endif
-
-// ---- per-slot FULL / FREE words instead of the per-chunk workgroup barrier (FLAGS = true; A/B: MGX_TILE_FLAGS=1) -------------------
-// flags[s] counts the loader waves that have published a chunk into ring slot s (a chunk is readable once NL * (its generation + 1)
-// have); flags[8 + s] counts the consumer waves that have released it (refillable once NC * generation have).  LDS atomics by lane 0,
-// volatile LDS polls with s_sleep; a poll gives up after 2^20 rounds so that a bug shows as a wrong answer, never as a hung GPU.
-typedef __attribute__((address_space(3))) uint32_t lds_u32;  // LDS address space: ds_* instructions (lgkmcnt), never flat loads (vmcnt)
-__device__ __forceinline__ void flag_add(lds_u32* f) {
-  if ((threadIdx.x & (kWave - 1)) == 0) __hip_atomic_fetch_add(f, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void flag_wait(lds_u32* f, uint32_t target) {
-  volatile lds_u32* vf = f;
-  for (int spin = 0; spin < (1 << 20); ++spin) {
-    if (*vf >= target) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
 
 // ---- loader waves ---------------------------------------------------------------------------------------------------------
-template <int W, int NL, int RING, bool FLAGS>
-__device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, lds_u32* flags, int wave, int lane, int tile, int cbeg, int n,
-                                            int col0) {
-  constexpr int NC = W - NL;
+template <int W, int NL, int RING>
+__device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, int wave, int lane, int tile, int cbeg, int n, int col0) {
   constexpr int PER = kDmaPerChunk / NL;  // DMA instructions per loader wave per chunk
   static_assert((RING - 2) * PER <= 48, "the counted vmcnt wait must stay below the 6-bit counter");
   const int g = lane >> 4, l = lane & 15;
@@ -114,44 +89,18 @@ __device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, lds_u
     }
   };
   const int pre = n < RING - 1 ? n : RING - 1;
-#ifdef MGX_TILE_STAMPS
-  unsigned long long t_wait = 0, t_bar = 0, t_issue = 0;
-  const unsigned long long t_begin = MGX_STAMP();
-#endif
   for (int k = 0; k < pre; ++k) issue(k);
   for (int c = 0; c < n; ++c) {
     const int rem = n - 1 - c;  // chunks issued after c that may stay in flight
-#ifdef MGX_TILE_STAMPS
-    const unsigned long long t0 = MGX_STAMP();
-#endif
     if (RING >= 4 && rem >= 2) wait_vmcnt<(RING >= 4 ? 2 : 0) * PER>();  // chunks c + 1, c + 2 may stay in flight
     else if (RING >= 3 && rem >= 1) wait_vmcnt<(RING >= 3 ? 1 : 0) * PER>();
     else wait_vmcnt<0>();
-#ifdef MGX_TILE_STAMPS
-    const unsigned long long t1 = MGX_STAMP();
-#endif
-    if (FLAGS) {
-      flag_add(flags + c % RING);  // this wave's share of chunk c has landed: publish
-      if (c >= 1 && c + RING - 1 < n) flag_wait(flags + 8 + (c - 1) % RING, (uint32_t)(NC * ((c - 1) / RING + 1)));  // chunk c - 1 released
-    } else {
-      __builtin_amdgcn_s_barrier();  // chunk c has landed; every consumer has finished chunk c - 1
-    }
+    // chunk c has landed; every consumer has finished chunk c - 1.  (Per-slot FULL / FREE words in LDS instead of this barrier were built
+    // and measured in round 4 -- slower at every geometry, docs/LOG_r04.md section 8 -- and are gone.)
+    __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#ifdef MGX_TILE_STAMPS
-    const unsigned long long t2 = MGX_STAMP();
-#endif
     if (c + RING - 1 < n) issue(c + RING - 1);  // into the slot chunk c - 1 occupied
-#ifdef MGX_TILE_STAMPS
-    const unsigned long long t3 = MGX_STAMP();
-    t_wait += t1 - t0; t_bar += t2 - t1; t_issue += t3 - t2;
-#endif
   }
-#ifdef MGX_TILE_STAMPS
-  if (a.stamps && lane == 0) {
-    unsigned long long* o = a.stamps + ((int64_t)tile * 16 + wave) * 8;
-    o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = MGX_STAMP() - t_begin; o[4] = n;
-  }
-#endif
   // the consumers' (n + 1)-th barrier (before the direct part reuses the ring): the loaders take part in it, as in gat_tile.inc,
   // instead of relying on exited waves being dropped from the workgroup's barrier count
   wait_vmcnt<0>();
@@ -159,9 +108,8 @@ __device__ __forceinline__ void tile_loader(const TileArgs& a, char* ring, lds_u
 }
 
 // ---- consumer waves -------------------------------------------------------------------------------------------------------
-template <int W, int NL, int NACC, int RING, bool FLAGS>
-__device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, lds_u32* flags, int cw, int lane, int tile, int cbeg, int n,
-                                              int col0) {
+template <int W, int NL, int NACC, int RING>
+__device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, int cw, int lane, int tile, int cbeg, int n, int col0) {
   constexpr int NC = W - NL;
   constexpr int R = NC * NACC * 4;
   const int g = lane >> 4, l = lane & 15;
@@ -170,10 +118,6 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, lds
   v4f acc[NACC];
 #pragma unroll
   for (int j = 0; j < NACC; ++j) acc[j] = (v4f)(0.f);
-#ifdef MGX_TILE_STAMPS
-  unsigned long long t_bar = 0, t_lds = 0, t_dir = 0, n_ss = 0, td0 = 0, td1 = 0;
-  const unsigned long long t_begin = MGX_STAMP();
-#endif
 
   // The per-wave STREAMS are read once from HBM, 16 bytes (LDS part) or 64 bytes (direct part) per superstep and wave: a
   // register prefetch two supersteps ahead exposes an HBM miss per cache line (measured: 3.7 us per chunk of 12 supersteps).
@@ -211,21 +155,8 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, lds
       const v4u cr = NACC > 8 ? cnt[2 * k + 1] : (v4u)(0u);
       const uint32_t cnts[8] = {cq.x, cq.y, cq.z, cq.w, cr.x, cr.y, cr.z, cr.w};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every LDS read of the previous chunk has returned
-#ifdef MGX_TILE_STAMPS
-      const unsigned long long tb0 = MGX_STAMP();
-#endif
-      if (FLAGS) {
-        if (c > 0) flag_add(flags + 8 + (c - 1) % RING);    // this wave is done with chunk c - 1: its slot may be refilled
-        flag_wait(flags + c % RING, (uint32_t)(NL * (c / RING + 1)));  // chunk c is in its ring slot
-      } else {
-        __builtin_amdgcn_s_barrier();                       // chunk c is in its ring slot
-      }
+      __builtin_amdgcn_s_barrier();                         // chunk c is in its ring slot
       asm volatile("" ::: "memory");
-#ifdef MGX_TILE_STAMPS
-      const unsigned long long tb1 = MGX_STAMP();
-      t_bar += tb1 - tb0;
-      const int ss_before = ss;
-#endif
       const uint32_t lrow = (uint32_t)(c % RING) * kChunkBytes + (uint32_t)l * 16u;
       auto gather4 = [&](uint32_t w, v4f (&v)[4]) {
 #pragma unroll
@@ -261,11 +192,6 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, lds
           ss += 1;
         }
       }
-#ifdef MGX_TILE_STAMPS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      t_lds += MGX_STAMP() - tb1;
-      n_ss += ss - ss_before;
-#endif
       k += NC;
     }
   }
@@ -277,14 +203,8 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, lds
   // staged part (barrier, which the loader waves join before they exit).
   auto direct_part = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#ifdef MGX_TILE_STAMPS
-    td0 = MGX_STAMP();
-#endif
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-#ifdef MGX_TILE_STAMPS
-    td1 = MGX_STAMP();
-#endif
     const int64_t k = (int64_t)tile * NC + cw;
     const int so = as_const(a.dir_off)[k], se = as_const(a.dir_off)[k + 1];  // supersteps
     if (se > so) {
@@ -353,10 +273,6 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, lds
         }
       }
     }
-#ifdef MGX_TILE_STAMPS
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    t_dir = MGX_STAMP() - td1;
-#endif
   };
 
   // (Measured and dropped: tiles alternating the ORDER of the two parts by dispatch round, with the direct part's windows in a
@@ -365,12 +281,6 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, lds
   staged_part();
   direct_part();
 
-#ifdef MGX_TILE_STAMPS
-  if (a.stamps && lane == 0) {
-    unsigned long long* o = a.stamps + ((int64_t)tile * 16 + (cw + NL)) * 8;
-    o[0] = t_bar; o[1] = t_lds; o[2] = t_dir; o[3] = MGX_STAMP() - t_begin; o[4] = n_ss; o[5] = td1 - td0; o[6] = t_begin; o[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20) /* XCC_ID */;
-  }
-#endif
   // ---- epilogue: one row per lane group and accumulator
   if (!cvalid) return;
 #pragma unroll
@@ -393,15 +303,10 @@ __device__ __forceinline__ void tile_consumer(const TileArgs& a, char* ring, lds
   }
 }
 
-template <int W, int NL, int NACC, int RING, bool FLAGS = false>
+template <int W, int NL, int NACC, int RING>
 __global__ __launch_bounds__(W * kWave, 4) void spmm_tile_kernel(const TileArgs a) {
   // W = 16: one workgroup per CU (4 waves per SIMD); W = 8: two per CU -- either way 128 registers per lane
   __shared__ __attribute__((aligned(1024))) char ring[RING * kChunkBytes + W * kStreamRingBytes];
-  __shared__ uint32_t flags[16];
-  if (FLAGS) {
-    if (threadIdx.x < 16) flags[threadIdx.x] = 0;
-    __syncthreads();
-  }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & (kWave - 1);
   // block b serves XCD b % 8 (observed round-robin placement; speed only): consecutive tiles of the schedule -- which share
@@ -412,8 +317,8 @@ __global__ __launch_bounds__(W * kWave, 4) void spmm_tile_kernel(const TileArgs 
   const int cbeg = a.tile_chunk_ptr[tile];
   const int n = a.tile_chunk_ptr[tile + 1] - cbeg;
   const int col0 = blockIdx.y * kPassCols;
-  if (wave < NL) tile_loader<W, NL, RING, FLAGS>(a, ring, (lds_u32*)flags, wave, lane, tile, cbeg, n, col0);
-  else tile_consumer<W, NL, NACC, RING, FLAGS>(a, ring, (lds_u32*)flags, wave - NL, lane, tile, cbeg, n, col0);
+  if (wave < NL) tile_loader<W, NL, RING>(a, ring, wave, lane, tile, cbeg, n, col0);
+  else tile_consumer<W, NL, NACC, RING>(a, ring, wave - NL, lane, tile, cbeg, n, col0);
 }
 
 // ---- narrow rows ------------------------------------------------------------------------------------------------------------
@@ -489,37 +394,14 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
       if (k < n) issue_rows(k);
       if (k + RING - 1 < n) issue_ids(k + RING - 1);
     }
-#ifdef MGX_TILE_STAMPS
-    unsigned long long t_wait = 0, t_bar = 0, t_issue = 0;
-    const unsigned long long t_begin = MGX_STAMP();
-#endif
     for (int c = 0; c < n; ++c) {
-#ifdef MGX_TILE_STAMPS
-      const unsigned long long t0 = MGX_STAMP();
-#endif
       if (c + 2 * RING - 2 <= n) wait_vmcnt<Geo::kAhead>();  // chunk c and the ids of chunk c + RING - 1 have landed
       else wait_vmcnt<0>();                                   // (the queue is shorter at the end of the tile)
-#ifdef MGX_TILE_STAMPS
-      const unsigned long long t1 = MGX_STAMP();
-#endif
       __builtin_amdgcn_s_barrier();                           // ... and every consumer has finished chunk c - 1
       asm volatile("" ::: "memory");
-#ifdef MGX_TILE_STAMPS
-      const unsigned long long t2 = MGX_STAMP();
-#endif
       if (c + RING - 1 < n) issue_rows(c + RING - 1);
       if (c + 2 * RING - 2 < n) issue_ids(c + 2 * RING - 2);
-#ifdef MGX_TILE_STAMPS
-      const unsigned long long t3 = MGX_STAMP();
-      t_wait += t1 - t0; t_bar += t2 - t1; t_issue += t3 - t2;
-#endif
     }
-#ifdef MGX_TILE_STAMPS
-    if (a.stamps && lane == 0 && blockIdx.y == 0) {
-      unsigned long long* o = a.stamps + ((int64_t)tile * 16 + 0) * 8;
-      o[0] = t_wait; o[1] = t_bar; o[2] = t_issue; o[3] = MGX_STAMP() - t_begin; o[4] = n;
-    }
-#endif
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();  // the consumers' barrier before the direct part (see tile_loader)
     return;
@@ -530,10 +412,6 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
   v4f acc[NACC];
 #pragma unroll
   for (int j = 0; j < NACC; ++j) acc[j] = (v4f)(0.f);
-#ifdef MGX_TILE_STAMPS
-  unsigned long long t_bar = 0, t_lds = 0, t_dir = 0, n_ss = 0, td0 = 0, td1 = 0;
-  const unsigned long long t_begin = MGX_STAMP();
-#endif
 
   if (n > 0) {
     const auto* cnt = as_const(reinterpret_cast<const v4u*>(a.lds_cnt));
@@ -569,16 +447,8 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
       const v4u cr = NACC > 8 ? cnt[2 * k + 1] : (v4u)(0u);
       const uint32_t cnts[8] = {cq.x, cq.y, cq.z, cq.w, cr.x, cr.y, cr.z, cr.w};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifdef MGX_TILE_STAMPS
-      const unsigned long long tb0 = MGX_STAMP();
-#endif
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-#ifdef MGX_TILE_STAMPS
-      const unsigned long long tb1 = MGX_STAMP();
-      t_bar += tb1 - tb0;
-      const int ss_before = ss;
-#endif
       const uint32_t lrow = (uint32_t)(c % RING) * Geo::CHB + (uint32_t)l * 16u;
       auto gather4 = [&](uint32_t w, v4f (&v)[4]) {
 #pragma unroll
@@ -614,25 +484,14 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
           ss += 1;
         }
       }
-#ifdef MGX_TILE_STAMPS
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      t_lds += MGX_STAMP() - tb1;
-      n_ss += ss - ss_before;
-#endif
       k += NC;
     }
   }
 
   // ---- direct part: its stream windows (1 KiB = WSD supersteps, ring of 4) live where the chunks were
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#ifdef MGX_TILE_STAMPS
-  td0 = MGX_STAMP();
-#endif
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-#ifdef MGX_TILE_STAMPS
-  td1 = MGX_STAMP();
-#endif
   {
     const int64_t k = (int64_t)tile * NC + cw;
     const int so = as_const(a.dir_off)[k], se = as_const(a.dir_off)[k + 1];
@@ -699,15 +558,6 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
     }
   }
 
-#ifdef MGX_TILE_STAMPS
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-  t_dir = MGX_STAMP() - td1;
-  if (a.stamps && lane == 0 && blockIdx.y == 0) {
-    unsigned long long* o = a.stamps + ((int64_t)tile * 16 + (cw + 1)) * 8;
-    o[0] = t_bar; o[1] = t_lds; o[2] = t_dir; o[3] = MGX_STAMP() - t_begin; o[4] = n_ss; o[5] = td1 - td0; o[6] = t_begin;
-    o[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20) /* XCC_ID */;
-  }
-#endif
   if (!cvalid) return;
 #pragma unroll
   for (int j = 0; j < NACC; ++j) {
@@ -729,13 +579,10 @@ __global__ __launch_bounds__(512, 4) void spmm_tile_narrow_kernel(const TileArgs
   }
 }
 
-#define MGX_TILE_LAUNCH(W_, NL_, NACC_, RING_)                                                                      \
-  do {                                                                                                             \
-    if (MGX_ENV_FLAG("MGX_TILE_FLAGS") && (NACC_) == 6)                                                           \
-      hipLaunchKernelGGL((spmm_tile_kernel<W_, NL_, NACC_, RING_, true>), grid, dim3(W_ * kWave), 0, s, a);        \
-    else                                                                                                           \
-      hipLaunchKernelGGL((spmm_tile_kernel<W_, NL_, NACC_, RING_>), grid, dim3(W_ * kWave), 0, s, a);              \
-    return true;                                                                                                   \
+#define MGX_TILE_LAUNCH(W_, NL_, NACC_, RING_)                                                            \
+  do {                                                                                                   \
+    hipLaunchKernelGGL((spmm_tile_kernel<W_, NL_, NACC_, RING_>), grid, dim3(W_ * kWave), 0, s, a);      \
+    return true;                                                                                         \
   } while (0)
 
 // (waves, loaders, rows per lane group) the library is built for
@@ -798,9 +645,6 @@ extern "C" int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan*
   a.tiles_per_xcd = (int)((tp->num_tiles + kXcds - 1) / kXcds);
   a.D = (int)D; a.lds = (int)u_stride; a.ldo = (int)out_stride;
   a.mean = reduce == MGX_REDUCE_MEAN; a.accum = (flags & MGX_SPMM_ACCUMULATE) ? 1 : 0;
-#ifdef MGX_TILE_STAMPS
-  a.stamps = g_tile_stamps;
-#endif
   const dim3 grid((unsigned)(a.tiles_per_xcd * kXcds), (unsigned)((D + kPassCols - 1) / kPassCols));
   hipStream_t s = (hipStream_t)stream;
   const int lg = tp->lanes_log2 == 0 ? 4 : tp->lanes_log2;
@@ -809,11 +653,9 @@ extern "C" int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan*
     const dim3 ngrid(grid.x, (unsigned)((D + (4 << lg) - 1) / (4 << lg)));
     const dim3 nblock(512);
     bool ok = true;
-    static const int ring = getenv("MGX_TILE_RING") ? atoi(getenv("MGX_TILE_RING")) : 2;
 #define MGX_NARROW(LG_, NACC_) \
   if (lg == LG_ && tp->nacc == NACC_) { \
-    if (LG_ == 2 && ring == 3) hipLaunchKernelGGL((spmm_tile_narrow_kernel<LG_, NACC_, LG_ == 2 ? 3 : 2>), ngrid, nblock, 0, s, a); \
-    else hipLaunchKernelGGL((spmm_tile_narrow_kernel<LG_, NACC_, 2>), ngrid, nblock, 0, s, a); \
+    hipLaunchKernelGGL((spmm_tile_narrow_kernel<LG_, NACC_, 2>), ngrid, nblock, 0, s, a); \
   } else
     MGX_NARROW(3, 3) MGX_NARROW(3, 4) MGX_NARROW(3, 5) MGX_NARROW(3, 6) MGX_NARROW(3, 8)
     MGX_NARROW(2, 2) MGX_NARROW(2, 3) MGX_NARROW(2, 4) MGX_NARROW(2, 6) MGX_NARROW(2, 8)
@@ -830,6 +672,3 @@ extern "C" int32_t mgx_spmm_tile_copy_u(const mgx_csr* csr, const mgx_spmm_plan*
   return MGX_OK;
 }
 
-#ifdef MGX_TILE_STAMPS
-extern "C" void mgx_debug_set_tile_stamps(void* p) { mgx::g_tile_stamps = (unsigned long long*)p; }
-#endif

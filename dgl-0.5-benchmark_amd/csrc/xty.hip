@@ -168,7 +168,6 @@ static bool launch_xty_v4_b(int bvg, int bst, int waves, int64_t n, int M, int K
 // 16-byte loads for the operand(s) that allow it; false = use the dword kernels above
 static bool launch_xty_v4(int mt, int kt, int waves, int64_t n, int M, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                           float* part, float* part_sum, hipStream_t s) {
-  if (MGX_ENV_FLAG("MGX_XTY_V1")) return false;  // A/B switch
   const bool bvec = ldb % 4 == 0 && (uintptr_t)B % 16 == 0 && K % 4 == 0 && K >= 64;
   if (!bvec) return false;
   const int bvg = K >= 128 ? 2 : 1, bst = (K - bvg * 64 + 15) / 16;

@@ -33,7 +33,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import dgl  # noqa: E402
 import dgl.function as fn  # noqa: E402
 from dgl.nn.pytorch import GATConv, Linear, BatchNorm1d  # noqa: E402
-from mi355x_graph import ops  # noqa: E402
+from mi355x_graph import config, ops  # noqa: E402
 from dgl.utils import expand_as_pair  # noqa: E402
 
 
@@ -74,7 +74,7 @@ class SAGEConv(nn.Module):
         feat_src, feat_dst = feat if isinstance(feat, tuple) else (feat, feat)
         graph.srcdata["h"] = feat_src
         graph.update_all(fn.copy_src("h", "m"), fn.mean("m", "neigh"))
-        if not self.plain and self.fc_self.bias is None and os.environ.get("MGX_SAGE_FUSED_ADD", "1") == "1":
+        if not self.plain and self.fc_self.bias is None and config.SAGE_FUSED_ADD:
             # fc_self(h) + fc_neigh(neigh): the second GEMM accumulates into the first's output (no separate add pass)
             return ops.linear_sum(feat_dst, self.fc_self.weight, graph.dstdata["neigh"], self.fc_neigh.weight, self.fc_neigh.bias)
         return self.fc_self(feat_dst) + self.fc_neigh(graph.dstdata["neigh"])

@@ -323,13 +323,8 @@ class GraphedBatchTrainer(object):
 def train_epoch_graphed(trainer, loader):
     trainer.model.train()
     loss = None
-    for i, (batched_graph, labels) in enumerate(loader):
+    for batched_graph, labels in loader:
         loss = trainer.step(batched_graph, labels)
-        if os.environ.get("MGX_DEBUG_NAN") == "1" and not (trainer.done.synchronize() or bool(torch.isfinite(loss))):
-            bad = [n for n, p_ in trainer.model.named_parameters() if not bool(torch.isfinite(p_).all())]
-            raise SystemExit("non-finite loss at step %d: n %d e %d b %d ghosts %d, non-finite parameters %s" % (
-                i, batched_graph.number_of_nodes(), batched_graph.number_of_edges(), labels.shape[0],
-                trainer.n_pad - batched_graph.number_of_nodes(), bad[:4]))
     return trainer.loss_value()
 
 

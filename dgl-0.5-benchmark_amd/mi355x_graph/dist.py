@@ -24,6 +24,7 @@ import torch.nn as nn
 
 from ._lib import DGLError
 from . import core, emulate, ops, schedule, sparse
+from . import config
 from . import function as fn
 from .graph import DGLGraph, Frame, GraphIndex
 
@@ -598,7 +599,7 @@ class DistSageMeanCatFn(torch.autograd.Function):
                 static_cache["version"], static_cache["recv"] = h._version, recv
         if not cat.holds(h):  # the layer-1 input lives elsewhere: copied into the left half unless it is the same unmodified tensor
             same = cat.static_key is not None and cat.static_key[0] is h and cat.static_key[1] == h._version
-            if not same or h.requires_grad or os.environ.get("MGX_SAGE_STATIC_CAT", "1") != "1":
+            if not same or h.requires_grad or not config.SAGE_STATIC_CAT:
                 cat.left.copy_(h)
                 cat.static_key = None if h.requires_grad else (h, h._version)
         cat.generation += 1
@@ -793,7 +794,7 @@ class DistGraph(DGLGraph):
         this tensor object exchanges its halo rows once and keeps them resident; every rank must make the same call.
         `None` withdraws the declaration."""
         self._static_halo.clear()
-        if x is not None and os.environ.get("MGX_STATIC_HALO", "1") == "1":
+        if x is not None:
             self._static_halo.update(tensor=x, version=None, recv=None)
 
     def number_of_nodes(self, ntype=None):
@@ -873,7 +874,7 @@ class DistGraph(DGLGraph):
         plan = self._plan
         if (plan.loc is None or h.dim() != 2 or h.dtype != torch.float32 or h.shape[0] != plan.n_own or h.shape[1] != D
                 or K % 4 or K > 128  # the one-GPU form's widths (ops.sage_project_first): N = 1 and N > 1 run the same module graph
-                or not torch.is_grad_enabled() or os.environ.get("MGX_SAGE_PROJECT_FIRST", "1") != "1"
+                or not torch.is_grad_enabled() or not config.SAGE_PROJECT_FIRST
                 or (bias is not None and K > getattr(sparse.backend_for(h), "COLUMN_SUM_MAX", 256))):
             return None
         aggs_now = 2 if h.requires_grad else 1
@@ -887,7 +888,7 @@ class DistGraph(DGLGraph):
         if (cat is None or plan.loc is None or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda or cat.K != h.shape[1]
                 or h.shape[0] != plan.n_own or cat.buf.shape[0] != plan.n_own or h.shape[1] % 4
                 or plan.loc.csc().indptr.dtype != torch.int32 or not torch.is_grad_enabled()
-                or os.environ.get("MGX_SAGE_CAT", "1") != "1" or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):
+                or not config.SAGE_CAT or not config.SAGE_FUSED_LAYER):
             return None
         if plan.return_csr().num_cols * h.shape[1] * 4 >= (1 << 32) or (plan.n_own + plan.n_halo) * 2 * h.shape[1] * 4 >= (1 << 32):
             return None

@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from ._lib import DGLError
 from . import function as fn
+from . import config
 from . import ops
 from .utils import expand_as_pair
 
@@ -111,7 +112,7 @@ class GATConv(nn.Module):
         """One-head layers that WIDEN (in < out, e.g. 16 hidden -> 41 classes): aggregate the input rows, project afterwards.
         Taken when the fused block exists for the input width and it saves a 16-column gather pass; MGX_GAT_AGG_FIRST=0 never."""
         if (self._num_heads != 1 or isinstance(feat, tuple) or get_attention or not hasattr(self, "fc") or not torch.is_tensor(feat)
-                or feat.dim() != 2 or os.environ.get("MGX_GAT_AGG_FIRST", "1") == "0"):
+                or feat.dim() != 2 or not config.GAT_AGG_FIRST):
             return False
         k, f = self._in_src_feats, self._out_feats
         if k % 4 != 0 or (k + 15) // 16 >= (f + 15) // 16:

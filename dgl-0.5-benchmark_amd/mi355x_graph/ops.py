@@ -16,6 +16,7 @@ from torch.autograd.function import once_differentiable
 
 from ._lib import DGLError
 from . import sparse
+from . import config
 from .graph import DGLGraph, GraphIndex
 
 __all__ = ["gspmm", "gsddmm", "edge_softmax", "gat_attention", "gat_fused", "segment_reduce", "copy_u_sum", "copy_u_mean", "u_mul_e_sum",
@@ -131,7 +132,7 @@ class GSpMM(torch.autograd.Function):
                 rev = gidx.csr()  # rows = src: the reversed graph's in-CSR
                 if op == "mul":
                     dX, _, _ = _raw_gspmm(rev, "mul", "sum", dZs, Y)
-                elif os.environ.get("MGX_SPARSE_GRAD", "0") == "1" and _torch_ops() is None:
+                elif config.SPARSE_GRAD and _torch_ops() is None:
                     dX = sparse.gspmm_grad_raw(rev, dZs)  # measured variant: flags the gradient's all-zero rows and skips them
                 else:  # add, copy_lhs: aggregation of the gradient over the reversed graph
                     dX = _raw_gspmm(rev, "copy_lhs", "sum", dZs, None)[0]
@@ -611,7 +612,7 @@ def batch_norm_supported(x):
 def _weight_grad(dy2, x2):
     be = sparse.backend_for(dy2)
     if (x2.shape[0] >= be.XTY_MIN_ROWS and dy2.shape[1] <= be.XTY_MAX[0] and x2.shape[1] <= be.XTY_MAX[1]
-            and os.environ.get("MGX_LINEAR_XTY", "1") == "1"):
+            and config.LINEAR_XTY):
         # millions of rows, <= 64 x 128 outputs: streamed once; mgx_xty takes row strides, so a column slice (the [:, :D] view of
         # a line-padded aggregation) is read in place
         return be.xty(dy2 if dy2.stride(1) == 1 else dy2.contiguous(), x2 if x2.stride(1) == 1 else x2.contiguous())
@@ -622,7 +623,7 @@ def _weight_bias_grad(dy2, x2):
     """(dy^T x, column sums of dy): the weight and the bias gradient of a dense layer from ONE pass over dy where mgx_xty_colsum applies."""
     be = sparse.backend_for(dy2)
     if (x2.shape[0] >= be.XTY_MIN_ROWS and dy2.shape[1] <= be.XTY_MAX[0] and x2.shape[1] <= be.XTY_MAX[1]
-            and os.environ.get("MGX_LINEAR_XTY", "1") == "1" and os.environ.get("MGX_XTY_COLSUM", "1") == "1"):
+            and config.LINEAR_XTY and config.XTY_COLSUM):
         return be.xty(dy2 if dy2.stride(1) == 1 else dy2.contiguous(), x2 if x2.stride(1) == 1 else x2.contiguous(), colsum=True)
     return _weight_grad(dy2, x2), be.column_sum(dy2 if dy2.is_contiguous() else dy2.contiguous())
 
@@ -749,12 +750,8 @@ class CatBuffer(object):
                 and h.stride(0) == self.buf.stride(0) and h.stride(1) == 1)
 
 
-_BWD_OWN_MATRIX = os.environ.get("MGX_SAGE_BWD_OWN_MATRIX", "0") == "1"
-
-
 # mgx_rows_gemm (csrc/rowsgemm.hip) for the projections of a layer over a CatBuffer: tall inputs only (the library GEMM wins below,
-# and the staging of B is per workgroup).  MGX_ROWS_GEMM=0: the library GEMM (+ the separate 1 / deg pass) everywhere (A/B runs).
-_ROWS_GEMM = os.environ.get("MGX_ROWS_GEMM", "1") == "1"
+# and the staging of B is per workgroup).  config.ROWS_GEMM = False: the library GEMM (+ the separate 1 / deg pass) everywhere.
 _ROWS_GEMM_MIN = 1 << 16
 
 
@@ -762,7 +759,7 @@ def _rows_dgrad(be, dy, wcat, inv_deg, K):
     """(d h, d neigh / deg) = the two halves of dy @ wcat, the second times 1 / deg: mgx_rows_gemm with the factor in its epilogue and
     each half a compact matrix of its own (the reversed aggregation then gathers from one and accumulates into the other), else the
     GEMM and a streaming pass over that half, the halves two column blocks of one matrix."""
-    if _ROWS_GEMM and dy.is_cuda and dy.shape[0] >= _ROWS_GEMM_MIN and K % 4 == 0:
+    if config.ROWS_GEMM and dy.is_cuda and dy.shape[0] >= _ROWS_GEMM_MIN and K % 4 == 0:
         pair = be.rows_gemm(dy, wcat, row_scale=inv_deg, scale_from=K, split_col=K)
         if pair is not None:
             return pair
@@ -774,7 +771,7 @@ def _rows_dgrad(be, dy, wcat, inv_deg, K):
 def _rows_linear(be, x2d, weight, bias):
     """F.linear(x2d, weight, bias) for a tall x2d through mgx_rows_gemm when it has the shape (weight: [out, in] as in nn.Linear).
     Outputs that are not a multiple of four columns wide (the 47 classes) keep the library GEMM: scalar stores, 0.49 against 0.47 ms."""
-    if _ROWS_GEMM and x2d.is_cuda and x2d.shape[0] >= _ROWS_GEMM_MIN and weight.shape[0] % 4 == 0:
+    if config.ROWS_GEMM and x2d.is_cuda and x2d.shape[0] >= _ROWS_GEMM_MIN and weight.shape[0] % 4 == 0:
         y = be.rows_gemm(x2d, weight, b_transposed=True, bias=bias)
         if y is not None:
             return y
@@ -795,7 +792,7 @@ class SageMeanCatFn(torch.autograd.Function):
             # SAME tensor object, unmodified (version counter), as in the previous pass the copy is skipped.  The buffer keeps
             # a reference to that tensor: a per-step temporary at a recycled address is a different object and is copied.
             same = cat.static_key is not None and cat.static_key[0] is h and cat.static_key[1] == h._version
-            if not same or h.requires_grad or os.environ.get("MGX_SAGE_STATIC_CAT", "1") != "1":
+            if not same or h.requires_grad or not config.SAGE_STATIC_CAT:
                 cat.left.copy_(h)
                 cat.static_key = None if h.requires_grad else (h, h._version)
         cat.generation += 1
@@ -842,15 +839,7 @@ class SageMeanCatFn(torch.autograd.Function):
         be = sparse.backend_for(dy)
         K = cat.K
         dh = None
-        if need[2] and _BWD_OWN_MATRIX:
-            # the reversed aggregation gathers from a matrix of its OWN and accumulates into another: gathering the right half of
-            # the matrix whose left half it read-modify-writes costs 2.60 against 2.38 ms per launch on the products shape (the
-            # output rows share 512-byte blocks with the rows being gathered), for a second pass of the dgrad GEMM over dy
-            dh = dy @ w_self
-            dn = dy @ w_neigh
-            dn.mul_(ctx.gidx.csc().inv_degrees().view(-1, 1))
-            be.spmm_copy_u_strided(ctx.gidx.csr(), "sum", dn, dh, accumulate=True)
-        elif need[2]:
+        if need[2]:
             # [N, 2K] = d[h | neigh], the `neigh` half times 1 / deg (d(sum / deg)): one mgx_rows_gemm with the factor in its epilogue,
             # else the GEMM and a streaming pass over that half -- never a per-edge factor
             dh, dn = _rows_dgrad(be, dy, torch.cat([w_self, w_neigh], dim=1), ctx.gidx.csc().inv_degrees(), K)
@@ -1057,7 +1046,7 @@ def sage_project_first(g, h, w_self, w_neigh, bias=None):
     if (type(g) is not DGLGraph or g.is_block or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda
             or h.device.type not in sparse._BACKENDS or not torch.is_grad_enabled() or g.idtype != torch.int32
             or g.number_of_src_nodes() != g.number_of_dst_nodes() or h.shape[0] != g.number_of_src_nodes()
-            or K % 4 or K > 128 or _torch_ops() is not None or os.environ.get("MGX_SAGE_PROJECT_FIRST", "1") != "1"
+            or K % 4 or K > 128 or _torch_ops() is not None or not config.SAGE_PROJECT_FIRST
             or (bias is not None and K > sparse.backend_for(h).COLUMN_SUM_MAX)
             or g.number_of_src_nodes() * 2 * K * 4 >= (1 << 32)):
         return None
@@ -1077,7 +1066,7 @@ def sage_mean_layer(g, h, w_self, w_neigh, bias=None, cat=None):
             or g.number_of_src_nodes() != g.number_of_dst_nodes() or h.shape[0] != g.number_of_src_nodes()
             or g.idtype != torch.int32  # the accumulating aggregation is exercised on the int32 kernels only
             or (bias is not None and w_self.shape[0] > sparse.backend_for(h).COLUMN_SUM_MAX)
-            or _torch_ops() is not None or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):
+            or _torch_ops() is not None or not config.SAGE_FUSED_LAYER):
         return None
     if cat is not None and _cat_eligible(g, h, cat):
         return SageMeanCatFn.apply(g._index, cat, h, w_self, w_neigh, bias)
@@ -1088,18 +1077,18 @@ def sage_mean_layer_act(g, h, w_self, w_neigh, bias, cat, p, out):
     """dropout(relu(SAGEConv(g, h)), p) as ONE node whose GEMM applies the activation in its epilogue and writes `out` (the left half of
     the next layer's CatBuffer, or None for a new matrix): bit for bit ops.relu_dropout(ops.sage_mean_layer(...), out=out), one pass
     over the N x out pre-activation less each way.  None when that form does not apply (the caller composes the two)."""
-    if (os.environ.get("MGX_SAGE_FUSED_ACT", "1") != "1" or not _ROWS_GEMM or type(g) is not DGLGraph or cat is None or capture_path()
+    if (not config.SAGE_FUSED_ACT or not config.ROWS_GEMM or type(g) is not DGLGraph or cat is None or capture_path()
             or not (0.0 < p < 1.0) or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda or h.device.type not in sparse._BACKENDS
             or not torch.is_grad_enabled() or g.is_block or g.number_of_src_nodes() != g.number_of_dst_nodes()
             or h.shape[0] != g.number_of_src_nodes() or h.shape[0] < _ROWS_GEMM_MIN or g.idtype != torch.int32
-            or _torch_ops() is not None or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1" or not _cat_eligible(g, h, cat)
+            or _torch_ops() is not None or not config.SAGE_FUSED_LAYER or not _cat_eligible(g, h, cat)
             or (bias is not None and w_self.shape[0] > sparse.backend_for(h).COLUMN_SUM_MAX) or w_self.shape[0] % 4
             or not sparse.backend_for(h).rows_gemm_supported(2 * cat.K, w_self.shape[0], cat.buf.stride(0))
             or (out is not None and (out.shape != (h.shape[0], w_self.shape[0]) or out.stride(1) != 1 or out.stride(0) % 4
                                      or out.data_ptr() % 16 or out.requires_grad))):
         return None
     K, D = w_self.shape
-    if os.environ.get("MGX_SAGE_PROJECT_FIRST", "1") == "1" and K % 4 == 0 and K <= 128 and 2 * max(K, 16) * 1.1 <= (2 if h.requires_grad else 1) * D:
+    if config.SAGE_PROJECT_FIRST and K % 4 == 0 and K <= 128 and 2 * max(K, 16) * 1.1 <= (2 if h.requires_grad else 1) * D:
         return None  # sage_project_first's rule: this layer aggregates fewer columns projected first (reddit: 602 -> 16)
     if os.environ.get("MGX_SAGE_L1_PROJECT_FIRST", "0") == "1" and not h.requires_grad and K < D:
         return None  # the opt-in layer-1 form (sage_static_input_project) takes this layer
@@ -1109,7 +1098,7 @@ def sage_mean_layer_act(g, h, w_self, w_neigh, bias, cat, p, out):
 def _cat_eligible(g, h, cat):
     K = h.shape[1]
     idx = g._index
-    return (os.environ.get("MGX_SAGE_CAT", "1") == "1" and cat.K == K and K % 4 == 0 and cat.buf.shape[0] == h.shape[0]
+    return (config.SAGE_CAT and cat.K == K and K % 4 == 0 and cat.buf.shape[0] == h.shape[0]
             and idx.csc().indptr.dtype == torch.int32 and h.shape[0] * 2 * K * 4 < (1 << 32))
 
 
@@ -1118,7 +1107,7 @@ def cat_buffer_for(g, x, K):
     if ((type(g) is not DGLGraph and not hasattr(g, "sage_mean_layer")) or g.is_block or x.dtype != torch.float32 or not x.is_cuda or x.device.type not in sparse._BACKENDS
             or not torch.is_grad_enabled() or K % 4 or g.number_of_src_nodes() != g.number_of_dst_nodes()
             or g.number_of_src_nodes() * 2 * K * 4 >= (1 << 32) or g.idtype != torch.int32
-            or os.environ.get("MGX_SAGE_CAT", "1") != "1" or os.environ.get("MGX_SAGE_FUSED_LAYER", "1") != "1"):
+            or not config.SAGE_CAT or not config.SAGE_FUSED_LAYER):
         return None
     return CatBuffer(g.number_of_src_nodes(), K, x.device)
 

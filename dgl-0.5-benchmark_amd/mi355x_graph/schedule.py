@@ -11,7 +11,7 @@ processed changes, so results and the DGL-visible numbering are unaffected.
   * split: rows with more than `split` edges become several work items whose partial sums are
     combined in a fixed order (deterministic), so a 17k-edge hub never serialises on one wavefront;
   * order: semi-synchronous label propagation (a few rounds of sort + run-length on the device)
-    groups rows into clusters (8 rounds; MGX_LP_ROUNDS); the schedule is the rows sorted by (final label, earlier labels).
+    groups rows into clusters (8 rounds: config.LP_ROUNDS); the schedule is the rows sorted by (final label, earlier labels).
 """
 import ctypes
 import os
@@ -19,6 +19,7 @@ import os
 import torch
 
 from ._lib import DGLError
+from . import config
 
 
 class MgxSpmmPlan(ctypes.Structure):
@@ -57,7 +58,7 @@ class SpmmPlan(object):
         """Cut the schedule into 8 contiguous stretches of equal EDGE count (one per XCD), boundaries on multiples of the
         workgroup's item count.  One device cumsum + 7 searches + one host read, once per plan."""
         n = int(self.item_row.shape[0])
-        if n < xcds * granule * 4 or os.environ.get("MGX_XCD_BALANCE", "1") != "1":
+        if n < xcds * granule * 4:
             return [0] * (xcds + 1)
         ln = (self.item_end - self.item_beg).to(torch.int64) + 1  # +1: an empty item still costs its fixed overhead
         csum = torch.cumsum(ln, 0)
@@ -183,12 +184,12 @@ def label_propagation(indptr, indices, n, rounds=5, seed=0, node_w=None, max_wei
     return history
 
 
-def locality_order(csr, rounds=int(os.environ.get("MGX_LP_ROUNDS", "8"))):
+def locality_order(csr, rounds=None):
     """Row permutation placing rows of one (nested) cluster next to each other."""
     n = csr.num_rows
     if n > csr.num_cols:
         raise DGLError("locality_order needs the destination nodes to be a prefix of the source nodes")
-    hist = label_propagation(csr.indptr, csr.indices, n, rounds)
+    hist = label_propagation(csr.indptr, csr.indices, n, config.LP_ROUNDS if rounds is None else rounds)
     order = torch.arange(n, device=csr.device)
     # stable sorts from the finest (earliest) to the coarsest (final) labels = lexicographic order
     for labels in hist[max(0, len(hist) - 3):]:
@@ -223,7 +224,7 @@ def _build_plan_device(csr, order, split, order_kind):
 
 
 def build_plan(csr, order=None, split=1024, order_kind="natural"):
-    if csr.indptr.is_cuda and os.environ.get("MGX_PLAN_BUILDER", "device") == "device":
+    if csr.indptr.is_cuda and config.PLAN_BUILDER == "device":
         return _build_plan_device(csr, order, split, order_kind)
     dev = csr.device
     n = csr.num_rows
@@ -267,7 +268,7 @@ def build_plan(csr, order=None, split=1024, order_kind="natural"):
 
 
 # nnz below which the whole gathered matrix is cache resident anyway and clustering cannot pay
-_CLUSTER_MIN_NNZ = int(os.environ.get("MGX_CLUSTER_MIN_NNZ", 4_000_000))
+
 
 
 _SMALL_NNZ = 200_000
@@ -276,7 +277,7 @@ _SMALL_NNZ = 200_000
 def _no_hubs_cheaply(csr):
     """Small graphs (sampled blocks, batched molecules): one fused max over the degrees, one host sync."""
     deg = csr.indptr[1:] - csr.indptr[:-1]
-    return int(deg.max().item()) <= int(os.environ.get("MGX_SPLIT", 256))
+    return int(deg.max().item()) <= config.HUB_SPLIT
 
 
 def plan_for(csr, split=None):
@@ -289,8 +290,8 @@ def plan_for(csr, split=None):
     if mode == "auto" and csr.nnz < _SMALL_NNZ and csr.nnz // max(csr.num_rows, 1) < 64 and _no_hubs_cheaply(csr):
         return None
     if split is None:
-        split = int(os.environ.get("MGX_SPLIT", 256))  # 256 measured best on MI355X (1024: +5..10 %)
-    want_cluster = mode == "cluster" or (mode == "auto" and csr.nnz >= _CLUSTER_MIN_NNZ)
+        split = config.HUB_SPLIT
+    want_cluster = mode == "cluster" or (mode == "auto" and csr.nnz >= config.CLUSTER_MIN_NNZ)
     order, kind = csr._row_order
     if kind is None:
         order, kind = None, "natural"

@@ -16,13 +16,12 @@ import torch
 
 from . import _lib
 from ._lib import DGLError, MgxCsr, OP, REDUCE, TARGET
+from . import config
 
 
 # Every tile plan is bounds-checked once when it is built (the kernels follow its tables blindly: a wrong entry would be an
 # out-of-bounds access on the device).  A dozen reductions with host syncs per plan; MGX_TILE_VALIDATE=0 skips them.
-_VALIDATE_TILE_PLANS = os.environ.get("MGX_TILE_VALIDATE", "1") != "0"
 PROFILE = None  # set to a list by bench.py to collect per-launch HIP-event timings of mgx_spmm_csr
-TILE_MIN_WIDTH = int(os.environ.get("MGX_TILE_MIN_WIDTH", 4))  # rows of 4 .. 20 columns take the 16-column tile pass, 24 .. 44 the 32-column one, wider the 64-column one
 
 
 class timed_call(object):
@@ -175,7 +174,7 @@ class CsrView(object):
                 pad = (-n_short) % nb
                 padded = torch.cat([lens, lens.new_zeros(pad)]) if pad else lens
                 worst = float(padded.view(-1, nb).max(dim=1)[0].sum()) * nb  # one host read
-                if edges / n_short < (16.0 if nb >= 8 else 3.0 * nb) and worst <= float(os.environ.get("MGX_ROWGROUP_IMBALANCE", "6.0")) * edges:
+                if edges / n_short < (16.0 if nb >= 8 else 3.0 * nb) and worst <= config.SHORT_ROWS_IMBALANCE * edges:
                     choice = True if (plan is None or plan.rest is None) else plan
             self._short[nb] = choice
         return self._short[nb]
@@ -210,7 +209,7 @@ class CsrView(object):
             nc, nacc, nl, tau = tileplan.gat_config()
             base = self._tile_base_plan()
             held = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=2, pair_rank=True)
-            if _VALIDATE_TILE_PLANS:
+            if config.TILE_VALIDATE:
                 tileplan.validate(held, self)
             self._tile_plan["gat"] = held
         return self._tile_plan["gat"]
@@ -229,36 +228,15 @@ class CsrView(object):
             self.plan()  # computes (and caches) the locality row order first
             nc, nacc, nl, tau = tileplan.config(lg)
             base = self._tile_base_plan()
-            # MGX_TILE_DIRECT=split (A/B, measured slower: reddit D = 64 1.13 -> 1.42 ms, docs/LOG_r04.md §8): the tile's once-used
-            # sources as a second, accumulating launch of the row kernel instead of the tile kernel's own direct part
-            split = lg == 4 and os.environ.get("MGX_TILE_DIRECT", "kernel") == "split"
-            tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=lg, split_direct=split,
-                                          tail=float(os.environ.get("MGX_TILE_TAIL", "0")))  # A/B: tiles that shrink toward a stretch's end
-            if _VALIDATE_TILE_PLANS:
+            tp = tileplan.build_tile_plan(self, base, nc, nacc, nl, tau, lanes_log2=lg)
+            if config.TILE_VALIDATE:
                 tileplan.validate(tp, self)
-            tp.direct_csr = None
-            if tp.direct_coo is not None and tp.direct_coo[0].numel():
-                # the tile's once-used sources as a CSR of their own (same rows, same row order) for the row-per-wave kernel
-                dv = coo_to_csr(self.num_rows, self.num_cols, tp.direct_coo[0], tp.direct_coo[1])
-                dv._tile_plan = None
-                dv._row_order = self._row_order
-                dv.dst_is_src_prefix = getattr(self, "dst_is_src_prefix", False)
-                tp.direct_csr = dv
-            tp.direct_coo = None
             self._tile_plan[lg] = tp
         return self._tile_plan[lg]
 
     def softmax_plan(self):
-        """Schedule of the edge-softmax / fused attention kernels: the g-SpMM plan unless MGX_SOFTMAX_SPLIT asks for a
-        different hub threshold (rows up to that length then stay on the single-wave path)."""
-        want = os.environ.get("MGX_SOFTMAX_SPLIT")
-        if not want or not self.indptr.is_cuda:
-            return self.plan()
-        if self._sm_plan is False:
-            from . import schedule
-            self.plan()  # computes (and caches) the row order first
-            self._sm_plan = schedule.plan_for(self, split=int(want))
-        return self._sm_plan
+        """Schedule of the edge-softmax / fused attention kernels: the g-SpMM plan."""
+        return self.plan()
 
     def to(self, device):
         out = CsrView(self.num_rows, self.num_cols, self.indptr.to(device), self.indices.to(device),
@@ -421,14 +399,14 @@ class HipBackend(object):
             if op != "copy_lhs":
                 arg_e = torch.empty((csr.num_rows, out_len), dtype=csr.indptr.dtype, device=dev)
         if (op == "copy_lhs" and reduce in ("sum", "mean") and src_scale is None and u_off is None and e_off is None
-                and u_len == out_len and out_len >= TILE_MIN_WIDTH and out_len % 4 == 0 and csr.idx_bits == 32
+                and u_len == out_len and out_len >= config.TILE_MIN_WIDTH and out_len % 4 == 0 and csr.idx_bits == 32
                 and csr.num_cols * out_len * 4 < 2 ** 32 and U.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0 and not want_arg):
             tp = csr.tile_plan(out_len)
             if tp is not None:  # dense neighbourhoods: the LDS-staged tile kernel
                 self.spmm_tile_copy_u(csr, tp, reduce, U.view(csr.num_cols, out_len), out, accumulate_into is not None, dst_scale)
                 return out, None, None
         if (op == "copy_lhs" and reduce in ("sum", "mean") and src_scale is None and u_off is None and e_off is None
-                and u_len == out_len and out_len % 4 != 0 and TILE_MIN_WIDTH <= 4 and csr.idx_bits == 32 and not want_arg
+                and u_len == out_len and out_len % 4 != 0 and config.TILE_MIN_WIDTH <= 4 and csr.idx_bits == 32 and not want_arg
                 and csr.num_cols * (out_len + 3) * 4 < 2 ** 32):
             padded = (out_len + 3) // 4 * 4
             tp = csr.tile_plan(padded)
@@ -513,7 +491,7 @@ class HipBackend(object):
         if (U2d.dim() != 2 or out2d.dim() != 2 or U2d.stride(1) != 1 or out2d.stride(1) != 1 or out2d.shape[1] != D
                 or U2d.shape[0] != csr.num_cols or out2d.shape[0] != csr.num_rows):
             raise DGLError("spmm_copy_u_strided: expected row-strided [num_cols, D] -> [num_rows, D] views")
-        if (D >= TILE_MIN_WIDTH and D % 4 == 0 and csr.idx_bits == 32 and csr.num_cols * int(U2d.stride(0)) * 4 < 2 ** 32
+        if (D >= config.TILE_MIN_WIDTH and D % 4 == 0 and csr.idx_bits == 32 and csr.num_cols * int(U2d.stride(0)) * 4 < 2 ** 32
                 and U2d.stride(0) % 4 == 0 and out2d.stride(0) % 4 == 0 and U2d.data_ptr() % 16 == 0 and out2d.data_ptr() % 16 == 0):
             tp = csr.tile_plan(D)
             if tp is not None:
@@ -563,13 +541,6 @@ class HipBackend(object):
             if rec is not None:
                 rec["end"].record(torch.cuda.current_stream(dev))
                 PROFILE.append(rec)
-        dv = getattr(tile_plan, "direct_csr", None)
-        if dv is not None:  # the edges the tile plan left out (sources used once in their tile): row kernel, accumulating
-            scale = dst_scale
-            if reduce == "mean":
-                inv = csr.inv_degrees()
-                scale = inv if dst_scale is None else inv * dst_scale
-            self.spmm_copy_u_strided(dv, "sum", U2d, out2d, accumulate=True, dst_scale=scale)
         return out2d
 
     def sddmm(self, graph_index, op, L, R, lhs_target, rhs_target, l_len, r_len, out_len, reduce_size, l_off, r_off):
@@ -733,6 +704,8 @@ class HipBackend(object):
 
     @staticmethod
     def _gat_pack_ws(csc, H, F, dev):
+        if not config.GAT_PACK:
+            return None
         need = _lib.lib().mgx_gat_fused_pack_workspace(csc.num_cols, csc.num_rows, H, F)
         return torch.empty(need // 4, dtype=torch.float32, device=dev) if need else None
 
@@ -1157,9 +1130,7 @@ def _as_f32(t, what):
     return t.contiguous()
 
 
-_WIDE_PAD = os.environ.get("MGX_WIDE_PAD", "1") != "0"
 _WIDE_PAD_MIN = 176  # above this width the g-SpMM runs in column passes of 128 columns (csrc/spmm.hip launch_fast_v)
-_WIDE_PAD_MIN_NNZ = int(os.environ.get("MGX_WIDE_PAD_MIN_NNZ", 1 << 20))  # tests lower it to reach the path on small graphs
 
 
 def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=False, accumulate_into=None, dense_out=False):
@@ -1181,7 +1152,7 @@ def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=Fa
     if E is not None and E.shape[0] != csr.nnz:
         raise DGLError("gspmm: expected %d edge rows, got %d" % (csr.nnz, E.shape[0]))
     if (op == "copy_lhs" and reduce in ("sum", "mean") and U.dim() == 2 and U.is_cuda and accumulate_into is None
-            and U.shape[1] > _WIDE_PAD_MIN and U.shape[1] % 32 and csr.nnz >= max(_WIDE_PAD_MIN_NNZ, 64 * csr.num_cols) and _WIDE_PAD):
+            and U.shape[1] > _WIDE_PAD_MIN and U.shape[1] % 32 and csr.nnz >= max(config.WIDE_PAD_MIN_NNZ, 64 * csr.num_cols) and config.WIDE_PAD):
         # Wide rows that are not whole 128-byte lines (reddit's 602 input features: 2408-byte rows) on a dense graph: every
         # 512-byte column pass of a gathered row straddles one more line and 16-byte lanes are misaligned.  Aggregating a copy
         # padded to whole lines and returning the [:, :D] view is faster by more than the copy costs once a row is gathered
@@ -1211,7 +1182,6 @@ def gspmm_raw(csr, op, reduce, U, E, src_scale=None, dst_scale=None, want_arg=Fa
 
 
 # nnz below which a separate pass over the gradient to flag its zero rows cannot pay
-_SPARSE_GRAD_MIN_NNZ = int(os.environ.get("MGX_SPARSE_GRAD_MIN_NNZ", 2_000_000))
 
 
 def gspmm_grad_raw(csr, dZ, dst_scale=None, accumulate_into=None, dense_out=False):
@@ -1224,7 +1194,7 @@ def gspmm_grad_raw(csr, dZ, dst_scale=None, accumulate_into=None, dense_out=Fals
     gathers: no net gain (23.4 vs 23.5 ms).  Exact either way; kept with its test as a measured variant."""
     be = backend_for(dZ)
     flat = dZ.contiguous().view(dZ.shape[0], -1)
-    if (os.environ.get("MGX_SPARSE_GRAD", "0") == "1" and be.name == "hip" and csr.nnz >= _SPARSE_GRAD_MIN_NNZ and csr.idx_bits == 32
+    if (config.SPARSE_GRAD and be.name == "hip" and csr.nnz >= config.SPARSE_GRAD_MIN_NNZ and csr.idx_bits == 32
             and flat.shape[1] % 4 == 0 and flat.shape[1] >= 4 and dZ.dtype == torch.float32 and dZ.shape[0] == csr.num_cols
             and csr.num_cols * flat.shape[1] * 4 < 2 ** 32 and flat.data_ptr() % 16 == 0):
         bits = be.row_nonzero_bits(flat)

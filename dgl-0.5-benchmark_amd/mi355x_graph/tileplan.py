@@ -25,6 +25,8 @@ import os
 
 import torch
 
+from . import config as _settings
+
 GROUPS = 4          # 16-lane groups of a wave (one 64-column pass: 16 lanes x float4)
 CHUNK_SLOTS = 128   # LDS rows per chunk: 127 staged sources + the all-zero slot
 ZERO_SLOT = CHUNK_SLOTS - 1
@@ -125,7 +127,7 @@ def _streams(seg_key, nseg, payload, pad, dtype, seg_order=None, groups=GROUPS, 
         base[seg_order] = laid[:-1]
     stream = torch.full(((total + STREAM_TAIL) * groups * 4,), pad, dtype=dtype, device=dev)
     if seg_key.numel():
-        if bank_classes and os.environ.get("MGX_TILE_BANK_ORDER", "1") == "1":
+        if bank_classes:
             # narrow rows: a 16-lane pass of ds_read_b128 reads 16 / lanes-per-row rows, and two of them conflict when their slots
             # are equal mod `bank_classes` (a 64-byte row is one bank quarter, a 128-byte row one half).  Inside a group's list the
             # order is free (a sum): every group walks its entries class by class, starting from a class of its own, so that the
@@ -147,19 +149,7 @@ NUM_CUS = 256
 WG_SLOTS = 2 * NUM_CUS  # 8-wave workgroups, two per CU
 
 
-def _longest_first(tile_edges, T, xcds=8):
-    """Dispatch order: XCD x keeps its contiguous stretch of tiles (they share sources: one L2), but runs the longest first -- a launch
-    is only a few tiles per CU deep, and a long tile that starts last leaves the other CUs idle at the end.  Measured on the reddit
-    shape and OFF by default (MGX_TILE_LPT=1): 7x8x1x3 D = 64 1.13 -> 1.22 ms, 14x6x2x3 1.14 -> 1.15 ms -- tiles of one community
-    no longer run side by side and share less in L2 than the shorter tail wins."""
-    per = (T + xcds - 1) // xcds
-    slot = torch.arange(T, device=tile_edges.device)
-    key = (slot // per) * (int(tile_edges.max()) + 1 if T else 1) + (int(tile_edges.max()) - tile_edges if T else 0)
-    return torch.sort(key, stable=True)[1].to(torch.int32)
-
-
-def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, pair_rank=False, split_direct=False,
-                    tail=0.0):
+def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=False, lanes_log2=4, pair_rank=False):
     """csr: CsrView (int32, device or host); base: SpmmPlan over it (items in schedule order; None = natural rows).
     pair_rank (the plans of the fused GAT walks, gat_tile.inc): every entry also carries the RANK k of its edge among the parallel
     edges of its (row, source) pair, in edge-id order -- (destination, source, k) is then a key per edge that both CSRs of a graph
@@ -167,10 +157,6 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     (`lds_stream16`); direct entries: k in bits 24-30 of the source id.  k is kept mod 128: a pair with MORE than 128 parallel
     edges (the heavy-tailed stand-ins have hub pairs with thousands; the datasets have none) re-uses keys, i.e. its edges with
     equal k mod 128 share a mask bit -- both CSRs still see the same multiset of bits per pair, so the three walks stay consistent."""
-    # split_direct (round 4): the edges whose source is used fewer than tau times in their tile -- nothing to re-use -- are NOT walked
-    # by the tile kernel (its direct part stays empty); they are returned as a COO (`tables["direct_coo"]`, destination row / source)
-    # for a second, accumulating launch of the row-per-wave kernel: in the tile kernel that part ran on 14 waves per CU with the
-    # LDS idle and took 40 % of a tile's time for 18 % of the edges (profiles/r03_tile_stamps.txt, reddit D = 64).
     dev = csr.indptr.device
     NC, NACC = int(consumers), int(nacc)
     if NC + int(loaders) not in TILE_WAVES or not 1 <= NACC <= CNT_STRIDE or int(loaders) not in (1, 2, 4):
@@ -208,24 +194,6 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         it_tile = torch.cumsum(newt, 0) - 1
         it_first = torch.cummax(torch.where(newt.bool(), torch.arange(I, device=dev), torch.zeros(I, dtype=torch.int64, device=dev)), 0)[0]
         T = int(it_tile[-1]) + 1
-    elif tail > 0.0 and I >= 64 * R:
-        # tiles that SHRINK toward the end of every XCD's stretch (round 4, MGX_TILE_TAIL=f): a launch is only a few tiles per workgroup
-        # slot deep, so whatever a stretch's last tiles take is idle time on the other slots.  The last fraction f of a stretch's items
-        # goes into tiles of R / 2 items (first half of it) and R / 4 items (the rest); every stretch is padded to the same tile count.
-        idx = torch.arange(I, device=dev)
-        x = torch.div(idx * XCDS, I, rounding_mode="floor")
-        starts = torch.div(torch.arange(XCDS + 1, device=dev) * I + XCDS - 1, XCDS, rounding_mode="floor")  # first item of stretch x: ceil(x I / 8)
-        sx, nx = starts[:-1][x], (starts[1:] - starts[:-1])[x]
-        j = idx - sx
-        A = (nx.double() * (1.0 - tail)).long() // R * R            # whole tiles of R
-        B = A + ((nx - A).double() * 0.5).long() // (R // 2) * (R // 2)
-        tA, tB = A // R, (B - A) // (R // 2)
-        t_loc = torch.where(j < A, j // R, torch.where(j < B, tA + (j - A) // (R // 2), tA + tB + (j - B) // (R // 4)))
-        f_loc = torch.where(j < A, j // R * R, torch.where(j < B, A + (j - A) // (R // 2) * (R // 2), B + (j - B) // (R // 4) * (R // 4)))
-        tpx = int(t_loc.max()) + 1
-        it_tile = x * tpx + t_loc
-        it_first = sx + f_loc
-        T = XCDS * tpx
     else:
         it_tile = torch.arange(I, device=dev) // R
         it_first = it_tile * R
@@ -263,11 +231,7 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         e_rank[order] = (torch.arange(E, device=dev) - run0).to(torch.int32)
         del pk, o1, o2, order, runs, run0, node, eid, e_csr
     e_tile, e_pos = it_tile[e_item], pos[e_item].to(torch.int32)
-    e_row = None
-    if split_direct:
-        e_row = (base.item_node if base is not None and base.item_node is not None else item_row).to(torch.int32)[e_item]
     del e_item, first
-    tile_edges = torch.bincount(e_tile, minlength=T) if os.environ.get("MGX_TILE_LPT", "0") == "1" else None
     # ---- sources gathered >= tau times inside a tile are staged; per tile they are ordered by multiplicity (dense chunks first)
     skey, perm = torch.sort(e_tile * n_src + e_src.long())
     uniq, inv, counts = torch.unique_consecutive(skey, return_inverse=True, return_counts=True)
@@ -320,11 +284,6 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
     del sk, e_slot
     # ---- direct streams: one per (tile, consumer wave)
     direct = ~staged
-    direct_coo = None
-    if split_direct:
-        direct_coo = (e_row[direct].contiguous(), e_src[direct].to(torch.int32).contiguous())
-        direct = torch.zeros_like(direct)  # the kernel's own direct part stays empty
-        del e_row
     dk = e_tile[direct] * per_unit + e_pos[direct]
     dir_payload = e_src[direct].to(torch.int32)
     if e_rank is not None and n_src < (1 << 24):
@@ -350,7 +309,7 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
              "dir_slot_fill": (E - n_staged) / max(int(dir_stream.shape[0]) - STREAM_TAIL * GROUPS * 4, 1),
              "parallel_edges": None if e_rank is None else max_rank > 0,
              "max_pair_rank": None if e_rank is None else max_rank,
-             "pair_rank_streams": lds16 is not None and n_src < (1 << 24), "direct_split": direct_coo is not None}
+             "pair_rank_streams": lds16 is not None and n_src < (1 << 24)}
     tables = {
         "tile_chunk_ptr": tile_chunk_ptr.to(torch.int32),
         "chunk_ids": chunk_ids,
@@ -364,8 +323,7 @@ def build_tile_plan(csr, base, consumers=12, nacc=6, loaders=4, tau=2, balance=F
         "zero_row": torch.zeros(64, dtype=torch.float32, device=dev),
         "tile_node": tile_node,
         "lds_stream16": None if lds16 is None else lds16.view(torch.int32),  # [lds_supersteps * groups * 2] words: 4 x (slot | rank << 8)
-        "tile_order": _longest_first(tile_edges, T) if tile_edges is not None else None,
-        "direct_coo": direct_coo,
+        "tile_order": None,  # optional dispatch order (ABI field); longest-tile-first was measured and lost (docs/LOG_r01_r03.md)
     }
     if lds_total * 4 >= 2 ** 31 or dir_total * 16 >= 2 ** 31:
         raise ValueError("tile plan: stream offsets exceed 31 bits")
@@ -511,22 +469,18 @@ def emulate(plan, x, out_rows, num_slots=0):
     return out, partial
 
 
-TILE_SPLIT = int(os.environ.get("MGX_TILE_SPLIT", 2048))  # hub threshold of the tile kernel's work items
-
-
-_DEFAULT_CFG = {4: "7x6x1x3", 3: "7x3x1x3", 2: "7x3x1x2"}  # 168 / 168 / 336 items per tile (profiles/r03_tile_narrow.txt)
+TILE_SPLIT = _settings.TILE_HUB_SPLIT  # hub threshold of the tile kernel's work items
 
 
 def config(lanes_log2=4):
     """(consumers, nacc, loaders, tau) of the 64- / 32- / 16-column kernel: 8-wave workgroups (7 consumers + 1 loader), two or three
-    per CU.  MGX_TILE_CFG=14x6x2x3 overrides the 64-column kernel's, MGX_TILE_CFG_NARROW the other two."""
-    env = os.environ.get("MGX_TILE_CFG" if lanes_log2 == 4 else "MGX_TILE_CFG_NARROW", "") or _DEFAULT_CFG[int(lanes_log2)]
-    return tuple(int(v) for v in env.split("x"))
+    per CU; 168 / 168 / 336 items per tile (profiles/r03_tile_narrow.txt).  The constants live in mi355x_graph/config.py."""
+    return tuple(_settings.TILE_CONFIG[int(lanes_log2)])
 
 
 def gat_config():
     """(consumers, nacc, loaders, tau) of the tile plans behind the fused GAT walks (gat_tile.inc: 7 + 1 waves, nacc 3 or 4)."""
-    return tuple(int(v) for v in (os.environ.get("MGX_GAT_TILE_CFG", "") or "7x3x1x2").split("x"))
+    return tuple(_settings.GAT_TILE_CONFIG)
 
 
 def lanes_log2_for(width):

@@ -20,7 +20,7 @@ Round 4: the ops are DEFINED AND IMPLEMENTED IN C++ (csrc/torch_bind.cpp: TORCH_
 CUDA, ...) in libmi355x_graph_torch.so, a host translation unit linked against libmi355x_graph.so; the C header stays free of
 torch types).  This module loads that library and adds what belongs to Python: the fake implementations and the autograd
 formula of edge_softmax.  Every op takes a trailing `plan: int = 0` -- the address of the CSR's live mgx_spmm_plan
-(`plan_handle(csr)`), 0 = natural row order.  Without the library (MGX_TORCH_OPS_NATIVE=0, or a tree where it was not built)
+(`plan_handle(csr)`), 0 = natural row order.  Without the library (a tree where it was not built)
 the same schemas are registered from Python over sparse.HipBackend, where a CSR finds its cached schedule again through a
 weak registry keyed by its tensors' storage.
 
@@ -43,7 +43,7 @@ _views = weakref.WeakValueDictionary()
 
 EXT_PATH = os.path.join(CSRC_DIR, "libmi355x_graph_torch.so")
 NATIVE = False
-if os.environ.get("MGX_TORCH_OPS_NATIVE", "1") == "1" and os.path.exists(EXT_PATH):
+if os.path.exists(EXT_PATH):
     torch.ops.load_library(EXT_PATH)  # TORCH_LIBRARY(mi355x_graph): schemas + HIP implementations
     NATIVE = True
 

@@ -56,7 +56,7 @@ torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
 
 # ---- the same raw call through the dispatcher op torch.ops.mi355x_graph.gspmm: C++ (csrc/torch_bind.cpp) unless
-# MGX_TORCH_OPS_NATIVE=0 selects the Python registration
+# (a tree without libmi355x_graph_torch.so falls back to the Python registration)
 from mi355x_graph import torch_ops
 args = torch_ops.csr_args(g._index.csc())
 ph = torch_ops.plan_handle(g._index.csc()) if torch_ops.NATIVE else 0

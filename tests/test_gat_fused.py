@@ -5,6 +5,8 @@ the oracle in test_gpu_parity.py).  Tolerance: 1e-4 relative (north_star), state
 import numpy as np
 import pytest
 import torch
+
+from mi355x_graph import config as mgx_config
 import torch.nn.functional as F
 
 import mi355x_graph as mg
@@ -208,7 +210,7 @@ def test_one_head_widening_layer_aggregates_first(k, f, residual, monkeypatch):
     real = ops.gat_fused
     monkeypatch.setattr(ops, "gat_fused", lambda g_, feat, *a, **kw: (widths.append(int(feat.shape[-1])), real(g_, feat, *a, **kw))[1])
     for first in ("1", "0"):
-        monkeypatch.setenv("MGX_GAT_AGG_FIRST", first)
+        monkeypatch.setattr(mgx_config, "GAT_AGG_FIRST", first == "1")
         x = x0.clone().requires_grad_(True)
         conv.zero_grad()
         y = conv(g, x)
@@ -421,7 +423,7 @@ def test_fused_rejects_mismatched_rows():
 @pytest.mark.parametrize("H,F", [(1, 16), (1, 41), (2, 8), (1, 24), (4, 4)])
 def test_packed_gather_operands_change_nothing(H, F, monkeypatch):
     """Narrow layers gather [feat | el] and [d_out | er, m, 1/s, t] rows packed into whole lines (one L2 request per edge
-    instead of two, mgx_gat_fused_pack_workspace); MGX_GAT_NO_PACK=1 gathers the separate arrays: same bits."""
+    instead of two, mgx_gat_fused_pack_workspace); config.GAT_PACK = False gathers the separate arrays: same bits."""
     from mi355x_graph import _lib
     n = 4000
     src, dst = random_graph(n, n, 60000, seed=H * 100 + F, skew=True)
@@ -436,7 +438,7 @@ def test_packed_gather_operands_change_nothing(H, F, monkeypatch):
     res = []
     for nopack in (False, True):
         if nopack:
-            monkeypatch.setenv("MGX_GAT_NO_PACK", "1")
+            monkeypatch.setattr(mgx_config, "GAT_PACK", False)
         feat, el, er = (t.clone().requires_grad_(True) for t in (feat0, el0, er0))
         out = ops.gat_fused(g, feat, el, er, 0.2)
         (out * w).sum().backward()

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from mi355x_graph import config as mgx_config
+
 import mi355x_graph as mg
 from mi355x_graph import ops
 from conftest import random_graph
@@ -58,7 +60,7 @@ def test_fuzz_gspmm(oracle, seed, monkeypatch):
     red = str(rng.choice(["sum", "mean", "max", "min"]))
     idtype = torch.int32 if rng.integers(0, 2) else torch.int64
     monkeypatch.setenv("MGX_SCHEDULE", str(rng.choice(["auto", "natural", "none"])))
-    monkeypatch.setenv("MGX_SPLIT", str(int(rng.choice([64, 256, 1024]))))
+    monkeypatch.setattr(mgx_config, "HUB_SPLIT", int(rng.choice([64, 256, 1024])))
     ewidth = D if rng.integers(0, 2) else 1          # full-width or scalar edge feature
     X = rng.standard_normal((n_src, D)).astype(np.float32)
     E = (rng.random((nnz, ewidth)).astype(np.float32) + 0.5)
@@ -104,7 +106,7 @@ def test_fuzz_edge_softmax_and_gat_attention(oracle, seed, monkeypatch):
     nnz = int(rng.integers(1, 60000))
     src, dst = random_graph(n, n, nnz, seed=200 + seed)
     H = int(rng.choice([1, 2, 3, 4, 8, 16]))
-    monkeypatch.setenv("MGX_SPLIT", str(int(rng.choice([64, 256]))))
+    monkeypatch.setattr(mgx_config, "HUB_SPLIT", int(rng.choice([64, 256])))
     g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().to(DEV)
     z = (rng.standard_normal((nnz, H, 1)) * 3).astype(np.float32)
     ip, ix, ei = oracle.coo_to_csr(n, dst, src)

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+from mi355x_graph import config as mgx_config
+
 import mi355x_graph as mg
 from mi355x_graph import ops, sparse
 from conftest import random_graph
@@ -457,9 +459,9 @@ def test_device_plan_builder_bit_exact(idtype, monkeypatch):
     order = torch.randperm(n, device=DEV)
     for ordr in (None, order):
         for split in (64, 256):
-            monkeypatch.setenv("MGX_PLAN_BUILDER", "device")
+            monkeypatch.setattr(mgx_config, "PLAN_BUILDER", "device")
             a = schedule.build_plan(csc, ordr, split)
-            monkeypatch.setenv("MGX_PLAN_BUILDER", "torch")
+            monkeypatch.setattr(mgx_config, "PLAN_BUILDER", "torch")
             b = schedule.build_plan(csc, ordr, split)
             assert a.num_items == b.num_items and a.num_hubs == b.num_hubs and a.num_slots == b.num_slots
             assert a.num_hubs > 0
@@ -794,8 +796,8 @@ def test_row_sparse_gradient_aggregation(oracle, D, density, monkeypatch):
     """mgx_row_nonzero_bits + mgx_spmm_copy_u_masked (the backward aggregation of copy_u when most gradient rows are zero,
     main_dgl_product_sage.py:105-106 trains on 8 % of the nodes): bitmap bit-exact, result == the plain g-SpMM == oracle,
     with hub rows (chunked path), every density incl. all-zero and dense, and through autograd."""
-    monkeypatch.setenv("MGX_SPARSE_GRAD_MIN_NNZ", "0")
-    monkeypatch.setenv("MGX_SPARSE_GRAD", "1")
+    monkeypatch.setattr(mgx_config, "SPARSE_GRAD_MIN_NNZ", 0)
+    monkeypatch.setattr(mgx_config, "SPARSE_GRAD", True)
     n, nnz = 3000, 90000
     src, dst = random_graph(n, n, nnz, seed=D)
     src[:4000], dst[:2500] = 7, 11                       # a hub source and a hub destination
@@ -826,7 +828,7 @@ def test_row_sparse_gradient_aggregation(oracle, D, density, monkeypatch):
     w = torch.randn(sel.shape[0], D, device=DEV)
     (ops.gspmm(g, "copy_lhs", "mean", h, None)[sel] * w).sum().backward()
     h2 = h.detach().clone().requires_grad_(True)
-    monkeypatch.setenv("MGX_SPARSE_GRAD", "0")
+    monkeypatch.setattr(mgx_config, "SPARSE_GRAD", False)
     (ops.gspmm(g, "copy_lhs", "mean", h2, None)[sel] * w).sum().backward()
     assert float((h.grad - h2.grad).abs().max()) <= 1e-5 * max(float(h2.grad.abs().max()), 1e-6)
 

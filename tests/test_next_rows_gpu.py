@@ -15,6 +15,8 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 import torch
+
+from mi355x_graph import config as mgx_config
 import torch.nn.functional as F
 
 import mi355x_graph as mg
@@ -238,9 +240,9 @@ def test_fused_sage_layer_node_matches_the_composition(monkeypatch):
     x0 = torch.randn(n, 48, device=DEV)
     w = torch.randn(n, 32, device=DEV)
     res = []
-    monkeypatch.setenv("MGX_SAGE_PROJECT_FIRST", "0")  # 48 -> 32 with a differentiable input would project first (below)
+    monkeypatch.setattr(mgx_config, "SAGE_PROJECT_FIRST", False)  # 48 -> 32 with a differentiable input would project first (below)
     for fused in ("1", "0"):
-        monkeypatch.setenv("MGX_SAGE_FUSED_LAYER", fused)
+        monkeypatch.setattr(mgx_config, "SAGE_FUSED_LAYER", fused == "1")
         x = x0.clone().requires_grad_(True)
         conv.zero_grad()
         y = conv(g, x)
@@ -250,7 +252,7 @@ def test_fused_sage_layer_node_matches_the_composition(monkeypatch):
     for a, b in zip(*res):
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6
     # the projection BEFORE the aggregation (ops.SageMeanProjectFirstFn; upstream dgl.nn.SAGEConv's lin_before_mp): same layer
-    monkeypatch.setenv("MGX_SAGE_PROJECT_FIRST", "1")
+    monkeypatch.setattr(mgx_config, "SAGE_PROJECT_FIRST", True)
     x = x0.clone().requires_grad_(True)
     conv.zero_grad()
     y = conv(g, x)
@@ -283,7 +285,7 @@ def test_log_softmax_on_selected_rows_is_the_same_model_output():
 @pytest.mark.parametrize("batch_norm", [False, True])
 def test_one_gemm_layers_over_cat_buffers_match_the_two_gemm_form(monkeypatch, batch_norm):
     """Default GraphSAGE with dropout: layers as ONE GEMM on [h | neigh] (ops.CatBuffer: strided aggregation in place,
-    relu_dropout writing the next layer's left half, strided backward) against MGX_SAGE_CAT=0 (two GEMMs per layer) with
+    relu_dropout writing the next layer's left half, strided backward) against config.SAGE_CAT = False (two GEMMs per layer) with
     the same dropout masks: same loss, same parameter gradients, over two training steps (the input-feature copy is reused)."""
     sys.path.insert(0, PKG)
     import full_graph
@@ -296,7 +298,7 @@ def test_one_gemm_layers_over_cat_buffers_match_the_two_gemm_form(monkeypatch, b
     idx = torch.arange(0, n, 9, device=DEV)
     runs = []
     for cat in ("1", "0"):
-        monkeypatch.setenv("MGX_SAGE_CAT", cat)
+        monkeypatch.setattr(mgx_config, "SAGE_CAT", cat == "1")
         torch.manual_seed(77)
         ops.ReluDropout._calls = 0
         m = full_graph.GraphSAGE(100, 64, 47, 3, 0.5, batch_norm).to(DEV)  # batch_norm: main_dgl_arxiv_sage.py's bn -> relu -> dropout

@@ -6,6 +6,8 @@ import sys
 import pytest
 import torch
 
+from mi355x_graph import config as mgx_config
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dgl-0.5-benchmark_amd"))
 import mi355x_graph as mg  # noqa: E402,F401
@@ -83,7 +85,7 @@ def test_sage_layer_takes_it_and_keeps_its_gradients():
     rows = torch.arange(0, n, 9, device=DEV)
     results = []
     for on in (True, False):
-        ops._ROWS_GEMM = on
+        mgx_config.ROWS_GEMM = on
         try:
             torch.manual_seed(5)
             model = full_graph.GraphSAGE(100, 64, 47, 3, 0.0, False, True).to(DEV)
@@ -91,7 +93,7 @@ def test_sage_layer_takes_it_and_keeps_its_gradients():
             loss.backward()
             results.append((float(loss), [p.grad.clone() for p in model.parameters()]))
         finally:
-            ops._ROWS_GEMM = True
+            mgx_config.ROWS_GEMM = True
     (l1, g1), (l0, g0) = results
     assert abs(l1 - l0) <= 1e-5 * abs(l0)
     for a, b in zip(g1, g0):
@@ -112,7 +114,7 @@ def test_layer_with_the_activation_in_the_epilogue_is_bitwise_the_composition():
     rows = torch.arange(0, n, 7, device=DEV)
     results = []
     for fused in ("1", "0"):
-        os.environ["MGX_SAGE_FUSED_ACT"] = fused
+        mgx_config.SAGE_FUSED_ACT = fused == "1"
         try:
             torch.manual_seed(11)
             ops.ReluDropout._calls = 0
@@ -123,7 +125,7 @@ def test_layer_with_the_activation_in_the_epilogue_is_bitwise_the_composition():
             loss.backward()
             results.append((out.detach().clone(), float(loss), [p.grad.clone() for p in model.parameters()], ops.ReluDropout._calls))
         finally:
-            os.environ.pop("MGX_SAGE_FUSED_ACT", None)
+            mgx_config.SAGE_FUSED_ACT = True
     (o1, l1, g1, c1), (o0, l0, g0, c0) = results
     assert c1 == c0 == 2                                   # two activations, two positions in the random stream either way
     assert torch.equal(o1, o0) and l1 == l0

@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from mi355x_graph import config as mgx_config
+
 from mi355x_graph import schedule, sparse, tileplan
 from conftest import random_graph
 
@@ -35,7 +37,7 @@ def host_csr(n, src, dst):
 @pytest.mark.parametrize("cfg", [(12, 2, 4, 2, 4), (14, 5, 2, 2, 4), (12, 6, 4, 3, 4), (14, 8, 2, 1, 4), (7, 12, 1, 2, 4),
                                  (7, 8, 1, 3, 3), (7, 4, 1, 2, 2)])
 def test_tile_plan_walks_to_the_dense_product(cfg, monkeypatch):
-    monkeypatch.setenv("MGX_PLAN_BUILDER", "host")
+    monkeypatch.setattr(mgx_config, "PLAN_BUILDER", "host")
     n = 500
     src, dst, hub = hub_graph(n, 20000, 3000, seed=5)
     csr = host_csr(n, src, dst)
@@ -198,7 +200,7 @@ def test_gat_tile_plan_carries_nodes_and_ranks_among_parallel_edges(monkeypatch)
     """The plans behind the tile forms of the fused GAT walks (csrc/gat_tile.inc): every position knows its NODE (hub chunks:
     their row), and every entry the rank of its edge among the parallel edges of its (row, source) pair, mod 128 -- in the second
     byte of the 16-bit staged stream and in bits 24-30 of a direct id.  Per pair the ranks are 0 .. m - 1: a key per edge."""
-    monkeypatch.setenv("MGX_PLAN_BUILDER", "host")
+    monkeypatch.setattr(mgx_config, "PLAN_BUILDER", "host")
     n = 400
     src, dst, hub = hub_graph(n, 30000, 5000, seed=13)       # multigraph: the hub row repeats its sources ~12 times
     src = np.concatenate([src, np.full(300, 7)])             # and one pair with 300 parallel edges (ranks wrap at 128)
