@@ -26,14 +26,24 @@ HBM_PEAK = 8.0e12
 def time_op(fn, reps=10):
     times = []
     for i in range(reps):
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        fn()
-        e.record()
-        torch.cuda.synchronize()
+        if not torch.cuda.is_available() or CPU_RUN:  # --gpu -1: the CPU (OpenMP) variants, host clock (kernel/utils.py:18-34 does the same)
+            import time
+            t0 = time.perf_counter()
+            fn()
+            dt = time.perf_counter() - t0
+        else:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            dt = s.elapsed_time(e) / 1e3
         if i >= N_COLD:
-            times.append(s.elapsed_time(e) / 1e3)
+            times.append(dt)
     return sum(times) / len(times), min(times), max(times)
+
+
+CPU_RUN = False
 
 
 def spread(avg, best, worst):
@@ -87,9 +97,15 @@ def main():
                    help="order of the edge list (= of the edge ids): as generated (random), or sorted by destination / source")
     p.add_argument("--json", type=str, default=None)
     args = p.parse_args()
-    if args.gpu == "-1":
-        raise SystemExit("this backend has no CPU path; run the CPU oracle through bench.py's cpu_baseline leg")
-    ctx = torch.device("cuda:%d" % int(args.gpu))
+    global CPU_RUN
+    if args.gpu == "-1":  # kernel/dgl-new.py:55-58: the CPU kernels -- here the library's CPU (OpenMP) variants, switched on explicitly
+        import mi355x_graph
+        mi355x_graph.enable_cpu_backend(True)
+        CPU_RUN = True
+        ctx = torch.device("cpu")
+        print("CPU (OpenMP) variants: %d threads" % mi355x_graph.cpu_backend.lib().mgx_cpu_num_threads())
+    else:
+        ctx = torch.device("cuda:%d" % int(args.gpu))
     results = []
     for ds in args.datasets.split(","):
         g = get_graph(ds, ctx, args.scale, args.edge_order).int().to(ctx)
@@ -103,7 +119,8 @@ def main():
                 # every width measured on freshly placed operands: inside a sweep that reuses the allocator's cached blocks
                 # the proteins D = 128 launch took 6.4 ms against 2.07 ms on its own (same kernel, same sizes; only the
                 # placement of the 68 / 153 / 68 MB operands differs -- observed twice, not understood)
-                torch.cuda.empty_cache()
+                if not CPU_RUN:
+                    torch.cuda.empty_cache()
                 nfeat = torch.rand(n_src, n_hid, device=ctx)
                 efeat = torch.rand(nnz, n_hid, device=ctx) if args.spmm_binary != "copy_lhs" else None
                 avg, best, worst = time_op(lambda: dgl.ops.gspmm(g, args.spmm_binary, args.spmm_reduce, nfeat, efeat))
@@ -127,7 +144,8 @@ def main():
                                         min_s=best, max_s=worst, edges_per_s=nnz / avg, algo_GBps=gbs))
                     del ufeat, vfeat
         del g
-        torch.cuda.empty_cache()
+        if not CPU_RUN:
+            torch.cuda.empty_cache()
     if args.json:
         with open(args.json, "w") as f:
             json.dump(results, f, indent=1)

@@ -582,6 +582,8 @@ class HipBackend(object):
         return out
 
     SDDMM_PERM_MIN_EDGES = 1 << 20
+    SDDMM_PERM_MIN_WIDTH = 32  # measured (profiles/r05_sddmm_perm.txt): D = 64 / 128 gain 17 - 27 %, D = 16 loses 20 % (a 64-byte output row
+                               # is half a line: scattering it costs more than the operand misses it saves)
 
     @staticmethod
     def _sddmm_in_csr_order(gidx, op, L, R, lt, rt, l_len, r_len, out_len, l_off, r_off):
@@ -598,7 +600,7 @@ class HipBackend(object):
             return False
         if mode == "csr":
             return True
-        if getattr(gidx, "ephemeral", False) or csc.nnz < HipBackend.SDDMM_PERM_MIN_EDGES:
+        if getattr(gidx, "ephemeral", False) or csc.nnz < HipBackend.SDDMM_PERM_MIN_EDGES or out_len < HipBackend.SDDMM_PERM_MIN_WIDTH:
             return False
         if not gidx.has_format("coo"):
             return True  # no edge list to walk: the lean kernel over the CSR's order replaces the generic CSR body

@@ -16,9 +16,10 @@ for p in (os.path.join(HERE, "shims"), os.path.join(ROOT, "dgl-0.5-benchmark_amd
 
 import torch  # noqa: E402
 
-if not torch.cuda.is_available():
+if not torch.cuda.is_available() and os.environ.get("MGX_CPU_BACKEND", "0") != "1":
     import oracle_backend  # noqa: E402
     oracle_backend.install()
+# (MGX_CPU_BACKEND=1: `import dgl` registers the PRODUCT's CPU (OpenMP) variants -- csrc/cpu_ops.cpp -- and the oracle stays out)
 
 script = os.path.abspath(sys.argv[1])
 sys.argv = [script] + sys.argv[2:]

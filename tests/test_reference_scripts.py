@@ -52,6 +52,16 @@ def test_reference_script_runs_unmodified(script, args):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("script,args", [SCRIPTS[0], SCRIPTS[2], SCRIPTS[8]], ids=["citation_sage", "citation_gat", "molhiv_gcn"])
+def test_config0_on_the_product_cpu_variants(script, args):
+    """BASELINE configs[0] ("2-layer GraphSAGE on cora ... runs without a GPU") through the PRODUCT's CPU (OpenMP) variants
+    (include/mi355x_graph_cpu.h; MGX_CPU_BACKEND=1) -- the oracle is not even imported in that process."""
+    out = run(script, *args, MGX_CPU_BACKEND="1")
+    if "graph_classification" not in script:
+        assert re.findall(r"Training time/epoch ([0-9.eE+-]+)", out), out[-1500:]
+
+
+@pytest.mark.timeout(900)
 def test_neighbor_sampling_script_runs_unmodified():
     """reddit/ns-sage-dgl.py (MultiLayerNeighborSampler + NodeDataLoader + dglnn.SAGEConv on
     blocks, full-neighbour inference) on a 1 %-scale reddit stand-in."""
