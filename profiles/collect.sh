@@ -2,14 +2,14 @@
 # Commands that produced the summaries in this directory (run on the MI355X box through gpurun, from the
 # repo root; rocprofv3 needs a writable cwd/TMPDIR).  Counters are collected in their own passes
 # (--pmc only, never combined with tracing), as the pool requires.
-#   gpurun -- 'bash profiles/collect.sh r02'   then the summaries are written by profiles/summarize.py (called below)
+#   gpurun -- 'bash profiles/collect.sh r05'   then the summaries are written by profiles/summarize.py (called below)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline --no-pmc --no-controls --no-plain --no-scale-model"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-pmc --no-controls --no-plain --no-scale-model --no-secondary --no-variants"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_bench_trace -- $BENCH --steps 5 --warmup 2 > $O/${TAG}_bench_trace.log 2>&1
 python3 $R/experiments/epoch_timeline.py $O/${TAG}_bench_trace > $O/${TAG}_epoch_timeline.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_bench_fetch -- $BENCH --steps 3 --warmup 1 > $O/${TAG}_bench_fetch.log 2>&1
