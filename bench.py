@@ -154,6 +154,24 @@ def cpu_baseline(g, feat_dim, hidden, budget_s=30.0):
                                     "%d threads; no optimizer step" % cores}
     except Exception as err:
         out["epoch"] = {"error": str(err)[:200]}
+    # the library's own CPU (OpenMP) variants (include/mi355x_graph_cpu.h, csrc/cpu_ops.cpp: product code, opt-in) on one D = hidden
+    # aggregation, same cores -- beside the oracle's number, never instead of it
+    try:
+        import ctypes
+        from mi355x_graph import cpu_backend, sparse as msparse
+        cpu_backend.lib().mgx_cpu_set_num_threads(cores)
+        ip, ix = host["csc"]
+        view = msparse.CsrView(n, n, torch.from_numpy(ip), torch.from_numpy(ix), None)
+        xh = torch.from_numpy(feats[hidden])
+        be_cpu = cpu_backend.CpuBackend()
+        be_cpu.spmm(view, "copy_lhs", "mean", xh[:, :4].contiguous(), None, 4, 0, 4, None, None, None, None, False)  # threads started outside the clock
+        t0 = time.perf_counter()
+        be_cpu.spmm(view, "copy_lhs", "mean", xh, None, hidden, 0, hidden, None, None, None, None, False)
+        dt = time.perf_counter() - t0
+        out["product_cpu_variants"] = {"value": nnz / dt, "unit": "edges/s", "kind": "mgx_cpu_spmm_csr (copy_u/mean, D=%d), libmi355x_graph_cpu.so" % hidden,
+                                       "cores": cores, "seconds": round(dt, 3)}
+    except Exception as err:  # must not lose the bench line
+        out["product_cpu_variants"] = {"value": None, "error": str(err)[:200]}
     # independent second CPU number: PyTorch's own CSR SpMM on the same cores, one D=hidden aggregation
     try:
         torch.set_num_threads(cores)
@@ -404,7 +422,10 @@ def main():
             "per_rank": [{"owned_rows": r[0], "halo_rows": r[1], "send_rows": r[2], "local_edges": r[3], "halo_edges": r[4],
                           "halo_bytes_per_exchange_D%d" % D_hid: r[1] * D_hid * 4} for r in allr],
             "max_halo_bytes_per_exchange": max(r[1] for r in allr) * D_hid * 4,
-            "exchanges_per_epoch": "2 forward (the layer-1 input halo is resident) + 2 backward, D=%d each" % D_hid})
+            "exchanges_per_epoch": "2 forward (the layer-1 input halo is resident) + 2 backward, D=%d each; dense-row bytes above -- with "
+                                   "MGX_SPARSE_HALO (default) the relu + dropout rows cross as bitmaps + non-zeros and their gradients under "
+                                   "the same bitmaps (dist.SparseHalo): bytes_received_per_epoch below is what really moved" % D_hid,
+            "sparse_halo": mdist.SPARSE_HALO})
     if world > 1 or not args.emulate_ranks:
         del src, dst
     opt = torch.optim.Adam(model.parameters(), lr=cfg["lr"])
