@@ -368,11 +368,14 @@ def structural_zeros(t):
     """True when the caller marked `t` as the output of relu (+ dropout): its zeros are structural -- whoever produced it multiplies
     the gradient arriving at a zero position by zero (ops.relu_dropout tags its result; torch.relu outputs can be tagged with
     mark_structural_zeros).  Only then may the halo exchange drop those gradient entries."""
-    return bool(getattr(t, "_mgx_structural_zeros", False))
+    tagged = getattr(t, "_mgx_structural_zeros", None)
+    # the tag holds the tensor's version counter at tagging time: an in-place write afterwards (h.sub_(c), h[i] = 0 ...) may create zeros that
+    # are NOT annihilated by the producer's backward, so it voids the tag
+    return tagged is not None and tagged is not False and int(tagged) == int(t._version)
 
 
 def mark_structural_zeros(t):
-    t._mgx_structural_zeros = True
+    t._mgx_structural_zeros = int(t._version)
     return t
 
 

@@ -553,7 +553,7 @@ def _structural_zeros(y):
     """Tag a relu (+ dropout) output: its zeros are structural -- this node's backward multiplies whatever gradient arrives at a zero
     position by zero -- which lets a partition's halo exchange send the row as bitmap + non-zeros and take back only the gradient
     entries under that bitmap (dist.SparseHalo).  A plain attribute on the tensor object: it does not survive further ops."""
-    y._mgx_structural_zeros = True
+    y._mgx_structural_zeros = int(y._version)  # (an in-place write afterwards bumps the version and voids the tag: dist.structural_zeros)
     return y
 
 

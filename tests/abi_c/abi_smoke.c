@@ -170,6 +170,64 @@ int main(void) {
     }
   }
 
+  /* round 5: halo rows as bitmaps + packed values -- unpack(pack(x)) == x bit for bit, rows gathered through an index, a strided source */
+  {
+    enum { NR = 37, PD = 100, LD = 104, NS = 23 };
+    static float P[NR * LD], Q[NS * PD];
+    static int32_t idx[NS], cnt[NS];
+    static int64_t off[NS + 1];
+    static uint64_t msk[NS * 2];
+    for (int i = 0; i < NR * LD; ++i) P[i] = ((i * 2654435761u) >> 7) % 4 == 0 ? (float)(i % 97) - 48.f : 0.f;  /* ~25 % non-zero */
+    for (int i = 0; i < NS; ++i) idx[i] = (i * 7) % NR;
+    if (mgx_rows_mask_words(PD) != 2) { printf("mgx_rows_mask_words(100) != 2\n"); return 12; }
+    float* d_P = dev_copy(P, sizeof P);
+    int32_t* d_idx = dev_copy(idx, sizeof idx);
+    uint64_t* d_msk = dev_copy(NULL, sizeof msk);
+    int32_t* d_cnt = dev_copy(NULL, sizeof cnt);
+    CHECK_MGX(mgx_rows_pack_count(NS, d_idx, 32, PD, d_P, LD, d_msk, d_cnt, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(cnt, d_cnt, sizeof cnt, hipMemcpyDeviceToHost));
+    off[0] = 0;
+    for (int i = 0; i < NS; ++i) {
+      int want_n = 0;
+      for (int c = 0; c < PD; ++c) want_n += P[idx[i] * LD + c] != 0.f;
+      if (cnt[i] != want_n) { printf("rows_pack_count: row %d has %d non-zeros, kernel says %d\n", i, want_n, cnt[i]); return 12; }
+      off[i + 1] = off[i] + cnt[i];
+    }
+    int64_t* d_off = dev_copy(off, sizeof off);
+    float* d_val = dev_copy(NULL, (size_t)off[NS] * 4);
+    float* d_Q = dev_copy(NULL, sizeof Q);
+    CHECK_MGX(mgx_rows_pack_values(NS, d_idx, 32, PD, d_P, LD, d_msk, d_off, d_val, NULL));
+    CHECK_MGX(mgx_rows_unpack(NS, PD, d_msk, d_off, d_val, d_Q, PD, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(Q, d_Q, sizeof Q, hipMemcpyDeviceToHost));
+    for (int i = 0; i < NS; ++i)
+      for (int c = 0; c < PD; ++c)
+        if (Q[i * PD + c] != P[idx[i] * LD + c]) { printf("rows pack / unpack mismatch at (%d, %d)\n", i, c); return 12; }
+  }
+
+  /* round 5: u_add_v walked in the in-CSR's order with the edge id as the output row == the walk in edge-id order */
+  {
+    enum { SD = 8 };
+    static float U8[5 * SD], a_coo[8 * SD], a_perm[8 * SD];
+    for (int i = 0; i < 5 * SD; ++i) U8[i] = (float)(i % 13) * 0.5f;
+    /* the CSR as an edge list in ITS order: sources = indices, destinations = the row of every position, perm = eids */
+    const int32_t rows_of_pos[8] = {0, 1, 2, 2, 3, 3, 3, 3};
+    float* d_U8 = dev_copy(U8, sizeof U8);
+    int32_t* d_rows = dev_copy(rows_of_pos, sizeof rows_of_pos);
+    float *d_a1 = dev_copy(NULL, sizeof a_coo), *d_a2 = dev_copy(NULL, sizeof a_perm);
+    CHECK_MGX(mgx_sddmm_coo(n, n, nnz, d_src, d_dst, 32, MGX_OP_ADD, d_U8, d_U8, MGX_TARGET_U, MGX_TARGET_V, SD, SD, SD, 1, NULL, NULL, d_a1, NULL));
+    CHECK_MGX(mgx_sddmm_coo_perm(n, n, nnz, d_indices, d_rows, d_eids, 32, MGX_OP_ADD, d_U8, d_U8, MGX_TARGET_U, MGX_TARGET_V, SD, d_a2, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(a_coo, d_a1, sizeof a_coo, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(a_perm, d_a2, sizeof a_perm, hipMemcpyDeviceToHost));
+    for (int e = 0; e < nnz; ++e)
+      for (int c = 0; c < SD; ++c) {
+        const float ref = U8[src[e] * SD + c] + U8[dst[e] * SD + c];
+        if (a_coo[e * SD + c] != ref || a_perm[e * SD + c] != ref) { printf("sddmm_coo_perm mismatch at edge %d\n", e); return 13; }
+      }
+  }
+
   /* error path: bad argument must return a code and a message, not crash */
   if (mgx_spmm_csr(NULL, NULL, 0, 0, NULL, NULL, 1, 1, 1, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL) != MGX_ERR_INVALID_ARGUMENT ||
       strstr(mgx_last_error(), "csr is NULL") == NULL) { printf("error path broken\n"); return 8; }

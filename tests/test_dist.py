@@ -237,6 +237,21 @@ def test_partition_is_balanced_and_cuts_less_than_random():
         oracle_backend.uninstall()
 
 
+def test_structural_zero_tag_is_voided_by_an_in_place_write():
+    """dist.SparseHalo may drop gradient entries at the zeros of a relu (+ dropout) output only: the tag carries the tensor's version
+    counter, so a later in-place write -- which may create zeros the producer's backward does not annihilate -- voids it."""
+    from mi355x_graph import ops
+    y = ops.relu_dropout(torch.randn(6, 8), 0.0, True)
+    assert mdist.structural_zeros(y)
+    assert not mdist.structural_zeros(y[:3]) and not mdist.structural_zeros(y * 1.0)      # new tensor objects carry no tag
+    y.sub_(0.25)
+    assert not mdist.structural_zeros(y)
+    z = mdist.mark_structural_zeros(torch.relu(torch.randn(4, 8)))
+    assert mdist.structural_zeros(z)
+    z[0, 0] = 0.0
+    assert not mdist.structural_zeros(z)
+
+
 def test_halo_plan_consistency():
     """Every rank's receive list from q must equal q's send list to it (same order)."""
     from mi355x_graph.datasets import synthetic_edges
