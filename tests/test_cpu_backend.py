@@ -197,3 +197,47 @@ def test_bad_arguments_raise_not_crash():
     c = mg._lib.MgxCsr(1, 1, 0, None, None, None, 16, 0)
     assert L.mgx_cpu_spmm_csr(ctypes.byref(c), None, 0, 0, None, None, 1, 1, 1, None, None, None, None, None, None, None, None, 0, None) == 1
     assert L.mgx_cpu_sddmm_coo(1, 1, 1, None, None, 32, 99, None, None, 0, 2, 1, 1, 1, 1, None, None, None, None) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("op,reduce", [("copy_lhs", "sum"), ("copy_lhs", "mean"), ("mul", "sum"), ("add", "max"), ("copy_rhs", "min")])
+def test_hip_kernels_and_cpu_variants_agree(cpu_on, op, reduce):
+    """Two product implementations of one contract, HIP (libmi355x_graph.so) and CPU (libmi355x_graph_cpu.so), on the same inputs:
+    selections (max / min values and arg indices) and element-wise g-SDDMM bit for bit, sums within 1e-4 of the row's sum of |terms|."""
+    dev = torch.device("cuda:0")
+    n_src, n_dst, nnz, D = 900, 700, 40000, 24
+    src, dst = random_graph(n_src, n_dst, nnz, seed=21)
+    rng = np.random.default_rng(6)
+    U = torch.from_numpy(rng.standard_normal((n_src, D)).astype(np.float32))
+    E = torch.from_numpy((rng.random((nnz, D)) + 0.5).astype(np.float32))
+    edges = (torch.from_numpy(src), torch.from_numpy(dst))
+    g_cpu = mg.create_block(edges, n_src, n_dst, idtype=torch.int32)
+    g_hip = mg.create_block(edges, n_src, n_dst, idtype=torch.int32, device=dev)
+    out_c = ops.gspmm(g_cpu, op, reduce, U, E)
+    out_h = ops.gspmm(g_hip, op, reduce, U.to(dev), E.to(dev)).cpu()
+    if reduce in ("max", "min"):
+        assert torch.equal(out_c, out_h)
+    else:
+        scale = ops.gspmm(g_cpu, op, "sum", U.abs(), E.abs()) + 1e-6
+        assert float(((out_c - out_h).abs() / scale).max()) <= 1e-4
+    V = torch.from_numpy(rng.standard_normal((n_dst, D)).astype(np.float32))
+    for sop in ("add", "mul", "sub"):
+        assert torch.equal(ops.gsddmm(g_cpu, sop, U, V), ops.gsddmm(g_hip, sop, U.to(dev), V.to(dev)).cpu())
+    z = torch.from_numpy((rng.standard_normal((nnz, 2, 1)) * 2).astype(np.float32))
+    a_c, a_h = ops.edge_softmax(g_cpu, z), ops.edge_softmax(g_hip, z.to(dev)).cpu()
+    assert float((a_c - a_h).abs().max()) <= 1e-6
+
+
+@pytest.mark.gpu
+def test_secondary_bench_leg_runs_and_reports_a_roofline(monkeypatch):
+    """bench.py's `secondary` block (secondary_bench.py): one leg end to end on the GPU at a reduced size -- ms_per_step, the dominant
+    hot-path call and SURVEY 8d's bytes for it."""
+    monkeypatch.setenv("MGX_DATASET_SCALE", "0.2")
+    sys.path.insert(0, os.path.join(ROOT, "dgl-0.5-benchmark_amd"))
+    import secondary_bench as sb
+    out = sb.sage_arxiv(torch.device("cuda:0"), steps=3, warmup=2)
+    r = out["roofline"]
+    assert out["ms_per_step"] > 0 and r["bound"] == "hbm" and "g-SpMM copy_lhs" in r["kernel"] and r["D"] if "D" in r else True
+    assert r["algorithmic_bytes_per_launch"] > 0 and 0 < r["frac"] < 1 and r["launches_timed"] >= 3
+    out = sb._gat(torch.device("cuda:0"), "reddit-small", 2, 8, 16, 0.0, 2, 1, "test", "-")
+    assert "fused GAT block" in out["roofline"]["kernel"] and out["ms_per_step"] > 0
