@@ -231,6 +231,64 @@ extern "C" int32_t mgx_rows_unpack(int64_t n, int64_t D, const uint64_t* masks, 
 // walks its entries in CSR order (= peer order: deterministic), rows without entries are left alone.
 namespace mgx {
 namespace {
+// One 64-column block per row (D <= 64): the entries' metadata is fetched by the lane group TOGETHER -- lane q of the group loads position,
+// offset and mask of the row's q-th entry -- and handed round with ds_bpermute, so that a row of k entries costs two dependent round trips
+// + k independent value gathers (issued four at a time) instead of 3 k dependent ones.  Entries are still added in CSR order.
+template <int G>
+__global__ __launch_bounds__(kBlock) void rows_unpack_add_csr1_kernel(int64_t n, const int32_t* __restrict__ indptr, const int32_t* __restrict__ pos,
+                                                                      int D, const uint64_t* __restrict__ masks,
+                                                                      const int64_t* __restrict__ offsets, const float* __restrict__ values,
+                                                                      float* __restrict__ out, int64_t ldo) {
+  constexpr int RPW = kWave / G;
+  constexpr int U = 4;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int l = lane % G, sub = lane / G, gbase = sub * G;
+  const int64_t wave_id = (int64_t)blockIdx.x * kWavesPerBlock + threadIdx.x / kWave;
+  const int64_t n_waves = (int64_t)gridDim.x * kWavesPerBlock;
+  const int c0 = l * 4;
+  const bool cact = c0 < D;
+  for (int64_t base = wave_id * RPW; base < n; base += n_waves * RPW) {  // wave-uniform trip count: the cross-lane reads below need every lane
+    const int64_t v = base + sub;
+    const bool live = v < n;
+    const int32_t beg = live ? indptr[v] : 0, end = live ? indptr[v + 1] : 0;
+    v4f acc = (v4f)(0.f);
+    if (live && cact && end > beg) acc = *reinterpret_cast<const v4f*>(out + v * ldo + c0);
+    for (int32_t chunk = 0;; chunk += G) {  // G entries of every row of the wave at a time
+      const int cnt = (end - beg - chunk) < G ? (end - beg - chunk) : G;  // this row's entries in the chunk (may be <= 0)
+      if (__builtin_amdgcn_ballot_w64(cnt > 0) == 0) break;
+      int32_t p = 0;
+      uint32_t off_lo = 0, m_lo = 0, m_hi = 0;
+      if (l < cnt) {
+        p = pos[beg + chunk + l];
+        const int64_t o = offsets[p];  // below 2^32 values per message (host check)
+        const uint64_t m = masks[p];
+        off_lo = (uint32_t)o; m_lo = (uint32_t)m; m_hi = (uint32_t)(m >> 32);
+      }
+      const int maxcnt = __builtin_amdgcn_readfirstlane(__reduce_max_sync(~0ull, cnt > 0 ? cnt : 0));
+      for (int q = 0; q < maxcnt; q += U) {
+        float got[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int bi = (gbase + ((q + u) < G ? (q + u) : 0)) * 4;
+          const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)off_lo);
+          const uint64_t m = ((uint64_t)(uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)m_hi) << 32) | (uint32_t)__builtin_amdgcn_ds_bpermute(bi, (int)m_lo);
+          const bool have = (q + u) < cnt && cact;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int bit = c * G + l;
+            got[u][c] = (have && ((m >> bit) & 1ull)) ? values[o + __popcll(m & ((1ull << bit) - 1ull))] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] += got[u][c];  // (adding 0.f for an absent entry changes nothing: x + 0 == x, and -0 never occurs in acc + 0)
+      }
+    }
+    if (live && cact && end > beg) *reinterpret_cast<v4f*>(out + v * ldo + c0) = acc;
+  }
+}
+
 template <int G>
 __global__ __launch_bounds__(kBlock) void rows_unpack_add_csr_kernel(int64_t n, const int32_t* __restrict__ indptr, const int32_t* __restrict__ pos,
                                                                      int D, int nblk, const uint64_t* __restrict__ masks,
@@ -278,6 +336,18 @@ extern "C" int32_t mgx_rows_unpack_add_csr(int64_t n, const int32_t* indptr, con
   const RowShape sh = row_shape(D);
   const dim3 grid((unsigned)stream_blocks(n, kWave / sh.G)), block(kBlock);
   hipStream_t s = (hipStream_t)stream;
+  if (sh.nblk == 1 && sh.G >= 2) {  // one block per row: the lane group fetches its entries' metadata together
+#define MGX_UA1(GG) hipLaunchKernelGGL((rows_unpack_add_csr1_kernel<GG>), grid, block, 0, s, n, indptr, positions, (int)D, masks, offsets, values, out, out_stride)
+    switch (sh.G) {
+      case 2: MGX_UA1(2); break;
+      case 4: MGX_UA1(4); break;
+      case 8: MGX_UA1(8); break;
+      default: MGX_UA1(16); break;
+    }
+#undef MGX_UA1
+    MGX_CHECK_LAUNCH();
+    return MGX_OK;
+  }
 #define MGX_UA(GG) hipLaunchKernelGGL((rows_unpack_add_csr_kernel<GG>), grid, block, 0, s, n, indptr, positions, (int)D, sh.nblk, masks, offsets, values, out, out_stride)
   switch (sh.G) {
     case 1: MGX_UA(1); break;

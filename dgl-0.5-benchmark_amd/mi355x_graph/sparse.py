@@ -1052,8 +1052,8 @@ class HipBackend(object):
     def rows_unpack_add_csr(self, csr, masks, offsets, values, out):
         """out[v] += the packed rows at the positions listed in row v of `csr` (int32), in CSR order; out row-strided."""
         dev = self._check_dev(csr.indptr, masks, offsets, values, out)
-        if csr.idx_bits != 32:
-            raise DGLError("rows_unpack_add_csr: int32 CSR only")
+        if csr.idx_bits != 32 or values.numel() >= 2 ** 32:
+            raise DGLError("rows_unpack_add_csr: int32 CSR and fewer than 2^32 packed values only")
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mgx_rows_unpack_add_csr(csr.num_rows, _ptr(csr.indptr), _ptr(csr.indices), int(out.shape[1]), _ptr(masks),
                                                           _ptr(offsets), _ptr(values), _ptr(out), out.stride(0), _stream(dev)))

@@ -498,7 +498,8 @@ int32_t mgx_rows_pack_values(int64_t n, const void* idx, int32_t idx_bits, int64
 int32_t mgx_rows_unpack(int64_t n, int64_t D, const uint64_t* masks, const int64_t* offsets, const float* values,
                         float* out /* [n, D] rows out_stride apart; zeros where the mask is clear */, int64_t out_stride, void* stream);
 /* out[v, :] += sum over the entries p = positions[q], q in [indptr[v], indptr[v+1]), of the packed row p (int32 CSR over the n output rows;
- * entries added in CSR order: deterministic): the returned halo-row gradients added into their owners without a dense intermediate. */
+ * entries added in CSR order: deterministic): the returned halo-row gradients added into their owners without a dense intermediate.
+ * `values` holds fewer than 2^32 floats (offsets are used as 32-bit numbers on the D <= 64 path). */
 int32_t mgx_rows_unpack_add_csr(int64_t n, const int32_t* indptr, const int32_t* positions, int64_t D, const uint64_t* masks,
                                 const int64_t* offsets, const float* values, float* out, int64_t out_stride, void* stream);
 
