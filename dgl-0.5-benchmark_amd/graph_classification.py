@@ -198,28 +198,47 @@ class GraphedBatchTrainer(object):
     def fits(self, bg):
         return bg.number_of_nodes() + 2 <= self.n_pad and bg.number_of_edges() <= self.e_pad  # two ghost nodes at least
 
-    def _pad(self, bg, labels):
-        """Host tensors of the padded batch (ghost nodes / edges / graphs appended)."""
+    def _pad(self, bg, labels, into=None):
+        """Host tensors of the padded batch (ghost nodes / edges / graphs appended), written IN PLACE into `into` (a set of static-shape
+        buffers: the pinned staging set of step()) or into new tensors.  A dozen slice assignments: no concatenation, no second copy."""
         n, e, b = bg.number_of_nodes(), bg.number_of_edges(), int(labels.shape[0])
         n_pad, e_pad, B = self.n_pad, self.e_pad, self.B
         src, dst = bg.edges()
+        atom, bond = bg.ndata["feat"], bg.edata["feat"]
+        if into is None:
+            into = {"src": torch.empty(e_pad, dtype=torch.int32), "dst": torch.empty(e_pad, dtype=torch.int32),
+                    "atom": atom.new_empty((n_pad,) + tuple(atom.shape[1:])), "bond": bond.new_empty((e_pad,) + tuple(bond.shape[1:])),
+                    "bnn": torch.empty(B + 1, dtype=torch.int64), "labels": torch.empty(B), "gmask": torch.empty(B),
+                    "gcount": torch.empty(()), "mask": torch.empty((n_pad, 1), dtype=torch.bool), "count": torch.empty(())}
+        if getattr(self, "_ramp", None) is None:
+            self._ramp = torch.arange(e_pad + 1, dtype=torch.int32)
         # ghost edges run round-robin over the ghost nodes (i -> i + 1): ghost rows keep the degree of ordinary nodes, so
         # their values stay in the range of real rows under a sum aggregator (one ghost hub overflowed GIN's to inf)
-        gi = torch.arange(e_pad - e, dtype=torch.int32)
-        gsrc, gdst = n + gi % (n_pad - n), n + (gi + 1) % (n_pad - n)
-        atom, bond = bg.ndata["feat"], bg.edata["feat"]
-        return {
-            "src": torch.cat([src.to(torch.int32), gsrc]), "dst": torch.cat([dst.to(torch.int32), gdst]),
-            "atom": torch.cat([atom, atom.new_zeros((n_pad - n,) + tuple(atom.shape[1:]))]),
-            "bond": torch.cat([bond, bond.new_zeros((e_pad - e,) + tuple(bond.shape[1:]))]),
-            "bnn": torch.cat([bg.batch_num_nodes().to(torch.int64), torch.zeros(B - b, dtype=torch.int64),
-                              torch.tensor([n_pad - n], dtype=torch.int64)]),
-            "labels": torch.cat([labels.float().view(-1), torch.zeros(B - b)]),
-            "gmask": (torch.arange(B) < b).float(),
-            "gcount": torch.tensor(float(b)),
-            "mask": (torch.arange(n_pad) < n).unsqueeze(1),
-            "count": torch.tensor(float(n)),
-        }
+        ghosts, ge = n_pad - n, e_pad - e
+        into["src"][:e].copy_(src)
+        into["dst"][:e].copy_(dst)
+        if ge:
+            torch.remainder(self._ramp[:ge], ghosts, out=into["src"][e:])
+            torch.remainder(self._ramp[1:ge + 1], ghosts, out=into["dst"][e:])
+            into["src"][e:].add_(n)
+            into["dst"][e:].add_(n)
+        into["atom"][:n].copy_(atom)
+        into["atom"][n:].zero_()
+        into["bond"][:e].copy_(bond)
+        into["bond"][e:].zero_()
+        bnn = into["bnn"]
+        bnn[:b].copy_(bg.batch_num_nodes())
+        bnn[b:B].zero_()
+        bnn[B] = ghosts
+        into["labels"][:b].copy_(labels.view(-1))
+        into["labels"][b:].zero_()
+        into["gmask"][:b].fill_(1.0)
+        into["gmask"][b:].zero_()
+        into["gcount"].fill_(float(b))
+        into["mask"][:n].fill_(True)
+        into["mask"][n:].fill_(False)
+        into["count"].fill_(float(n))
+        return into
 
     def _forward_loss(self, buf):
         from mi355x_graph.graph import DGLGraph, GraphIndex
@@ -287,8 +306,9 @@ class GraphedBatchTrainer(object):
             h = len(parts) // 2
             self.step(batch_graphs(parts[:h]), labels[:h])
             return self.step(batch_graphs(parts[h:]), labels[h:])
-        pad = self._pad(bg, labels)  # host work: overlaps with the previous replay, like the loader's collate
+        pad = None
         if self.graph is None:
+            pad = self._pad(bg, labels)
             self._capture(pad)
             self.done = torch.cuda.Event()
             # pinned staging, two sets in ping-pong: the copies below are then real stream commands (a copy from pageable
@@ -303,10 +323,13 @@ class GraphedBatchTrainer(object):
         i = self.turn
         self.turn ^= 1
         self.staged[i].synchronize()  # the copies that last read this staging set (two steps ago) are done
-        for k, v in pad.items():
-            self.stage[i][k].copy_(v)
+        if pad is None:
+            self._pad(bg, labels, into=self.stage[i])  # straight into the pinned set: host work that overlaps with the previous replay
+        else:
+            for k, v in pad.items():
+                self.stage[i][k].copy_(v)
         with torch.cuda.stream(self.side):
-            for k in pad:
+            for k in self.buf:
                 self.buf[k].copy_(self.stage[i][k], non_blocking=True)
             self.staged[i].record()
             self.graph.replay()

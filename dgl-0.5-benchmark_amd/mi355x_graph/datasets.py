@@ -203,6 +203,8 @@ class SmallGraphDataset(object):
         self.labels = torch.tensor(self.labels, dtype=torch.int64)
         self.num_classes = self.num_labels = num_classes
         self.max_num_node = int(sizes.max())
+        # one storage for all graphs: batch() of any subset is then a dozen index operations (transform.GraphPool)
+        self.pool = transform.GraphPool.adopt(self.graphs)
 
     def __getitem__(self, i):
         return self.graphs[i], self.labels[i]

@@ -241,6 +241,7 @@ class Frame(MutableMapping):
         self._n = num_rows
         self._d = dict(data) if data else {}
         self._kind = kind
+        self._stamp = 0  # bumped by every assignment / deletion of a field (transform.GraphPool checks it)
 
     def __getitem__(self, k):
         return self._d[k]
@@ -252,9 +253,11 @@ class Frame(MutableMapping):
             raise DGLError("Expect number of features to match number of %ss. Got %s and %d instead."
                            % (self._kind, v.shape[0] if v.dim() else "a scalar", self._n))
         self._d[k] = v
+        self._stamp += 1
 
     def __delitem__(self, k):
         del self._d[k]
+        self._stamp += 1
 
     def __iter__(self):
         return iter(self._d)

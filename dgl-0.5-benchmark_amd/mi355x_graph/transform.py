@@ -104,12 +104,121 @@ def from_scipy(sp_mat, idtype=None, device=None):
                  num_nodes=max(sp_mat.shape), idtype=idtype, device=device)
 
 
+class GraphPool(object):
+    """The small graphs of a dataset in ONE storage: all edge lists (local node ids) and all feature rows concatenated, with offsets per
+    graph.  `GraphPool.adopt(graphs)` builds it once and rewires every graph to VIEWS of it (same DGLGraph objects, same values; in-place
+    feature writes land in the pool), so that `batch()` of any subset -- a shuffled mini-batch of 256 molecules, main_dgl_molhiv_gcn.py:163 --
+    is a dozen index operations on the pooled arrays instead of four `torch.cat`s over 256 tensors and a Python loop over the graphs:
+    3.6 ms -> 0.3 ms per batch on the host, which is what bounds the captured molhiv loop (docs/LOG_r05.md section 10).
+    A graph whose fields were reassigned after adoption (Frame._stamp), or a list that mixes pools, takes the general path."""
+
+    def __init__(self, idtype, node_off, edge_off, src, dst, ndata, edata):
+        self.idtype, self.node_off, self.edge_off = idtype, node_off, edge_off
+        self.src, self.dst, self.ndata, self.edata = src, dst, ndata, edata
+        self.members = None  # weak references to the adopted graphs (members_clean)
+
+    def members_clean(self):
+        """True when no adopted graph had a field reassigned or deleted since adoption (in-place writes go to the pool and are fine)."""
+        for ref in self.members or ():
+            g = ref()
+            if g is not None:
+                p = getattr(g, "_pool", None)
+                if p is None or p[2] != g._src_frame._stamp or p[3] != g._edge_frame._stamp:
+                    return False
+        return True
+
+    @staticmethod
+    def adopt(graphs):
+        """Pool `graphs` (homogeneous, CPU, not batched, COO available, equal idtype and feature keys / dtypes / trailing shapes) and
+        rewire them to views; returns the pool, or None when the list does not qualify (nothing is changed then)."""
+        import numpy as np
+        if len(graphs) < 2:
+            return None
+        g0 = graphs[0]
+        nkeys, ekeys = list(g0._src_frame.keys()), list(g0._edge_frame.keys())
+        for g in graphs:
+            if (type(g) is not DGLGraph or g.is_block or g._batch_num_nodes is not None or g.device.type != "cpu" or g.idtype != g0.idtype
+                    or not g._index.has_format("coo") or list(g._src_frame.keys()) != nkeys or list(g._edge_frame.keys()) != ekeys
+                    or getattr(g, "_pool", None) is not None):
+                return None
+            for k in nkeys:
+                if g._src_frame[k].dtype != g0._src_frame[k].dtype or g._src_frame[k].shape[1:] != g0._src_frame[k].shape[1:]:
+                    return None
+            for k in ekeys:
+                if g._edge_frame[k].dtype != g0._edge_frame[k].dtype or g._edge_frame[k].shape[1:] != g0._edge_frame[k].shape[1:]:
+                    return None
+        n_nodes = np.fromiter((g.number_of_nodes() for g in graphs), np.int64, len(graphs))
+        coos = [g._index.coo() for g in graphs]
+        n_edges = np.fromiter((int(s.shape[0]) for s, _ in coos), np.int64, len(graphs))
+        node_off = np.concatenate([[0], np.cumsum(n_nodes)])
+        edge_off = np.concatenate([[0], np.cumsum(n_edges)])
+        src, dst = torch.cat([s for s, _ in coos]), torch.cat([d for _, d in coos])
+        ndata = {k: torch.cat([g._src_frame[k] for g in graphs], dim=0) for k in nkeys}
+        edata = {k: torch.cat([g._edge_frame[k] for g in graphs], dim=0) for k in ekeys}
+        pool = GraphPool(g0.idtype, node_off, edge_off, src, dst, ndata, edata)
+        for i, g in enumerate(graphs):
+            a, b, ea, eb = int(node_off[i]), int(node_off[i + 1]), int(edge_off[i]), int(edge_off[i + 1])
+            g._index = GraphIndex(b - a, b - a, coo=(src[ea:eb], dst[ea:eb]))
+            for k in nkeys:
+                g._src_frame._d[k] = ndata[k][a:b]
+            for k in ekeys:
+                g._edge_frame._d[k] = edata[k][ea:eb]
+            g._pool = (pool, i, g._src_frame._stamp, g._edge_frame._stamp)
+        import weakref
+        pool.members = [weakref.ref(g) for g in graphs]
+        return pool
+
+    @staticmethod
+    def of(graphs):
+        """(pool, ids) when every graph of the list is an unmodified member of one pool, else None."""
+        import numpy as np
+        first = getattr(graphs[0], "_pool", None)
+        if first is None:
+            return None
+        pool = first[0]
+        ids = np.empty(len(graphs), np.int64)
+        for j, g in enumerate(graphs):
+            p = getattr(g, "_pool", None)
+            if p is None or p[0] is not pool or p[2] != g._src_frame._stamp or p[3] != g._edge_frame._stamp or g._batch_num_nodes is not None:
+                return None
+            ids[j] = p[1]
+        return pool, ids
+
+    def batch(self, ids):
+        import numpy as np
+
+        def ragged(starts, lens):
+            total = int(lens.sum())
+            if total == 0:
+                return torch.zeros(0, dtype=torch.int64)
+            excl = np.cumsum(lens) - lens
+            return torch.from_numpy(np.arange(total, dtype=np.int64) + np.repeat(starts - excl, lens))
+
+        n_nodes = self.node_off[ids + 1] - self.node_off[ids]
+        n_edges = self.edge_off[ids + 1] - self.edge_off[ids]
+        e_idx, n_idx = ragged(self.edge_off[ids], n_edges), ragged(self.node_off[ids], n_nodes)
+        shift = torch.from_numpy(np.repeat(np.cumsum(n_nodes) - n_nodes, n_edges)).to(self.idtype)
+        total = int(n_nodes.sum())
+        out = DGLGraph(GraphIndex(total, total, coo=(self.src.index_select(0, e_idx) + shift, self.dst.index_select(0, e_idx) + shift)))
+        out._index.ephemeral = True
+        out._batch_num_nodes = torch.from_numpy(n_nodes.copy())
+        out._batch_num_edges = torch.from_numpy(n_edges.copy())
+        for k, v in self.ndata.items():
+            out.ndata[k] = v.index_select(0, n_idx)
+        for k, v in self.edata.items():
+            out.edata[k] = v.index_select(0, e_idx)
+        return out
+
+
 def batch(graphs, ndata="__ALL__", edata="__ALL__"):
     """Block-diagonal union with node / edge id offsets; records batch_num_nodes / batch_num_edges.
     A handful of tensor ops per batch (not per graph): collation of 256 molecules must not cost more than the
-    GPU work of the iteration it feeds."""
+    GPU work of the iteration it feeds.  Members of one GraphPool are batched from the pooled arrays."""
     if len(graphs) == 0:
         raise DGLError("The input list of graphs cannot be empty.")
+    pooled = GraphPool.of(graphs)
+    if pooled is not None:
+        return pooled[0].batch(pooled[1])
     idtype, device = graphs[0].idtype, graphs[0].device
     srcs, dsts, n_nodes, n_edges, bn, be = [], [], [], [], [], []
     for g in graphs:
