@@ -722,10 +722,10 @@ def main():
             if "error" in m:
                 pred["P=%d" % m["ranks"]] = m
                 continue
-            keep = {k: m[k] for k in ("edge_cut_pct", "exchanges_per_epoch", "messages_per_epoch", "halo_bytes_per_epoch", "imbalance",
-                                      "compute_ms_max", "compute_ms_mean", "max_pair_bytes_per_exchange", "max_recv_bytes_per_exchange",
+            keep = {k: m[k] for k in m if k in ("edge_cut_pct", "exchanges_per_epoch", "messages_per_epoch", "halo_bytes_per_epoch", "imbalance",
+                                      "compute_ms_max", "compute_ms_mean", "solo_epoch_ms_max", "solo_epoch_ms_mean", "max_pair_bytes_per_exchange", "max_recv_bytes_per_exchange",
                                       "final_loss", "predicted")}
-            keep["per_rank"] = [{k: p[k] for k in ("owned_rows", "halo_rows", "local_edges", "halo_edges", "compute_ms",
+            keep["per_rank"] = [{k: p[k] for k in ("owned_rows", "halo_rows", "local_edges", "halo_edges", "compute_ms", "solo_epoch_ms",
                                                    "overlap_window_ms_per_exchange")} for p in m["per_rank"]]
             pred["P=%d" % m["ranks"]] = keep
         line["config"]["partition"] = {"predicted": pred}

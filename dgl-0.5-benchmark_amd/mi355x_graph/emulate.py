@@ -18,6 +18,18 @@ blocking collective inside a backward node would deadlock.
 
 dist.py routes its collectives here whenever the calling thread belongs to an EmuWorld (`current()`); nothing in the
 product path changes for a real process group.
+
+Two ways of timing a rank (scale_model.py reports both):
+  traced stretches   HIP events around every stretch between two collectives, one rank at a time.  Every wait() hands the token to
+                     the next rank, so a rank re-starts with an empty queue after each of its ~7 collectives: the host never runs
+                     ahead across a collective and every launch gap of a host-bound stretch counts.  CONSERVATIVE.
+  solo epochs        `record_epoch()` keeps what the rank received in one live epoch; `solo_epochs()` then runs the rank's epochs
+                     back to back, ALONE (no token passing, no events), every collective completed by a device copy of the kept payload
+                     on the compute stream -- the way an RCCL work handle's wait() orders the stream without blocking the host.  The
+                     wall clock of those epochs is what ONE rank's process does per epoch when the exchange itself costs nothing:
+                     host and device overlap as they do in a real process (the host still stops at the step's own reads: the
+                     packed exchange's sizes, loss.item()).  The payloads are one epoch old, so the numbers a solo epoch computes
+                     are not a training trajectory -- it is a timing device only.
 """
 import threading
 import time
@@ -51,6 +63,19 @@ class _Handle(object):
         return True
 
 
+class _SoloHandle(object):
+    """A collective of a solo epoch: wait() puts the payload kept by record_epoch() into `out` (stream-ordered, the host goes on)."""
+
+    def __init__(self, ctx, out):
+        self.ctx, self.out = ctx, out
+
+    def wait(self):
+        if self.out is not None:
+            self.ctx._solo_fill(self.out)
+            self.out = None
+        return True
+
+
 class EmuRank(object):
     """One rank's view of the world: the collectives dist.py needs, and the trace of what ran between them."""
 
@@ -59,6 +84,8 @@ class EmuRank(object):
         self.size = world.size
         self._seq = 0
         self.n_exchanges = 0
+        self._recording = None  # record_epoch(): what this rank received, collective after collective
+        self._solo = None       # solo_epochs(): [kept payloads, position]
         # trace: ("seg", label, start, end) stretches of this rank's own work and ("post" | "wait", kind, seq, info) points
         self.trace = None
         self._label = "other"
@@ -89,10 +116,63 @@ class EmuRank(object):
 
     def mark(self, label):
         """Names the stretch of work that starts here (dist.py: pack / owned-source / halo-source / dense / ...)."""
-        if self.trace is not None:
-            self._close()
-            self._open = self._now()
+        if self.trace is not None:  # ONE event ends the running stretch and starts the next (the apparatus is on the timeline it measures)
+            ev = self._now()
+            if self._open is not None:
+                self.trace.append(("seg", self._label, self._open, ev))
+            self._open = ev
         self._label = label
+
+    # ---- a rank's epochs alone (module docstring: "solo epochs")
+    def record_epoch(self, step):
+        """One LIVE epoch (`step()`, all ranks together as always) whose received payloads are kept: the argument of solo_epochs()."""
+        self._recording = []
+        try:
+            step()
+            return self._recording
+        finally:
+            self._recording = None
+
+    def _keep(self, t):
+        if self._recording is not None:
+            self._recording.append(t.detach().clone())
+
+    def _solo_fill(self, out):
+        kept, pos = self._solo
+        if pos >= len(kept):
+            raise EmuError("solo epoch: rank %d issues more collectives than the recorded epoch's %d" % (self.rank, len(kept)))
+        self._solo[1] = pos + 1
+        src = kept[pos]
+        if out.numel():
+            # a message whose size depends on THIS epoch's dropout mask (the gradient values of a packed exchange) has no kept
+            # counterpart of the same size: zeros of the right size -- the same bytes written
+            if src.shape == out.shape and src.dtype == out.dtype:
+                out.detach().copy_(src)
+            else:
+                out.detach().zero_()
+
+    def solo_epochs(self, step, kept, epochs, warmup=1):
+        """This rank's epochs back to back with nobody else running: ms per epoch by the wall clock (device synchronised at both
+        ends).  Call between two barriers so that the other ranks are parked."""
+        dev = self.world.device
+        sync = (lambda: torch.cuda.synchronize(dev)) if dev is not None and dev.type == "cuda" else (lambda: None)
+        trace, self.trace = self.trace, None
+        self._solo = [kept, 0]
+        try:
+            for _ in range(warmup):
+                self._solo[1] = 0
+                step()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(epochs):
+                self._solo[1] = 0
+                step()
+                if self._solo[1] != len(kept):
+                    raise EmuError("solo epoch: rank %d issued %d collectives, the recorded epoch %d" % (self.rank, self._solo[1], len(kept)))
+            sync()
+            return (time.perf_counter() - t0) * 1e3 / max(epochs, 1)
+        finally:
+            self._solo, self.trace = None, trace
 
     # ---- the two halves of every collective
     def _post(self, kind, payload, info=None):
@@ -107,9 +187,11 @@ class EmuRank(object):
             slot["data"][self.rank] = payload
             slot["count"] += 1
         if self.trace is not None:
-            self._close()
+            ev = self._now()
+            if self._open is not None:
+                self.trace.append(("seg", self._label, self._open, ev))
             self.trace.append(("post", kind, seq, info))
-            self._open = self._now()
+            self._open = ev
         return seq
 
     def _complete(self, seq):
@@ -149,6 +231,8 @@ class EmuRank(object):
         exchange, dist.SparseHalo), "gradient values" -- for the byte accounting of the scaling model."""
         self.n_exchanges += 1
         rank = self.rank
+        if self._solo is not None:
+            return _SoloHandle(self, out)
         info = {"recv_rows": list(out_splits), "row_bytes": int(out[0].numel() * out.element_size()) if out.shape[0] else
                 int(inp[0].numel() * inp.element_size()) if inp.shape[0] else 0, "tag": tag}
         seq = self._post("all_to_all", (inp, list(in_splits)), info)
@@ -163,12 +247,16 @@ class EmuRank(object):
                                    % (seq, rank, tuple(outs[p].shape), p, tuple(piece.shape)))
                 if piece.numel():
                     outs[p].copy_(piece)
+            self._keep(out)
         return _Handle(self, seq, finish)
 
     def all_to_all(self, out, inp, out_splits, in_splits):
         self.all_to_all_async(out, inp, out_splits, in_splits).wait()
 
     def all_reduce(self, t, op="sum"):
+        if self._solo is not None:
+            self._solo_fill(t)
+            return t
         seq = self._post("all_reduce", t.detach().clone(), {"bytes": int(t.numel() * t.element_size())})
         parts = self._complete(seq)
         acc = parts[0].clone()
@@ -182,10 +270,13 @@ class EmuRank(object):
             else:
                 raise EmuError("all_reduce: unsupported op %r" % (op,))
         t.detach().copy_(acc)
+        self._keep(t)
         self._release(seq)
         return t
 
     def broadcast(self, t, src=0):
+        if self._solo is not None:
+            return t
         seq = self._post("broadcast", t.detach().clone() if self.rank == src else None)
         parts = self._complete(seq)
         if self.rank != src:
@@ -194,6 +285,8 @@ class EmuRank(object):
         return t
 
     def barrier(self):
+        if self._solo is not None:
+            return
         seq = self._post("barrier", None)
         self._complete(seq)
         self._release(seq)

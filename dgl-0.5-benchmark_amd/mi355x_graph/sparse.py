@@ -1033,6 +1033,8 @@ class HipBackend(object):
         dev = self._check_dev(x2d, idx, masks, offsets)
         values = torch.empty(int(total), dtype=torch.float32, device=dev)
         n = int(masks.shape[0])
+        if int(total) == 0:  # every mask empty (a layer whose boundary rows are all zero): nothing to write, and an empty tensor has no address
+            return values
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().mgx_rows_pack_values(n, _ptr(idx), 0 if idx is None else (32 if idx.dtype == torch.int32 else 64),
                                                        int(x2d.shape[1]), _ptr(x2d), x2d.stride(0), _ptr(masks), _ptr(offsets), _ptr(values),

@@ -23,7 +23,8 @@ import torch
 LINK_RATES_GBPS = (32.0, 48.0, 64.0)  # per link and direction; see report(): MI355X xGMI is 7 links x ~153 GB/s bidirectional
 
 
-def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, warmup=2, dropout=None, progress=None, tune_dense=False):
+def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, warmup=2, dropout=None, progress=None, tune_dense=False,
+        host_profile=None, solo_extra=0, solo_clock=None):
     """Partition the graph P ways and run `warmup` + `steps` training epochs of every rank (the step of bench.py) inside an
     emulated world.  Returns a dict: partition statistics, per-rank typical-epoch stages (median over the steps), byte matrices, priced epochs."""
     import full_graph
@@ -95,7 +96,29 @@ def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, w
         lt = torch.tensor([loss], dtype=torch.float64, device=device)
         mdist.all_reduce(lt)
         torch.cuda.synchronize(device)
-        return {"stages": emulate.typical_epoch(traces), "loss": float(lt.item()), "n_own": plan.n_own, "n_halo": plan.n_halo,
+        # the same epochs with this rank ALONE on the device and every collective completed by a copy of what arrived in one recorded
+        # epoch (emulate.py, "solo epochs"): host and device overlap as in a rank's own process, no token passing, no events
+        kept = ctx.record_epoch(step)
+        ctx.barrier()
+        solo_ms = ctx.solo_epochs(step, kept, epochs=max(steps, 3), warmup=1)
+        if host_profile and rank == 0:  # experiments/prof_rank_host.py: the Python side of rank 0's solo epochs
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
+            ctx.solo_epochs(step, kept, epochs=max(steps, 3), warmup=0)
+            prof.disable()
+            prof.dump_stats(host_profile)
+        if solo_extra and rank == 0:  # experiments/solo_trace.sh: a long stretch of one rank's solo epochs for a kernel trace to look at
+            torch.cuda.synchronize(device)
+            stamp = [time.clock_gettime_ns(c) for c in (time.CLOCK_MONOTONIC, time.CLOCK_BOOTTIME, time.CLOCK_REALTIME)]
+            ms = ctx.solo_epochs(step, kept, epochs=solo_extra, warmup=0)
+            stamp += [time.clock_gettime_ns(c) for c in (time.CLOCK_MONOTONIC, time.CLOCK_BOOTTIME, time.CLOCK_REALTIME)]
+            if solo_clock:
+                with open(solo_clock, "w") as fh:
+                    fh.write(" ".join(str(v) for v in stamp) + " %d %.6f\n" % (solo_extra, ms))
+        del kept
+        ctx.barrier()
+        return {"stages": emulate.typical_epoch(traces), "loss": float(lt.item()), "solo_epoch_ms": solo_ms, "n_own": plan.n_own, "n_halo": plan.n_halo,
                 "send_rows": int(sum(plan.send_splits)), "recv_splits": list(plan.recv_splits), "local_edges": block.number_of_edges(),
                 "halo_edges": int(plan.halo.num_edges()), "train_rows": int(train_idx.numel())}
 
@@ -124,6 +147,7 @@ def summarize(res, P, D, pstats, n, num_edges):
         per_rank.append({"owned_rows": r["n_own"], "halo_rows": r["n_halo"], "send_rows": r["send_rows"],
                          "local_edges": r["local_edges"], "halo_edges": r["halo_edges"], "train_rows": r["train_rows"],
                          "compute_ms": round(sum(by_label.values()), 4),
+                         "solo_epoch_ms": None if r.get("solo_epoch_ms") is None else round(r["solo_epoch_ms"], 4),
                          "compute_ms_by_stretch": {k: round(v, 4) for k, v in sorted(by_label.items())},
                          "overlap_window_ms_per_exchange": window_ms})
     # halo byte matrix of ONE hidden-width exchange sent as DENSE rows: [receiver][sender] -- the reference point
@@ -160,16 +184,25 @@ def summarize(res, P, D, pstats, n, num_edges):
            "compute_ms_max": max(p["compute_ms"] for p in per_rank),
            "compute_ms_mean": round(sum(p["compute_ms"] for p in per_rank) / P, 4),
            "predicted": {}}
+    solo = [p["solo_epoch_ms"] for p in per_rank]
+    if all(v is not None for v in solo):
+        out["solo_epoch_ms_max"], out["solo_epoch_ms_mean"] = max(solo), round(sum(solo) / P, 4)
+    else:
+        solo = None
     for rate in LINK_RATES_GBPS:
         over = emulate.price_epoch(ranks, rate, overlap=True)
         ser = emulate.price_epoch(ranks, rate, overlap=False)
         out["predicted"]["%g GB/s per link" % rate] = {
             "epoch_ms_overlapped": round(over["epoch_ms"], 3), "epoch_ms_not_overlapped": round(ser["epoch_ms"], 3),
+            # a rank's solo epoch (exchange free of charge) + what the lock-step replay leaves exposed for that rank
+            "epoch_ms_solo_plus_exposed": None if solo is None else round(max(solo[r] + sum(x[r]["exposed"] for x in over["exchanges"])
+                                                                              for r in range(P)), 3),
             "exposed_exchange_ms_worst_rank": round(max(sum(x[r]["exposed"] for x in over["exchanges"]) for r in range(P)), 3),
             "exchange_ms_per_exchange_worst_rank": [round(max(x[r]["done"] - x[r]["posted"] for r in range(P)), 3)
                                                     for x in over["exchanges"]]}
     out["predicted"]["no exchange cost (compute only, lock step)"] = {
-        "epoch_ms_overlapped": round(emulate.price_epoch(ranks, 1e9, latency_us=0.0, allreduce_us=0.0)["epoch_ms"], 3)}
+        "epoch_ms_overlapped": round(emulate.price_epoch(ranks, 1e9, latency_us=0.0, allreduce_us=0.0)["epoch_ms"], 3),
+        "epoch_ms_solo_plus_exposed": None if solo is None else round(max(solo), 3)}
     out["stages_rank0"] = [{"kind": st["kind"], "pre_ms": round(_stage_ms(st, "pre"), 4),
                             "window_ms": round(_stage_ms(st, "window"), 4)} for st in ranks[0]]
     return out
@@ -190,11 +223,12 @@ def report(models, one_gpu_ms=None, header=""):
         lines.append("== P = %d   edge cut %.2f %%   %d exchanges / epoch   final loss %.6f" % (P, m["edge_cut_pct"], m["exchanges_per_epoch"], m["final_loss"]))
         lines.append("   imbalance (max / mean): owned rows %.3f, in-edges %.3f, compute %.3f"
                      % (m["imbalance"]["owned_rows_max_over_mean"], m["imbalance"]["in_edges_max_over_mean"], m["imbalance"]["compute_ms_max_over_mean"]))
-        lines.append("   rank  owned rows  halo rows  send rows   in-edges  halo edges  compute ms  windows ms (per exchange)")
+        lines.append("   rank  owned rows  halo rows  send rows   in-edges  halo edges  compute ms  solo epoch ms  windows ms (per exchange)")
         for r, p in enumerate(m["per_rank"]):
-            lines.append("   %4d  %10d %10d %10d %10d %11d  %10.3f  %s" % (r, p["owned_rows"], p["halo_rows"], p["send_rows"], p["local_edges"],
-                                                                          p["halo_edges"], p["compute_ms"],
-                                                                          " ".join("%.3f" % w for w in p["overlap_window_ms_per_exchange"])))
+            lines.append("   %4d  %10d %10d %10d %10d %11d  %10.3f  %13s  %s" % (r, p["owned_rows"], p["halo_rows"], p["send_rows"], p["local_edges"],
+                                                                                p["halo_edges"], p["compute_ms"],
+                                                                                "-" if p.get("solo_epoch_ms") is None else "%.3f" % p["solo_epoch_ms"],
+                                                                                " ".join("%.3f" % w for w in p["overlap_window_ms_per_exchange"])))
         labels = sorted({k for p in m["per_rank"] for k in p["compute_ms_by_stretch"]})
         lines.append("   compute by stretch, ms (mean over ranks / worst rank):")
         for lab in labels:
@@ -228,4 +262,7 @@ def report(models, one_gpu_ms=None, header=""):
             else:
                 sp = (" speed-up %.2fx" % (one_gpu_ms / v["epoch_ms_overlapped"])) if one_gpu_ms else ""
                 lines.append("      %-24s %7.3f%s" % (k, v["epoch_ms_overlapped"], sp))
+            if v.get("epoch_ms_solo_plus_exposed") is not None:
+                sp = (" speed-up %.2fx" % (one_gpu_ms / v["epoch_ms_solo_plus_exposed"])) if one_gpu_ms else ""
+                lines.append("      %-24s solo epoch of the slowest rank + its exposed exchange %7.3f%s" % ("", v["epoch_ms_solo_plus_exposed"], sp))
     return "\n".join(lines) + "\n"

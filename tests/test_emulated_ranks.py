@@ -129,6 +129,51 @@ def test_trace_and_priced_epoch():
     assert emulate.price_epoch(tl, 64.0)["epoch_ms"] > 0
 
 
+def test_solo_epochs_replay_the_recorded_payloads():
+    """record_epoch() keeps what a rank received; solo_epochs() runs the rank's epochs alone with every collective completed from the
+    kept payloads (same sizes: copied; another size: zeros), counts the collectives, and leaves the live world usable afterwards."""
+    seen = {}
+
+    def body(rank):
+        ctx = emulate.current()
+        comm = mdist._Comm()
+        state = {"recv": None, "red": None, "odd": None, "extra": False}
+
+        def step():
+            send = torch.full((2, 4), float(rank + 1))
+            recv = torch.zeros((2, 4))
+            w = comm.all_to_all_async(recv, send, [2, 0] if rank else [0, 2], [2, 0] if rank else [0, 2])
+            w.wait()
+            red = torch.full((3,), float(rank + 1))
+            mdist.all_reduce(red)
+            n = 5 if ctx._solo is not None else 3          # a message whose size changes from epoch to epoch
+            odd = torch.ones((n, 2))
+            comm.all_to_all_async(odd, torch.ones((n, 2)), [n, 0] if rank else [0, n], [n, 0] if rank else [0, n]).wait()
+            if state["extra"]:
+                mdist.all_reduce(torch.ones(1))
+            state.update(recv=recv, red=red, odd=odd)
+
+        kept = ctx.record_epoch(step)
+        assert len(kept) == 3
+        live = (state["recv"].clone(), state["red"].clone())
+        ctx.barrier()
+        ms = ctx.solo_epochs(step, kept, epochs=2, warmup=1)
+        assert ms >= 0 and ctx._solo is None
+        assert torch.equal(state["recv"], live[0]) and torch.equal(state["red"], live[1])   # the kept payloads
+        assert state["odd"].shape == (5, 2) and float(state["odd"].abs().sum()) == 0.0      # no counterpart of that size: zeros
+        state["extra"] = True
+        with pytest.raises(emulate.EmuError):
+            ctx.solo_epochs(step, kept, epochs=1, warmup=0)                                  # one collective more than recorded
+        state["extra"] = False
+        ctx.barrier()
+        step()                                                                                # the live world still works
+        seen[rank] = float(state["recv"][0, 0])
+        return ms
+
+    emulate.EmuWorld(2).run(body)
+    assert seen == {0: 2.0, 1: 1.0}
+
+
 @pytest.mark.parametrize("world", [4, 8])
 def test_emulated_ring_partition_matches_single_process_on_cpu(world):
     """The same ring problem tests/test_dist.py runs over gloo processes, as threads of one process."""

@@ -121,6 +121,19 @@ def test_empty_and_unsupported_shapes():
     masks, counts = be.rows_pack_count(x, None)
     assert masks.shape == (0, 1) and counts.numel() == 0
     assert be.rows_unpack(masks, torch.zeros(1, dtype=torch.int64, device=dev), torch.empty(0, device=dev), 64).shape == (0, 64)
+    # rows that are all zero (a dead layer's boundary rows): empty masks, an EMPTY value vector -- packed, unpacked and added back
+    z = torch.zeros(37, 64, device=dev)
+    masks, counts = be.rows_pack_count(z, None)
+    assert int(counts.sum()) == 0 and int((masks != 0).sum()) == 0
+    off = torch.zeros(38, dtype=torch.int64, device=dev)
+    vals = be.rows_pack_values(z, None, masks, off, 0)
+    assert vals.numel() == 0
+    assert torch.equal(be.rows_unpack(masks, off, vals, 64), z)
+    csr = sparse.coo_to_csr(5, 37, torch.arange(37, device=dev, dtype=torch.int32) % 5, torch.arange(37, device=dev, dtype=torch.int32))
+    base = torch.rand(5, 64, device=dev)
+    out = base.clone()
+    be.rows_unpack_add_csr(csr, masks, off, vals, out)
+    assert torch.equal(out, base)
     assert not be.rows_pack_supported(torch.rand(4, 6, device=dev)) and not be.rows_pack_supported(torch.rand(4, 260, device=dev))
     with pytest.raises(_lib.DGLError):
         be.rows_pack_count(torch.rand(4, 6, device=dev), None)
