@@ -48,7 +48,7 @@ def _pooled_source(dataset):
 class GraphDataLoader(DataLoader):
     """dgl.dataloading.GraphDataLoader.  For datasets whose graphs live in one GraphPool the loader iterates over INDICES and collates
     from the pooled arrays (no per-sample __getitem__, no per-graph Python work): same batches, same order for the same seed, as the
-    general path -- `tests/test_graphed_batches.py` compares them."""
+    general path -- `tests/test_graph_pool.py` compares them."""
 
     def __init__(self, dataset, collate_fn=None, **kwargs):
         src = _pooled_source(dataset) if collate_fn is None else None

@@ -581,7 +581,7 @@ class DistSageMeanCatFn(torch.autograd.Function):
     `static_cache`: DistGraph.set_static_input's declaration for the layer-1 input (its halo rows stay resident)."""
 
     @staticmethod
-    def forward(ctx, plan, comm, cat, h, w_self, w_neigh, bias, static_cache, sparse_exchange=False):
+    def forward(ctx, plan, comm, cat, h, w_self, w_neigh, bias, static_cache, sparse_exchange=False, act=None):
         be = sparse.backend_for(h)
         comm.mark("pack")
         sparse_exchange = sparse_exchange and static_cache is None  # (decided by the caller on the tensor it holds: DistGraph.sage_mean_layer)
@@ -618,22 +618,43 @@ class DistSageMeanCatFn(torch.autograd.Function):
             be.spmm_copy_u_strided(plan.halo.csc(), "sum", recv, cat.right, accumulate=True, dst_scale=plan.inv_deg)
         ctx.plan, ctx.comm, ctx.cat, ctx.generation = plan, comm, cat, cat.generation
         ctx.halo_x = halo_x
-        ctx.save_for_backward(w_self, w_neigh)
         comm.mark("dense")
         from . import ops
-        return ops._rows_linear(be, cat.buf, torch.cat([w_self, w_neigh], dim=1), bias)
+        wcat = torch.cat([w_self, w_neigh], dim=1)
+        if act is not None:
+            # dropout(relu(.)) in the GEMM's epilogue, written into the next layer's left half (ops.SageMeanCatFn's fused form: same
+            # position in the random stream as ops.relu_dropout would take, same bits); the N x out pre-activation is never stored
+            p, into = act
+            seed = torch.initial_seed() & (2 ** 64 - 1)
+            offset = (ops.ReluDropout._calls * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
+            ops.ReluDropout._calls += 1
+            out = None if into is None else into.t
+            fused = be.rows_gemm_relu_dropout(cat.buf, wcat, True, bias, float(p), seed, offset, out=out)
+            y, mask = fused if fused is not None else be.relu_dropout_fwd(ops._rows_linear(be, cat.buf, wcat, bias), float(p), seed, offset, out=out)
+            ctx.save_for_backward(w_self, w_neigh, mask)
+            ctx.p = float(p)
+            return y
+        ctx.save_for_backward(w_self, w_neigh)
+        ctx.p = None
+        return ops._rows_linear(be, cat.buf, wcat, bias)
 
     @staticmethod
     @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy):
         from . import ops
-        w_self, w_neigh = ctx.saved_tensors
         plan, comm, cat = ctx.plan, ctx.comm, ctx.cat
         if cat.generation != ctx.generation:
             raise DGLError("SAGEConv: a later forward pass overwrote the [h | neigh] buffer this backward pass needs")
+        be = sparse.backend_for(dy)
+        if ctx.p is not None:
+            w_self, w_neigh, mask = ctx.saved_tensors
+            if not dy.is_contiguous() and not (hasattr(be, "_row_strided") and be._row_strided(dy)):
+                dy = dy.contiguous()
+            dy = be.relu_dropout_bwd(dy, mask, ctx.p)  # the gradient of the pre-activation, as ops.ReluDropout.backward forms it
+        else:
+            w_self, w_neigh = ctx.saved_tensors
         dy = dy.contiguous()
         need = ctx.needs_input_grad
-        be = sparse.backend_for(dy)
         K = cat.K
         dh = None
         if need[3]:
@@ -674,7 +695,7 @@ class DistSageMeanCatFn(torch.autograd.Function):
                     be.spmm_copy_u_strided(plan.return_csr(), "sum", back, dh_own, accumulate=True)
             dh = dh_own
         comm.mark("dense")
-        return None, None, None, dh, dws, dwn, db, None, None
+        return None, None, None, dh, dws, dwn, db, None, None, None
 
 
 class DistSageProjectFirstFn(torch.autograd.Function):
@@ -897,6 +918,30 @@ class DistGraph(DGLGraph):
             return None
         static = self._static_halo if self._static_halo.get("tensor") is h else None
         return DistSageMeanCatFn.apply(plan, self._comm, cat, h, w_self, w_neigh, bias, static, static is None and sparse_halo_applies(h, plan))
+
+    def sage_mean_layer_act(self, h, w_self, w_neigh, bias, cat, p, out):
+        """dropout(relu(sage_mean_layer(...)), p) as ONE node (ops.sage_mean_layer_act dispatches here): the layer's GEMM applies the
+        activation in its epilogue and writes `out` -- the next layer's left half --, tagged as ops.relu_dropout tags its result, so the
+        next layer's halo exchange takes the packed form.  None when that form does not apply (the caller composes the two)."""
+        from . import ops
+        plan = self._plan
+        be = sparse.backend_for(h) if h.is_cuda or h.device.type in sparse._BACKENDS else None
+        if (be is None or not hasattr(be, "rows_gemm_relu_dropout") or not config.SAGE_FUSED_ACT or not config.ROWS_GEMM or cat is None
+                or not (0.0 < p < 1.0) or ops.capture_path() or w_self.shape[0] % 4 or h.shape[0] < ops._ROWS_GEMM_MIN
+                or not be.rows_gemm_supported(2 * cat.K, w_self.shape[0], cat.buf.stride(0))
+                or (bias is not None and w_self.shape[0] > be.COLUMN_SUM_MAX)
+                or (out is not None and (out.shape != (h.shape[0], w_self.shape[0]) or out.stride(1) != 1 or out.stride(0) % 4
+                                         or out.data_ptr() % 16 or out.requires_grad))):
+            return None
+        if (plan.loc is None or h.dim() != 2 or h.dtype != torch.float32 or cat.K != h.shape[1] or h.shape[0] != plan.n_own
+                or cat.buf.shape[0] != plan.n_own or h.shape[1] % 4 or plan.loc.csc().indptr.dtype != torch.int32
+                or not torch.is_grad_enabled() or not config.SAGE_CAT or not config.SAGE_FUSED_LAYER
+                or plan.return_csr().num_cols * h.shape[1] * 4 >= (1 << 32) or (plan.n_own + plan.n_halo) * 2 * h.shape[1] * 4 >= (1 << 32)):
+            return None
+        static = self._static_halo if self._static_halo.get("tensor") is h else None
+        y = DistSageMeanCatFn.apply(plan, self._comm, cat, h, w_self, w_neigh, bias, static, static is None and sparse_halo_applies(h, plan),
+                                    (float(p), None if out is None else ops._Into(out)))
+        return ops._structural_zeros(y)
 
 
 # ----------------------------------------------------------------------------- training helpers

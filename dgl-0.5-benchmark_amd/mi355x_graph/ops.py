@@ -1077,6 +1077,8 @@ def sage_mean_layer_act(g, h, w_self, w_neigh, bias, cat, p, out):
     """dropout(relu(SAGEConv(g, h)), p) as ONE node whose GEMM applies the activation in its epilogue and writes `out` (the left half of
     the next layer's CatBuffer, or None for a new matrix): bit for bit ops.relu_dropout(ops.sage_mean_layer(...), out=out), one pass
     over the N x out pre-activation less each way.  None when that form does not apply (the caller composes the two)."""
+    if hasattr(g, "sage_mean_layer_act"):  # dist.DistGraph: the same fused layer with the halo exchange inside
+        return g.sage_mean_layer_act(h, w_self, w_neigh, bias, cat, p, out)
     if (not config.SAGE_FUSED_ACT or not config.ROWS_GEMM or type(g) is not DGLGraph or cat is None or capture_path()
             or not (0.0 < p < 1.0) or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda or h.device.type not in sparse._BACKENDS
             or not torch.is_grad_enabled() or g.is_block or g.number_of_src_nodes() != g.number_of_dst_nodes()

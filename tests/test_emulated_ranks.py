@@ -320,6 +320,71 @@ def test_every_rank_of_a_partition_on_the_hip_path_matches_one_gpu(world):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_fused_activation_on_a_partition_is_its_composition(monkeypatch):
+    """DistGraph.sage_mean_layer_act (relu + dropout in the layer GEMM's epilogue, written into the next layer's buffer, tagged for the
+    packed halo exchange) against the composition it stands for -- the layer, then ops.relu_dropout -- with REAL dropout: the same
+    position in the random stream, so the same bits: losses and every gradient of every rank are equal."""
+    import full_graph
+    from mi355x_graph import config as mgx_config, ops
+    dev = torch.device("cuda:0")
+    world = 4
+    n, src, dst, feats, labels, train = _products_like(dev)
+    total_train = float(train.sum())
+    assign, _ = mdist.partition_nodes(src, dst, n, world)
+    parts = [mdist.build_local_partition(src, dst, n, assign, r, world) for r in range(world)]
+    monkeypatch.setattr(ops, "_ROWS_GEMM_MIN", 0)      # the partitions of the test graph are below the tall-matrix threshold
+    taken = {"act": 0}
+    orig = mdist.DistSageMeanCatFn.forward
+
+    def counting(ctx, *a):
+        taken["act"] += 1 if len(a) > 9 and a[9] is not None else 0
+        return orig(ctx, *a)
+
+    def body(rank):
+        block, plan, own = parts[rank]
+        g = mdist.DistGraph(block, plan)
+        torch.manual_seed(77)
+        model = full_graph.GraphSAGE(100, 64, 47, 3, 0.5, False, True).to(dev)
+        model.rows_are_distinct = True
+        mdist.broadcast_parameters(model)
+        own_c = own.cpu()
+        x, y = feats[own_c].to(dev), labels[own_c].to(dev)
+        g.set_static_input(x)
+        idx = torch.nonzero(train[own_c]).flatten().to(dev)
+        bucket = mdist.GradBucket(model)
+        model.train()
+        losses = []
+        for _ in range(2):
+            bucket.zero()
+            loss = ops.nll_sum(model(g, x, rows=idx), y[idx]) / total_train
+            loss.backward()
+            bucket.all_reduce()
+            losses.append(float(loss))
+        return losses, [p.grad.clone() for p in model.parameters()]
+
+    results = {}
+    for fused in (True, False):
+        monkeypatch.setattr(mgx_config, "SAGE_FUSED_ACT", fused)
+        ops.ReluDropout._calls = 0
+        torch.manual_seed(5)
+        taken["act"] = 0
+        packed0 = list(mdist.SPARSE_EXCHANGES)
+        mdist.DistSageMeanCatFn.forward = staticmethod(counting)
+        try:
+            results[fused] = emulate.EmuWorld(world, dev).run(body)
+        finally:
+            mdist.DistSageMeanCatFn.forward = staticmethod(orig)
+        assert taken["act"] == (world * 2 * 2 if fused else 0)        # both hidden layers of every rank, both passes
+        # either way the hidden layers' inputs crossed as bitmaps + non-zeros: the fused form tags its output as ops.relu_dropout does
+        assert [a - b for a, b in zip(mdist.SPARSE_EXCHANGES, packed0)] == [world * 2 * 2, world * 2 * 2]
+    for (la, ga), (lb, gb) in zip(results[True], results[False]):
+        assert la == lb
+        for a, b in zip(ga, gb):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
 @pytest.mark.timeout(900)
 def test_bench_emulate_ranks_line_carries_the_scaling_model(tmp_path):
     """`python bench.py --emulate-ranks 2,4` end to end on a 2 % graph: the N = 1 line gains config.partition.predicted with, per P, the
