@@ -109,7 +109,7 @@ class GraphPool(object):
     graph.  `GraphPool.adopt(graphs)` builds it once and rewires every graph to VIEWS of it (same DGLGraph objects, same values; in-place
     feature writes land in the pool), so that `batch()` of any subset -- a shuffled mini-batch of 256 molecules, main_dgl_molhiv_gcn.py:163 --
     is a dozen index operations on the pooled arrays instead of four `torch.cat`s over 256 tensors and a Python loop over the graphs:
-    3.6 ms -> 0.3 ms per batch on the host, which is what bounds the captured molhiv loop (docs/LOG_r05.md section 10).
+    3.6 ms -> 0.3 ms per batch on the host; the eager molhiv loop 0.91 -> 0.70 s per epoch (docs/LOG_r05.md section 9a).
     A graph whose fields were reassigned after adoption (Frame._stamp), or a list that mixes pools, takes the general path."""
 
     def __init__(self, idtype, node_off, edge_off, src, dst, ndata, edata):

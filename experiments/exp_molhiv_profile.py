@@ -2,6 +2,7 @@
 import cProfile, pstats, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dgl-0.5-benchmark_amd"))
 import torch
+torch.set_num_threads(4)
 import torch.nn as nn
 import graph_classification as gc
 from mi355x_graph.datasets import molhiv_like
@@ -24,3 +25,5 @@ pr = cProfile.Profile(); pr.enable()
 gc.train_epoch(model, dev, loader, opt, loss_fn); torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(40)
+print("== by cumulative time")
+st.sort_stats("cumulative").print_stats(70)

@@ -35,7 +35,8 @@ def run(clock, P, epochs, scale):
 
 def read(out, clock):
     f = sorted(glob.glob(out + "/**/*kernel_trace.csv", recursive=True))[-1]
-    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f)))
+    ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", ""))
+                for r in csv.DictReader(open(f)))
     vals = open(clock).read().split()
     stamps, epochs, ms = [int(v) for v in vals[:6]], int(vals[6]), float(vals[7])
     lo, hi = ks[0][0], ks[-1][1]
