@@ -717,6 +717,10 @@ def main():
             torch.cuda.empty_cache()
         pred = {"kind": "MODEL, not a multi-GPU measurement: every rank's device time measured on this GPU (mi355x_graph/emulate.py), "
                         "exchanges priced per xGMI link (scale_model.py)",
+                "reading": "per P and link rate: epoch_ms_overlapped = every stretch between two collectives timed by HIP events, one rank at a "
+                           "time (the host never runs ahead across a collective: conservative, sensitive to the host's launch speed); "
+                           "epoch_ms_solo_plus_exposed = the slowest rank's epochs run back to back alone with recorded payloads "
+                           "(solo_epoch_ms: what one rank's process does per epoch when the exchange is free) + that rank's exposed exchange",
                 "epoch_ms_1gpu_measured": round(epoch * 1e3, 3)}
         for m in models:
             if "error" in m:

@@ -9,11 +9,13 @@ work between collectives (HIP events) and the rows every exchange moves between 
 replays the ranks in lock step with each exchange priced at a stated per-link rate: slice q -> r on its own xGMI link, full
 duplex, startable when both ranks have posted.
 
-What the model does NOT contain: RCCL's copy kernels competing with the aggregation for CUs and HBM during the window.  What it DOES
-contain: the launch gaps of a rank whose host is slower than its device work -- a stretch is the time between two events on the
-rank's stream, idle gaps included; at P = 8 they are ~1 ms of a rank's 4.3 ms (docs/LOG_r04.md section 19; one Python thread per
-rank here as in a real run).
+What the model does NOT contain: RCCL's copy kernels competing with the aggregation for CUs and HBM during the window, and the host cost
+of the RCCL calls themselves.  Two timings of a rank are reported (mi355x_graph/emulate.py's docstring): the traced stretches -- the time
+between two events on the rank's stream, idle gaps included, with the host starting from an empty queue after every collective:
+conservative, and as sensitive to the host's launch speed as a host-bound stretch is -- and the rank's SOLO epochs, run back to back with
+recorded payloads: a rank at P = 8 is then device-bound (busy 4.3 of 4.8 ms under the profiler, docs/LOG_r05.md section 9b).
 """
+import gc
 import os
 import tempfile
 import time
@@ -123,7 +125,12 @@ def run(device, src, dst, n, feats, labels, train_mask, cfg, spec, P, steps=5, w
                 "halo_edges": int(plan.halo.num_edges()), "train_rows": int(train_idx.numel())}
 
     t0 = time.perf_counter()
-    res = emulate.EmuWorld(P, device).run(rank_main)
+    gc.collect()
+    gc.disable()  # a collection inside a traced stretch is a millisecond of "device time" for whichever rank it hits (bench.py does the same)
+    try:
+        res = emulate.EmuWorld(P, device).run(rank_main)
+    finally:
+        gc.enable()
     say("P=%d: %d + %d epochs of every rank (%.1f s)" % (P, warmup, steps, time.perf_counter() - t0))
     return summarize(res, P, cfg["hidden"], pstats, n, int(src.shape[0]))
 

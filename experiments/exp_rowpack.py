@@ -59,3 +59,19 @@ ret = sparse.coo_to_csr(n_own, S, idx, torch.arange(S, dtype=torch.int32, device
 dh = torch.zeros(n_own, D, device=dev)
 print("%-58s %8.1f" % ("rows_unpack_add_csr (packed rows into their owners)", timed(lambda: be.rows_unpack_add_csr(ret, masks, off, vals, dh))))
 print("%-58s %8.1f" % ("  against: copy_u over return_csr of the dense rows", timed(lambda: be.spmm_copy_u_strided(ret, "sum", dense, dh, accumulate=True))))
+
+# ---- the halo-SOURCE aggregation straight from the packed rows (round 5, section 9b: would it pay to skip the unpack?): 310 k owned
+# rows with ~11 halo in-edges each, sources uniformly random among the 1 M received rows -- the shape of a P = 8 rank's halo CSC
+E = 3_400_000
+hd = torch.randint(0, n_own, (E,), device=dev, dtype=torch.int32)
+hs = torch.randint(0, S, (E,), device=dev, dtype=torch.int32)
+halo = sparse.coo_to_csr(n_own, S, hd, hs)
+out = torch.zeros(n_own, 2 * D, device=dev)[:, D:]
+inv = torch.rand(n_own, device=dev)
+t_un = timed(lambda: be.rows_unpack(masks, off, vals, D, out=dense))
+t_ag = timed(lambda: be.spmm_copy_u_strided(halo, "sum", dense, out, accumulate=True, dst_scale=inv))
+t_pk = timed(lambda: be.rows_unpack_add_csr(halo, masks, off, vals, out))
+print("# halo-source aggregation, %d edges into %d rows from %d received rows" % (E, n_own, S))
+print("%-58s %8.1f" % ("rows_unpack + copy_u over the dense rows (now)", t_un + t_ag))
+print("%-58s %8.1f" % ("  of which the aggregation", t_ag))
+print("%-58s %8.1f" % ("rows_unpack_add_csr over the halo CSC (no 1/deg yet)", t_pk))

@@ -28,4 +28,10 @@ cp $R/profiles/${TAG}_*kernel_stats.txt $R/profiles/${TAG}_pmc_summary.txt $O/ 2
 python3 $R/dgl-0.5-benchmark_amd/generate_result.py --out $O/${TAG}_generate_result.csv > $O/${TAG}_generate_result.txt 2>&1
 python3 $R/bench.py --emulate-ranks 2,4,8 --steps 10 --warmup 3 --report $O/${TAG}_scale_model.txt > $O/${TAG}_emu_bench_line.json 2> $O/${TAG}_emu_bench_line.err
 python3 $R/bench.py --steps 10 --warmup 3 > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench_line.err
+# one rank's solo epochs under the kernel trace (device-busy share, kernels, gaps) and the Python side of the same epochs
+cd $R
+bash experiments/solo_trace.sh 8 100 > /dev/null 2>&1; cp $O/solo_trace_P8.txt $O/${TAG}_solo_trace_P8.txt
+bash experiments/solo_trace.sh 2 40 > /dev/null 2>&1; cp $O/solo_trace_P2.txt $O/${TAG}_solo_trace_P2.txt
+python3 experiments/prof_rank_host.py 1.0 8 10 > $O/${TAG}_rank_host_profile.txt 2>&1
+python3 experiments/exp_rowpack.py > $O/${TAG}_rowpack.txt 2>/dev/null
 tail -c 600 $O/${TAG}_bench_line.json
