@@ -947,6 +947,14 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
   else launch_fast_v<Idx, 1, MODE>(a, nnz, s);
 }
 
+#include "spmm_slots.inc"
+static bool try_spmm_slots(const SpmmFastArgs<int32_t>& a, const void* slots, hipStream_t s) {
+  if (!slots || a.short_rows || !spmm_slots_eligible(a)) return false;
+  launch_spmm_slots(a, slots, s);
+  return true;
+}
+static bool try_spmm_slots(const SpmmFastArgs<int64_t>&, const void*, hipStream_t) { return false; }
+
 constexpr int kSpmmPartialPlan = 1 << 30;  // internal flag bit: the plan is one part of a two-part plan and need not cover every row
 
 template <typename Idx>
@@ -954,7 +962,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
                          int64_t u_len, int64_t e_len, int64_t out_len, const int64_t* u_off,
                          const int64_t* e_off, const float* src_scale, const float* dst_scale, float* out,
                          void* arg_u, void* arg_e, hipStream_t s, const uint32_t* src_bits = nullptr, int64_t u_stride = 0,
-                         int64_t out_stride = 0) {
+                         int64_t out_stride = 0, const void* slots = nullptr) {
   const int64_t n_rows = csr->num_rows;
   const int accumulate = (flag_bits & MGX_SPMM_ACCUMULATE) ? 1 : 0;
   if (n_rows == 0 || out_len == 0) return MGX_OK;
@@ -968,11 +976,12 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     mgx_spmm_plan head = *plan;
     head.rest = nullptr;
     int32_t st = spmm_impl<Idx>(csr, &head, partial_ws, flag_bits | kSpmmPartialPlan, op, reduce, U, E, u_len, e_len, out_len, u_off, e_off,
-                                src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride);
+                                src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride, slots);
     if (st != MGX_OK) return st;
     const char* head_kernel = mgx_last_spmm_kernel();
     st = spmm_impl<Idx>(csr, plan->rest, partial_ws, (flag_bits & ~MGX_SPMM_SHORT_ROWS) | kSpmmPartialPlan, op, reduce, U, E, u_len, e_len,
-                        out_len, u_off, e_off, src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride);
+                        out_len, u_off, e_off, src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride, slots);
+    if (slots && st == MGX_OK) return st;  // (the name of the family that walked `rest` -- "slots" or not -- is what a caller of the packed form asks for)
     note_spmm_kernel(head_kernel);  // the family that walked the short items (the bulk of such a plan)
     return st;
   }
@@ -1026,6 +1035,10 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
                         !src_bits;
         if (!ok) MGX_UNSUPPORTED("mgx_spmm_copy_u_strided: needs int32 ids, D and both strides multiples of 4, 16-byte aligned "
                                  "pointers and a gathered matrix under 4 GiB");
+      }
+      if (try_spmm_slots(a, slots, s)) {  // mostly-zero rows as 128-byte slots (spmm_slots.inc): the wave-per-item part only
+        MGX_CHECK_LAUNCH();
+        return fixup();
       }
       launch_fast<Idx, MODE_COPY_LHS>(a, csr->nnz, s);
       MGX_CHECK_LAUNCH();
@@ -1173,6 +1186,44 @@ extern "C" int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_pl
   return spmm_impl<int32_t>(csr, plan, partial_ws, flags & (MGX_SPMM_ACCUMULATE | MGX_SPMM_SHORT_ROWS), MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0,
                             D, nullptr, nullptr, nullptr, dst_scale, out, nullptr, nullptr, (hipStream_t)stream, nullptr, u_stride,
                             out_stride);
+}
+
+extern "C" int32_t mgx_rows_slots_pack(int64_t n, int64_t D, const float* x, int64_t x_stride, void* slots, int64_t* overflow_rows, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(n >= 0 && x_stride >= D, "mgx_rows_slots_pack: negative size or stride below D");
+  if (D != 64 || x_stride % 4 != 0 || (uintptr_t)x % 16 != 0 || (uintptr_t)slots % 16 != 0)
+    MGX_UNSUPPORTED("mgx_rows_slots_pack: rows of exactly 64 columns, stride a multiple of 4, 16-byte aligned pointers");
+  if (n == 0) return MGX_OK;
+  MGX_CHECK_ARG(x && slots, "mgx_rows_slots_pack: NULL pointer");
+  int64_t blocks = (n + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(rows_slots_pack_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, n, x, x_stride, (uint32_t*)slots,
+                     (unsigned long long*)overflow_rows);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_spmm_copy_u_slots(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t reduce, const float* ufeat, int64_t D,
+                                         int64_t u_stride, const void* slots, const float* dst_scale, float* out, int64_t out_stride,
+                                         float* partial_ws, int32_t flags, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(csr != nullptr, "mgx_spmm_copy_u_slots: csr is NULL");
+  MGX_CHECK_ARG(csr->num_rows >= 0 && csr->nnz >= 0, "mgx_spmm_copy_u_slots: negative sizes");
+  MGX_CHECK_ARG(csr->num_rows == 0 || csr->indptr != nullptr, "mgx_spmm_copy_u_slots: indptr is NULL");
+  MGX_CHECK_ARG(csr->nnz == 0 || csr->indices != nullptr, "mgx_spmm_copy_u_slots: indices is NULL");
+  MGX_CHECK_ARG(reduce == MGX_REDUCE_SUM || reduce == MGX_REDUCE_MEAN, "mgx_spmm_copy_u_slots: SUM or MEAN only, got %d", reduce);
+  MGX_CHECK_ARG(u_stride >= D && out_stride >= D, "mgx_spmm_copy_u_slots: strides must be >= D");
+  MGX_CHECK_ARG((ufeat != nullptr && slots != nullptr) || csr->num_cols == 0, "mgx_spmm_copy_u_slots: ufeat / slots is NULL");
+  MGX_CHECK_ARG(out != nullptr || csr->num_rows == 0, "mgx_spmm_copy_u_slots: out is NULL");
+  if (csr->idx_bits != 32 || D != 64 || u_stride % 4 != 0 || out_stride % 4 != 0 || (uintptr_t)ufeat % 16 != 0 || (uintptr_t)out % 16 != 0 ||
+      (uintptr_t)slots % 16 != 0 || csr->num_cols * (int64_t)128 >= (int64_t(1) << 32) || csr->num_cols * u_stride * 4 >= (int64_t(1) << 32))
+    MGX_UNSUPPORTED("mgx_spmm_copy_u_slots: int32 graphs, 64 columns, strides multiples of 4, 16-byte aligned operands below 4 GiB");
+  // u_stride / out_stride equal to D are passed as such: spmm_impl treats 0 as "contiguous"
+  return spmm_impl<int32_t>(csr, plan, partial_ws, flags & (MGX_SPMM_ACCUMULATE | MGX_SPMM_SHORT_ROWS), MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0,
+                            D, nullptr, nullptr, nullptr, dst_scale, out, nullptr, nullptr, (hipStream_t)stream, nullptr, u_stride,
+                            out_stride, slots);
 }
 
 extern "C" int32_t mgx_spmm_csr(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t op, int32_t reduce,

@@ -44,3 +44,8 @@ SPARSE_GRAD = False        # skip all-zero rows of a gradient in the reversed ag
 SPARSE_GRAD_MIN_NNZ = 2_000_000
 WIDE_PAD = True            # rows wider than 256 columns on dense graphs: line-padded passes
 WIDE_PAD_MIN_NNZ = 1 << 20
+
+# ---- mostly-zero rows as 128-byte slots (ops._packed_rows, csrc/spmm_slots.inc)
+PACKED_GATHER = True       # the forward aggregation of a [N, 64] relu + dropout output gathers one 128-byte slot per edge instead of the 256-byte row
+PACKED_GATHER_MIN_NNZ = 4_000_000    # smaller graphs: the pack pass and a second launch cost more than the gathers they halve
+PACKED_GATHER_MAX_OVERFLOW = 0.10    # share of rows with more than 24 non-zeros (read from the dense matrix) above which the dense kernels are used

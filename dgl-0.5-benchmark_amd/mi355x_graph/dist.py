@@ -367,11 +367,11 @@ SPARSE_EXCHANGES = [0, 0]  # forward / backward exchanges that took the packed f
 def structural_zeros(t):
     """True when the caller marked `t` as the output of relu (+ dropout): its zeros are structural -- whoever produced it multiplies
     the gradient arriving at a zero position by zero (ops.relu_dropout tags its result; torch.relu outputs can be tagged with
-    mark_structural_zeros).  Only then may the halo exchange drop those gradient entries."""
-    tagged = getattr(t, "_mgx_structural_zeros", None)
-    # the tag holds the tensor's version counter at tagging time: an in-place write afterwards (h.sub_(c), h[i] = 0 ...) may create zeros that
-    # are NOT annihilated by the producer's backward, so it voids the tag
-    return tagged is not None and tagged is not False and int(tagged) == int(t._version)
+    mark_structural_zeros).  Only then may the halo exchange drop those gradient entries.  The tag holds the tensor's version counter
+    at tagging time: an in-place write afterwards (h.sub_(c), h[i] = 0 ...) may create zeros that are NOT annihilated by the producer's
+    backward, so it voids the tag (ops.has_structural_zeros)."""
+    from . import ops
+    return ops.has_structural_zeros(t)
 
 
 def mark_structural_zeros(t):
@@ -906,41 +906,39 @@ class DistGraph(DGLGraph):
             return None
         return DistSageProjectFirstFn.apply(plan, self._comm, h, w_self, w_neigh, bias)
 
-    def sage_mean_layer(self, h, w_self, w_neigh, bias, cat):
-        """The one-GEMM SAGE layer on this partition (ops.sage_mean_layer dispatches here); None when it does not apply."""
+    def _cat_layer_applies(self, h, cat):
+        """The one-GEMM layer's conditions on this partition: a float32 [n_own, K] input that the CatBuffer holds, 32-bit offsets everywhere."""
         plan = self._plan
-        if (cat is None or plan.loc is None or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda or cat.K != h.shape[1]
-                or h.shape[0] != plan.n_own or cat.buf.shape[0] != plan.n_own or h.shape[1] % 4
-                or plan.loc.csc().indptr.dtype != torch.int32 or not torch.is_grad_enabled()
-                or not config.SAGE_CAT or not config.SAGE_FUSED_LAYER):
+        return not (cat is None or plan.loc is None or h.dim() != 2 or h.dtype != torch.float32 or not h.is_cuda or cat.K != h.shape[1]
+                    or h.shape[0] != plan.n_own or cat.buf.shape[0] != plan.n_own or h.shape[1] % 4
+                    or plan.loc.csc().indptr.dtype != torch.int32 or not torch.is_grad_enabled()
+                    or not config.SAGE_CAT or not config.SAGE_FUSED_LAYER
+                    or plan.return_csr().num_cols * h.shape[1] * 4 >= (1 << 32) or (plan.n_own + plan.n_halo) * 2 * h.shape[1] * 4 >= (1 << 32))
+
+    def sage_mean_layer(self, h, w_self, w_neigh, bias, cat, act=None):
+        """The one-GEMM SAGE layer on this partition (ops.sage_mean_layer dispatches here); None when it does not apply."""
+        if not self._cat_layer_applies(h, cat):
             return None
-        if plan.return_csr().num_cols * h.shape[1] * 4 >= (1 << 32) or (plan.n_own + plan.n_halo) * 2 * h.shape[1] * 4 >= (1 << 32):
-            return None
+        plan = self._plan
         static = self._static_halo if self._static_halo.get("tensor") is h else None
-        return DistSageMeanCatFn.apply(plan, self._comm, cat, h, w_self, w_neigh, bias, static, static is None and sparse_halo_applies(h, plan))
+        return DistSageMeanCatFn.apply(plan, self._comm, cat, h, w_self, w_neigh, bias, static, static is None and sparse_halo_applies(h, plan), act)
 
     def sage_mean_layer_act(self, h, w_self, w_neigh, bias, cat, p, out):
         """dropout(relu(sage_mean_layer(...)), p) as ONE node (ops.sage_mean_layer_act dispatches here): the layer's GEMM applies the
         activation in its epilogue and writes `out` -- the next layer's left half --, tagged as ops.relu_dropout tags its result, so the
         next layer's halo exchange takes the packed form.  None when that form does not apply (the caller composes the two)."""
         from . import ops
-        plan = self._plan
-        be = sparse.backend_for(h) if h.is_cuda or h.device.type in sparse._BACKENDS else None
-        if (be is None or not hasattr(be, "rows_gemm_relu_dropout") or not config.SAGE_FUSED_ACT or not config.ROWS_GEMM or cat is None
+        if not self._cat_layer_applies(h, cat):
+            return None
+        be = sparse.backend_for(h)
+        if (not hasattr(be, "rows_gemm_relu_dropout") or not config.SAGE_FUSED_ACT or not config.ROWS_GEMM
                 or not (0.0 < p < 1.0) or ops.capture_path() or w_self.shape[0] % 4 or h.shape[0] < ops._ROWS_GEMM_MIN
                 or not be.rows_gemm_supported(2 * cat.K, w_self.shape[0], cat.buf.stride(0))
                 or (bias is not None and w_self.shape[0] > be.COLUMN_SUM_MAX)
                 or (out is not None and (out.shape != (h.shape[0], w_self.shape[0]) or out.stride(1) != 1 or out.stride(0) % 4
                                          or out.data_ptr() % 16 or out.requires_grad))):
             return None
-        if (plan.loc is None or h.dim() != 2 or h.dtype != torch.float32 or cat.K != h.shape[1] or h.shape[0] != plan.n_own
-                or cat.buf.shape[0] != plan.n_own or h.shape[1] % 4 or plan.loc.csc().indptr.dtype != torch.int32
-                or not torch.is_grad_enabled() or not config.SAGE_CAT or not config.SAGE_FUSED_LAYER
-                or plan.return_csr().num_cols * h.shape[1] * 4 >= (1 << 32) or (plan.n_own + plan.n_halo) * 2 * h.shape[1] * 4 >= (1 << 32)):
-            return None
-        static = self._static_halo if self._static_halo.get("tensor") is h else None
-        y = DistSageMeanCatFn.apply(plan, self._comm, cat, h, w_self, w_neigh, bias, static, static is None and sparse_halo_applies(h, plan),
-                                    (float(p), None if out is None else ops._Into(out)))
+        y = self.sage_mean_layer(h, w_self, w_neigh, bias, cat, act=(float(p), None if out is None else ops._Into(out)))
         return ops._structural_zeros(y)
 
 

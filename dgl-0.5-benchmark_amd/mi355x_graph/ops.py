@@ -557,6 +557,60 @@ def _structural_zeros(y):
     return y
 
 
+def has_structural_zeros(t):
+    """True when `t` carries _structural_zeros' tag and has not been written in place since."""
+    tagged = getattr(t, "_mgx_structural_zeros", None)
+    return tagged is not None and tagged is not False and int(tagged) == int(t._version)
+
+
+class _SlotGate(object):
+    """Whether a graph's forward aggregations of relu + dropout outputs take the 128-byte-slot form (csrc/spmm_slots.inc).  The form is
+    exact at any density -- a row with more than 24 non-zeros is read from the dense matrix -- but only pays while such rows are rare, so
+    every pack leaves its overflow count in pinned host memory (asynchronously: no synchronisation) and the NEXT call looks at the last
+    count that has arrived: above config.PACKED_GATHER_MAX_OVERFLOW of the rows the dense kernels take the following 64 calls."""
+    __slots__ = ("pending", "host", "dense_until", "calls", "last_fraction")
+
+    def __init__(self):
+        self.pending, self.host, self.dense_until, self.calls, self.last_fraction = None, None, 0, 0, None
+
+    def allow(self):
+        self.calls += 1
+        if self.pending is not None and self.pending[0].query():
+            self.last_fraction = float(self.host[0]) / max(self.pending[1], 1)
+            self.pending = None
+            if self.last_fraction > config.PACKED_GATHER_MAX_OVERFLOW:
+                self.dense_until = self.calls + 64
+        return self.calls > self.dense_until
+
+    def watch(self, overflow, n):
+        if self.pending is not None:
+            return
+        if self.host is None:
+            self.host = torch.empty(1, dtype=torch.int64).pin_memory()
+        self.host.copy_(overflow, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.pending = (ev, int(n))
+
+
+def _packed_rows(be, gidx, csc, h, left):
+    """The 128-byte slots of `left` (== h, a [N, 64] relu + dropout output) for the forward aggregation over `csc`, or None: the dense rows."""
+    if (not config.PACKED_GATHER or left.shape[1] != 64 or not has_structural_zeros(h) or csc.nnz < config.PACKED_GATHER_MIN_NNZ
+            or not hasattr(be, "rows_slots_pack") or capture_path() or not be.rows_slots_supported(left, csc)):
+        return None
+    plan, short = csc.spmm_plan_for(64)
+    if short and (plan is None or plan.rest is None):
+        return None  # every work item is short: the lane-group kernel walks them all, nothing would read the slots
+    gate = getattr(gidx, "_slot_gate", None)
+    if gate is None:
+        gate = gidx._slot_gate = _SlotGate()
+    if not gate.allow():
+        return None
+    slots, overflow = be.rows_slots_pack(left)
+    gate.watch(overflow, left.shape[0])
+    return slots
+
+
 class _Into(object):
     __slots__ = ("t",)
 
@@ -796,7 +850,8 @@ class SageMeanCatFn(torch.autograd.Function):
                 cat.left.copy_(h)
                 cat.static_key = None if h.requires_grad else (h, h._version)
         cat.generation += 1
-        be.spmm_copy_u_strided(csc, "mean", cat.left, cat.right)
+        # a relu + dropout output (a hidden layer's input) is gathered as 128-byte slots, one cache line per edge instead of two
+        be.spmm_copy_u_strided(csc, "mean", cat.left, cat.right, slots=_packed_rows(be, gidx, csc, h, cat.left))
         ctx.gidx, ctx.cat, ctx.generation = gidx, cat, cat.generation
         if act is not None:
             # relu + dropout in the GEMM's epilogue (mgx_rows_gemm_relu_dropout): the activation lands in the next layer's buffer and
@@ -1094,7 +1149,7 @@ def sage_mean_layer_act(g, h, w_self, w_neigh, bias, cat, p, out):
         return None  # sage_project_first's rule: this layer aggregates fewer columns projected first (reddit: 602 -> 16)
     if os.environ.get("MGX_SAGE_L1_PROJECT_FIRST", "0") == "1" and not h.requires_grad and K < D:
         return None  # the opt-in layer-1 form (sage_static_input_project) takes this layer
-    return SageMeanCatFn.apply(g._index, cat, h, w_self, w_neigh, bias, (float(p), None if out is None else _Into(out)))
+    return _structural_zeros(SageMeanCatFn.apply(g._index, cat, h, w_self, w_neigh, bias, (float(p), None if out is None else _Into(out))))
 
 
 def _cat_eligible(g, h, cat):

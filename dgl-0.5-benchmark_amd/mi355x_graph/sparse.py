@@ -483,9 +483,28 @@ class HipBackend(object):
                 PROFILE.append(rec)
         return out
 
-    def spmm_copy_u_strided(self, csr, reduce, U2d, out2d, accumulate=False, dst_scale=None):
+    def rows_slots_supported(self, x2d, csr=None):
+        """Can x2d [n, 64] travel as 128-byte slots (mgx_rows_slots_pack) into the g-SpMM over `csr` (mgx_spmm_copy_u_slots)?"""
+        return (x2d.dim() == 2 and x2d.shape[1] == 64 and x2d.dtype == torch.float32 and x2d.stride(1) == 1 and x2d.stride(0) % 4 == 0
+                and x2d.data_ptr() % 16 == 0 and x2d.shape[0] < (1 << 25) and x2d.shape[0] * int(x2d.stride(0)) * 4 < 2 ** 32
+                and (csr is None or (csr.idx_bits == 32 and csr.num_cols == x2d.shape[0] and csr.tile_plan(64) is None)))
+
+    def rows_slots_pack(self, x2d, overflow=None):
+        """(slots [n, 32] int32 = one 128-byte slot per row of x2d [n, 64], overflow int64[1] on the device += rows with more than 24
+        non-zeros, which the consumer reads from x2d itself): include/mi355x_graph.h, mgx_rows_slots_pack."""
+        dev = self._check_dev(x2d, overflow)
+        n = int(x2d.shape[0])
+        slots = torch.empty((n, 32), dtype=torch.int32, device=dev)
+        if overflow is None:
+            overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_rows_slots_pack(n, int(x2d.shape[1]), _ptr(x2d), int(x2d.stride(0)), _ptr(slots), _ptr(overflow), _stream(dev)))
+        return slots, overflow
+
+    def spmm_copy_u_strided(self, csr, reduce, U2d, out2d, accumulate=False, dst_scale=None, slots=None):
         """copy_u / sum|mean reading rows of U2d [num_cols, D] and writing rows of out2d [num_rows, D] IN PLACE, both row-strided
-        views (stride(1) == 1) -- column blocks of wider matrices (mgx_spmm_copy_u_strided)."""
+        views (stride(1) == 1) -- column blocks of wider matrices (mgx_spmm_copy_u_strided).  `slots` = rows_slots_pack(U2d)[0]: the
+        wave-per-item part of the schedule gathers the 128-byte slots instead of the 256-byte rows (mgx_spmm_copy_u_slots)."""
         dev = self._check_dev(csr.indptr, U2d, out2d, dst_scale)
         D = int(U2d.shape[1])
         if (U2d.dim() != 2 or out2d.dim() != 2 or U2d.stride(1) != 1 or out2d.stride(1) != 1 or out2d.shape[1] != D
@@ -507,10 +526,20 @@ class HipBackend(object):
                 if short:
                     rec["variant"] = _short_variant(plan)
                 rec["start"].record(torch.cuda.current_stream(dev))
-            _lib.check(_lib.lib().mgx_spmm_copy_u_strided(
-                ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,
-                int(U2d.stride(0)), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial),
-                (1 if accumulate else 0) | (2 if short else 0), _stream(dev)))
+            if slots is not None:
+                if slots.shape != (U2d.shape[0], 32) or slots.dtype != torch.int32 or not slots.is_contiguous():
+                    raise DGLError("spmm_copy_u_strided: slots must be the [num_cols, 32] int32 result of rows_slots_pack")
+                if rec is not None:
+                    rec["variant"] = (rec.get("variant", "") + "+slots").lstrip("+")
+                _lib.check(_lib.lib().mgx_spmm_copy_u_slots(
+                    ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,
+                    int(U2d.stride(0)), _ptr(slots), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial),
+                    (1 if accumulate else 0) | (2 if short else 0), _stream(dev)))
+            else:
+                _lib.check(_lib.lib().mgx_spmm_copy_u_strided(
+                    ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,
+                    int(U2d.stride(0)), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial),
+                    (1 if accumulate else 0) | (2 if short else 0), _stream(dev)))
             if rec is not None:
                 rec["end"].record(torch.cuda.current_stream(dev))
                 PROFILE.append(rec)

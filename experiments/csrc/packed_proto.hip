@@ -13,6 +13,9 @@
 //   2  the real thing: every lane adds its three values into a per-lane-group accumulator row in LDS (ds_add_f32 at column address;
 //      columns of one row are distinct, lane groups own different rows: no two lanes of an instruction meet), the eight rows are summed
 //      per output column in the epilogue.  Fixed summation order.
+//   3  the same accumulator rows updated by plain LDS read - add - write (three reads, then three writes per lane and source row: the
+//      columns of one row are distinct, the padding column 64 is skipped), no atomics
+//   4  mode 2 with the padding column skipped (are the 8 lanes of a row that all add 0 to column 64 what serialises the atomics?)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(kBlock) void packed_spmm_kernel(const Args a) {
   const int grp = lane >> 3, gi = lane & 7;
   float* accw = &acc_all[wave][0][0];
   float* accg = accw + grp * kAccStride;
-  if (MODE == 2) {
+  if (MODE >= 2) {
     for (int i = lane; i < 8 * kAccStride; i += 64) accw[i] = 0.f;
   }
   const int xcd = blockIdx.x % kXcds;
@@ -109,6 +112,41 @@ __global__ __launch_bounds__(kBlock) void packed_spmm_kernel(const Args a) {
               got[c] = ((mine >> c) & 1u) ? fetched : 0.f;
             }
             if (live) accv += got;
+          } else if (MODE == 3) {
+            const uint32_t meta = (uint32_t)__float_as_int(val[u].x);
+            if (live) {
+              if ((meta >> 24) != 255u) {
+                const uint32_t c0 = meta & 0xffu, c1 = (meta >> 8) & 0xffu, c2 = (meta >> 16) & 0xffu;
+                const float a0 = accg[c0], a1 = accg[c1], a2 = accg[c2];
+                if (c0 < 64u) accg[c0] = a0 + val[u].y;
+                if (c1 < 64u) accg[c1] = a1 + val[u].z;
+                if (c2 < 64u) accg[c2] = a2 + val[u].w;
+              } else {
+                const float* dr = a.dense + (size_t)(roff[u] >> 7) * a.ld + gi * 8;
+                const v4f d0 = *reinterpret_cast<const v4f*>(dr), d1 = *reinterpret_cast<const v4f*>(dr + 4);
+                v4f* ar = reinterpret_cast<v4f*>(accg + gi * 8);
+                ar[0] += d0;
+                ar[1] += d1;
+              }
+            }
+          } else if (MODE == 4) {
+            const uint32_t meta = (uint32_t)__float_as_int(val[u].x);
+            if (live) {
+              if ((meta >> 24) != 255u) {
+                const uint32_t c0 = meta & 0xffu, c1 = (meta >> 8) & 0xffu, c2 = (meta >> 16) & 0xffu;
+                if (c0 < 64u) atomicAdd(&accg[c0], val[u].y);
+                if (c1 < 64u) atomicAdd(&accg[c1], val[u].z);
+                if (c2 < 64u) atomicAdd(&accg[c2], val[u].w);
+              } else {
+                const float* dr = a.dense + (size_t)(roff[u] >> 7) * a.ld + gi * 8;
+                const v4f d0 = *reinterpret_cast<const v4f*>(dr), d1 = *reinterpret_cast<const v4f*>(dr + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  atomicAdd(&accg[gi * 8 + c], d0[c]);
+                  atomicAdd(&accg[gi * 8 + 4 + c], d1[c]);
+                }
+              }
+            }
           } else {
             const uint32_t meta = (uint32_t)__float_as_int(val[u].x);
             if (live) {
@@ -131,7 +169,7 @@ __global__ __launch_bounds__(kBlock) void packed_spmm_kernel(const Args a) {
       }
     }
     float res;
-    if (MODE == 2) {
+    if (MODE >= 2) {
       res = 0.f;
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
@@ -210,6 +248,10 @@ extern "C" int packed_spmm(int mode, int unroll, int64_t grid, const int32_t* it
   else if (mode == 2 && unroll == 2) LAUNCH(2, 2);
   else if (mode == 2 && unroll == 4) LAUNCH(2, 4);
   else if (mode == 2 && unroll == 8) LAUNCH(2, 8);
+  else if (mode == 3 && unroll == 2) LAUNCH(3, 2);
+  else if (mode == 3 && unroll == 4) LAUNCH(3, 4);
+  else if (mode == 3 && unroll == 8) LAUNCH(3, 8);
+  else if (mode == 4 && unroll == 4) LAUNCH(4, 4);
   else return -1;
 #undef LAUNCH
   return (int)hipGetLastError();

@@ -115,11 +115,19 @@ print("%-62s %9s" % ("variant", "ms"))
 for mode, U, what in ((0, 2, "gather floor (one line per edge, values summed as fetched)"), (0, 4, "gather floor, 32 rows in flight per wave"),
                       (1, 2, "+ register unpack mix (4 bpermute + popcounts per edge), synthetic"), (1, 4, "same, 32 rows in flight"),
                       (2, 2, "LDS accumulate (ds_add_f32 per value), exact"), (2, 4, "LDS accumulate, 32 rows in flight"),
-                      (2, 8, "LDS accumulate, 64 rows in flight")):
+                      (2, 8, "LDS accumulate, 64 rows in flight"),
+                      (4, 4, "LDS atomics, padding column skipped"),
+                      (3, 2, "LDS read-add-write (no atomics), exact"), (3, 4, "LDS read-add-write, 32 rows in flight"),
+                      (3, 8, "LDS read-add-write, 64 rows in flight")):
     ms = timed(lambda: packed(mode, U))
     print("mode %d U %d  %-50s %9.3f" % (mode, U, what, ms))
 
-# ---------------------------------------------------------------- mode 2 is exact: compare with the dense kernel's rows
+# ---------------------------------------------------------------- modes 2 / 3 are exact: compare with the dense kernel's rows
+packed(3, 4)
+torch.cuda.synchronize()
+direct = rest.item_row[rest.item_row >= 0].long()
+err3 = (out[direct] - out_ref[direct]).abs().max() / out_ref[direct].abs().max()
+print("\nmode 3 against the dense kernel on the directly written rows of `rest`: max |diff| / max |ref| = %.2e" % float(err3))
 packed(2, 4)
 torch.cuda.synchronize()
 direct = rest.item_row[rest.item_row >= 0].long()

@@ -193,6 +193,27 @@ int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan /*
                                 const float* ufeat, int64_t D, int64_t u_stride, const float* dst_scale /* may be NULL */,
                                 float* out, int64_t out_stride, float* partial_ws, int32_t flags, void* stream);
 
+/* copy_u / sum | mean over MOSTLY-ZERO rows of exactly 64 columns (round 5; csrc/spmm_slots.inc) -- the input of a hidden GraphSAGE
+ * layer is dropout(relu(.)) (main_dgl_product_sage.py:93-96; 20-25 % non-zero on the benchmark model), and the wave-per-item g-SpMM is
+ * bound by the bytes of the gathered rows (L2 -> CU).  mgx_rows_slots_pack turns x [n, 64] into one 128-BYTE SLOT per row:
+ *     8 x { meta, v0, v1, v2 } (uint32, float, float, float), meta = c0 | c1 << 8 | c2 << 16 | flag << 24
+ *     the row's non-zero values in increasing order of (column % 4) * 16 + column / 4 -- the (component, lane) order of a 16-lane x float4
+ *     read --, three per group, c = their columns, 64 = no value (the value word is 0); at most 24 per row; a row with MORE has
+ *     flag = 255 in all eight metas (columns 64, values 0): the consumer reads the dense row instead.  *overflow_rows (device, may be
+ *     NULL) += the number of such rows.
+ * mgx_spmm_copy_u_slots is mgx_spmm_copy_u_strided with the slots beside the dense matrix (same rows: slots = pack(ufeat)): the work
+ * items that the wave-per-item kernel would walk -- a whole schedule, or the `rest` part of a two-part plan -- gather ONE cache line per
+ * edge and add its values at their columns (per lane group of 8 lanes a 64-float accumulator row in LDS, updated by plain
+ * read - add - write in a fixed order); short items (MGX_SPMM_SHORT_ROWS, the head of a two-part plan) keep the dense lane-group
+ * kernel.  Exact (values are moved, never rounded); the order of additions inside a row differs from the dense kernels', so results
+ * agree to fp32 rounding, not bit for bit.  products-shaped graph, D = 64, 25 % non-zero: the wave-per-item part 1.83 -> 1.21 ms.
+ * int32 graphs, 16-byte aligned operands below 4 GiB (and fewer than 2^25 source rows); otherwise MGX_ERR_UNSUPPORTED. */
+int32_t mgx_rows_slots_pack(int64_t n, int64_t D /* 64 */, const float* x, int64_t x_stride, void* slots /* [n, 128 bytes] */,
+                            int64_t* overflow_rows /* device, may be NULL */, void* stream);
+int32_t mgx_spmm_copy_u_slots(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int32_t reduce, const float* ufeat,
+                              int64_t D /* 64 */, int64_t u_stride, const void* slots, const float* dst_scale /* may be NULL */,
+                              float* out, int64_t out_stride, float* partial_ws, int32_t flags, void* stream);
+
 /* LDS-staged copy_u / sum | mean for DENSE neighbourhoods (round 3; csrc/spmm_tile.hip).  On graphs with hundreds of in-edges
  * per node (reddit, proteins: kernel/dgl-new.py:61; main_dgl_reddit_sage.py:73-80) destination rows scheduled next to each other
  * share most of their sources; a TILE of consumers * nacc * 4 work items of the schedule is aggregated by one workgroup of

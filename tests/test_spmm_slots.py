@@ -1,0 +1,227 @@
+"""csrc/spmm_slots.inc (round 5): copy_u / sum|mean over MOSTLY-ZERO rows of 64 columns -- the dropout(relu(.)) input of a hidden GraphSAGE
+layer (main_dgl_product_sage.py:93-96) -- gathered as one 128-byte slot per source row instead of the 256-byte row.
+
+  mgx_rows_slots_pack      against a plain restatement of the slot format (include/mi355x_graph.h): bit for bit
+  mgx_spmm_copy_u_slots    against the CPU oracle through the C ABI (the order of additions inside a row differs from the dense kernels':
+                           1e-4 of the row's sum of magnitudes, as for every split row), on a two-part plan with hub rows and on a single
+                           schedule, with mean / dst_scale / accumulate / strided operands, at every density incl. rows above 24 non-zeros
+  ops.SageMeanCatFn        the layer with and without the slot form: same output, same gradients (fp32 rounding)"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import mi355x_graph as mg
+from mi355x_graph import _lib, config as mgx_config, ops, sparse
+
+DEV = "cuda:0"
+
+
+def _reference_slots(x):
+    """[n, 32] uint32 slots of a host matrix [n, 64], and the number of rows above 24 non-zeros."""
+    n = x.shape[0]
+    out = np.zeros((n, 32), np.uint32)
+    order = sorted(range(64), key=lambda col: (col % 4) * 16 + col // 4)   # (component, lane) of a 16-lane x float4 read
+    over = 0
+    xb = x.view(np.uint32)
+    for r in range(n):
+        nz = [c for c in order if x[r, c] != 0]
+        meta = [[64, 64, 64] for _ in range(8)]
+        flag = 0
+        if len(nz) > 24:
+            flag, over = 255, over + 1
+        else:
+            for j, c in enumerate(nz):
+                meta[j // 3][j % 3] = c
+                out[r, 4 * (j // 3) + 1 + j % 3] = xb[r, c]
+        for i in range(8):
+            out[r, 4 * i] = meta[i][0] | (meta[i][1] << 8) | (meta[i][2] << 16) | (flag << 24)
+    return out, over
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("density", [0.0, 0.1, 0.25, 0.5, 1.0])
+def test_pack_follows_the_slot_format(density):
+    be = sparse.backend_for(torch.empty(1, device=DEV))
+    rng = np.random.default_rng(int(density * 100) + 3)
+    for n in (1, 5, 1003):
+        x = (rng.standard_normal((n, 64)) * (rng.random((n, 64)) < density)).astype(np.float32)
+        if n > 4 and 0 < density < 1:
+            x[2] = 0.0                                        # an empty row
+            x[3, :25] = 1.5                                   # 25 non-zeros at least: an overflow row
+            x[4] = 0.0
+            x[4, [0, 5, 63]] = [-0.0, 2.0, -3.0]              # -0.0 is zero: not stored
+        want, over = _reference_slots(x)
+        wide = torch.zeros(n, 128, device=DEV)
+        wide[:, :64] = torch.from_numpy(x).to(DEV)
+        for xt in (torch.from_numpy(x).to(DEV), wide[:, :64]):  # contiguous rows and the left half of a layer's [h | neigh] buffer
+            assert be.rows_slots_supported(xt)
+            slots, ovf = be.rows_slots_pack(xt)
+            assert np.array_equal(slots.cpu().numpy().view(np.uint32), want), (density, n)
+            assert int(ovf) == over
+    assert not be.rows_slots_supported(torch.zeros(8, 32, device=DEV)) and not be.rows_slots_supported(torch.zeros(8, 64, device=DEV)[:, ::2])
+    with pytest.raises(_lib.DGLError):
+        be.rows_slots_pack(torch.zeros(8, 32, device=DEV))
+
+
+def _skewed_graph(n_src, n_dst, seed):
+    """Mostly short rows, 2 % of the rows holding half of the edges, two rows beyond the split threshold: the policy's two-part plan."""
+    rng = np.random.default_rng(seed)
+    deg = rng.poisson(3.4, n_dst).astype(np.int64)
+    heavy = rng.integers(0, n_dst, n_dst // 50)
+    deg[heavy] = np.minimum(40 * rng.zipf(1.6, heavy.shape[0]), 900)
+    deg[rng.integers(0, n_dst, n_dst // 8)] = 0
+    deg[[7, 4001]] = [2300, 700]                                                   # hub rows: split into 256-edge chunks
+    dst = np.repeat(np.arange(n_dst), deg)
+    src = rng.integers(0, n_src, dst.shape[0])
+    perm = rng.permutation(dst.shape[0])
+    return src[perm], dst[perm], deg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("density", [0.05, 0.25, 0.6])
+def test_copy_u_over_slots_against_the_oracle(oracle, density):
+    n_src, n_dst, D = 30000, 160000, 64
+    src, dst, deg = _skewed_graph(n_src, n_dst, seed=int(density * 100))
+    g = mg.create_block((torch.from_numpy(src), torch.from_numpy(dst)), n_src, n_dst, idtype=torch.int32, device=DEV)
+    csc = g._index.csc()
+    be = sparse.backend_for(csc.indptr)
+    rng = np.random.default_rng(5)
+    X = (rng.standard_normal((n_src, D)) * (rng.random((n_src, D)) < density)).astype(np.float32)
+    X[11] = rng.standard_normal(D)                                                  # a dense row among the sources
+    ip, ix, ei = oracle.coo_to_csr(n_dst, dst, src)
+    absum = oracle.spmm(ip, ix, ei, "copy_lhs", "sum", np.abs(X), None)
+    wide_in = torch.zeros(n_src, 2 * D, device=DEV)
+    wide_in[:, :D] = torch.from_numpy(X).to(DEV)
+    x = wide_in[:, :D]
+    slots, ovf = be.rows_slots_pack(x)
+    assert (int(ovf) > n_src // 2) == (density > 0.5)
+    plan, short = csc.spmm_plan_for(D)
+    assert plan is not None and short and plan.rest is not None and plan.rest.num_slots >= 9   # a two-part plan with split rows
+    for red in ("sum", "mean"):
+        out = torch.full((n_dst, D), float("nan"), device=DEV)
+        be.spmm_copy_u_strided(csc, red, x, out, slots=slots)
+        assert _lib.lib().mgx_last_spmm_kernel().decode() == "slots"
+        ref = oracle.spmm(ip, ix, ei, "copy_lhs", red, X, None)
+        scale = absum / np.maximum(deg, 1)[:, None] if red == "mean" else absum
+        assert bool((np.abs(out.cpu().numpy() - ref) <= 1e-4 * scale + 1e-30).all()), (density, red)
+        dense = torch.empty_like(out)
+        be.spmm_copy_u_strided(csc, red, x, dense)
+        assert _lib.lib().mgx_last_spmm_kernel().decode() != "slots"
+        assert float((out - dense).abs().max()) <= 2e-6 * float(dense.abs().max())
+    # accumulate + dst_scale into the right half of a wider matrix: what a partition's aggregation asks for
+    sc = torch.from_numpy(rng.random(n_dst).astype(np.float32) + 0.5).to(DEV)
+    base = torch.from_numpy(rng.standard_normal((n_dst, 2 * D)).astype(np.float32)).to(DEV)
+    wide = base.clone()
+    be.spmm_copy_u_strided(csc, "sum", x, wide[:, D:], accumulate=True, dst_scale=sc, slots=slots)
+    want = base[:, D:].cpu().numpy() + oracle.spmm(ip, ix, ei, "copy_lhs", "sum", X, None) * sc.cpu().numpy()[:, None]
+    assert bool((np.abs(wide[:, D:].cpu().numpy() - want) <= 1e-4 * (absum * sc.cpu().numpy()[:, None] + np.abs(base[:, D:].cpu().numpy())) + 1e-30).all())
+    assert torch.equal(wide[:, :D], base[:, :D])
+    # ONE schedule (no short part): every item on the slot kernel, hub rows through the partial slots and the fix-up
+    csc._short = {nb: None for nb in (2, 4, 8, 16, 32, 64)}
+    plan1, short1 = csc.spmm_plan_for(D)
+    assert not short1 and plan1 is not None and plan1.rest is None
+    out = torch.empty((n_dst, D), device=DEV)
+    be.spmm_copy_u_strided(csc, "sum", x, out, slots=slots)
+    assert _lib.lib().mgx_last_spmm_kernel().decode() == "slots"
+    assert bool((np.abs(out.cpu().numpy() - oracle.spmm(ip, ix, ei, "copy_lhs", "sum", X, None)) <= 1e-4 * absum + 1e-30).all())
+    # and without any plan: natural row order straight from indptr
+    nat = sparse.CsrView(csc.num_rows, csc.num_cols, csc.indptr, csc.indices, csc.eids)
+    nat._plan = None
+    nat._short = {nb: None for nb in (2, 4, 8, 16, 32, 64)}
+    status = _lib.lib().mgx_spmm_copy_u_slots(ctypes.byref(nat.c_struct()), None, sparse.REDUCE["mean"], sparse._ptr(x), D, int(x.stride(0)),
+                                              sparse._ptr(slots), None, sparse._ptr(out), D, None, 0, None)
+    torch.cuda.synchronize()
+    if max(deg) <= 100000:
+        assert status == 0, _lib.lib().mgx_last_error()
+        ref = oracle.spmm(ip, ix, ei, "copy_lhs", "mean", X, None)
+        assert bool((np.abs(out.cpu().numpy() - ref) <= 1e-4 * absum / np.maximum(deg, 1)[:, None] + 1e-30).all())
+
+
+@pytest.mark.gpu
+def test_slots_refuse_what_they_cannot_do():
+    g = mg.graph((torch.tensor([0, 1]), torch.tensor([1, 2])), num_nodes=3).int().to(DEV)
+    csc = g._index.csc()
+    x = torch.rand(3, 32, device=DEV)
+    out = torch.empty(3, 32, device=DEV)
+    slots = torch.zeros(3, 32, dtype=torch.int32, device=DEV)
+    status = _lib.lib().mgx_spmm_copy_u_slots(ctypes.byref(csc.c_struct()), None, sparse.REDUCE["sum"], sparse._ptr(x), 32, 32, sparse._ptr(slots),
+                                              None, sparse._ptr(out), 32, None, 0, None)
+    assert status == 2                                                     # MGX_ERR_UNSUPPORTED: 64 columns only
+    status = _lib.lib().mgx_spmm_copy_u_slots(ctypes.byref(csc.c_struct()), None, sparse.REDUCE["max"], sparse._ptr(x), 64, 64, sparse._ptr(slots),
+                                              None, sparse._ptr(out), 64, None, 0, None)
+    assert status == 1                                                     # MGX_ERR_INVALID_ARGUMENT: SUM or MEAN only
+
+
+@pytest.mark.gpu
+def test_the_sage_layer_with_and_without_slots(monkeypatch):
+    """ops.SageMeanCatFn over a tagged relu + dropout output: the slot form (forced on this small graph) against the dense kernels."""
+    import full_graph
+    from mi355x_graph.datasets import synthetic_edges
+    n = 30000
+    src, dst = synthetic_edges(n, 500000, 2000, seed=3, device=torch.device(DEV), symmetric=True)
+    g = mg.graph((src, dst), num_nodes=n).int().formats(["csr", "csc"]).to(DEV)
+    gen = torch.Generator().manual_seed(2)
+    feats = torch.rand(n, 100, generator=gen).to(DEV)
+    labels = torch.randint(0, 47, (n,), generator=gen).to(DEV)
+    monkeypatch.setattr(mgx_config, "PACKED_GATHER_MIN_NNZ", 0)
+    monkeypatch.setattr(ops, "_ROWS_GEMM_MIN", 0)
+    results = {}
+    seen = {}
+    orig = sparse.HipBackend.spmm_copy_u_strided
+
+    def spy(self, csr, reduce, U2d, out2d, accumulate=False, dst_scale=None, slots=None):
+        seen["slots"] = seen.get("slots", 0) + (slots is not None)
+        return orig(self, csr, reduce, U2d, out2d, accumulate=accumulate, dst_scale=dst_scale, slots=slots)
+
+    monkeypatch.setattr(sparse.HipBackend, "spmm_copy_u_strided", spy)
+    for packed in (True, False):
+        monkeypatch.setattr(mgx_config, "PACKED_GATHER", packed)
+        seen["slots"] = 0
+        g._index.__dict__.pop("_slot_gate", None)
+        torch.manual_seed(7)
+        ops.ReluDropout._calls = 0
+        model = full_graph.GraphSAGE(100, 64, 47, 3, 0.5, False, True).to(DEV)
+        model.train()
+        losses = []
+        for _ in range(2):
+            model.zero_grad()
+            loss = ops.nll_sum(model(g, feats), labels) / n
+            loss.backward()
+            losses.append(float(loss))
+        results[packed] = (losses, [p.grad.clone() for p in model.parameters()])
+        assert seen["slots"] == (4 if packed else 0)        # the two hidden layers' forward aggregations, both passes
+    (la, ga), (lb, gb) = results[True], results[False]
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 1e-4 * max(float(b.abs().max()), 1e-6)
+
+
+@pytest.mark.gpu
+def test_the_gate_turns_the_slot_form_off_for_dense_rows(monkeypatch):
+    """relu alone leaves half of the entries: nearly every row has more than 24 non-zeros and would be read from the dense matrix anyway --
+    the second call finds the first one's overflow count and takes the dense kernels for the next 64 calls."""
+    n = 20000
+    src = torch.randint(0, n, (400000,))
+    dst = torch.randint(0, n, (400000,))
+    g = mg.graph((src, dst), num_nodes=n).int().to(DEV)
+    csc = g._index.csc()
+    be = sparse.backend_for(csc.indptr)
+    monkeypatch.setattr(mgx_config, "PACKED_GATHER_MIN_NNZ", 0)
+    csc._short = {nb: None for nb in (2, 4, 8, 16, 32, 64)}
+    h = ops._structural_zeros(torch.relu(torch.randn(n, 64, device=DEV)))
+    assert ops.has_structural_zeros(h)
+    assert ops._packed_rows(be, g._index, csc, h, h) is not None          # nothing known yet: packed, and watched
+    torch.cuda.synchronize()
+    assert ops._packed_rows(be, g._index, csc, h, h) is None              # the count arrived: ~100 % overflow rows
+    gate = g._index._slot_gate
+    assert gate.last_fraction > 0.9 and gate.dense_until >= 64
+    sparse_h = ops._structural_zeros(h * (torch.rand(n, 64, device=DEV) < 0.4))
+    gate.dense_until = 0                                                   # (64 calls later)
+    assert ops._packed_rows(be, g._index, csc, sparse_h, sparse_h) is not None
+    torch.cuda.synchronize()
+    assert ops._packed_rows(be, g._index, csc, sparse_h, sparse_h) is not None and gate.last_fraction < 0.1
+    h.add_(1.0)                                                            # an in-place write voids the tag: dense kernels
+    assert ops._packed_rows(be, g._index, csc, h, h) is None
