@@ -15,6 +15,7 @@
 // -- 256 contiguous bytes per row and store instruction (tile-major columns gave 64-byte pieces: 2.0 TB/s of writes).  K % 4 != 0 or an unaligned A (the 47-column output gradient) takes the DWORD
 // form: lane (c, q) loads A[row0 + c][4 s + q], B staged to match.  No atomics, fixed summation order.
 #include "common.h"
+#include "slots.h"
 
 namespace mgx {
 
@@ -33,6 +34,9 @@ struct RowsGemmAct {
   uint32_t drop_below;  // keep when the 32 random bits are >= this
   float scale;          // 1 / (1 - p)
   uint64_t seed, offset;
+  uint32_t* slots;      // optional (M == 64): the activation's rows as 128-byte slots as well (slots.h) -- the next layer's aggregation
+                        // gathers those instead of the rows; the epilogue holds a row exactly as the stand-alone pack pass reads it
+  unsigned long long* overflow;  // optional: += rows with more than 24 non-zeros
 };
 
 // KS = k-steps of 4 (K_pad / 4; a multiple of 4 in the float4 form), MT = column tiles of 16 (a multiple of 4: groups of 64 columns)
@@ -43,6 +47,8 @@ __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, i
                                                            int scale_from, float* __restrict__ C, int64_t ldc, RowsGemmAct act,
                                                            float* __restrict__ C2, int64_t ldc2, int split_col) {
   __shared__ float Bl[KS * MT * 64];
+  __shared__ uint32_t slot_stage[ACT ? kRgWaves * 4 * 32 : 1];
+  unsigned long long over_rows = 0;
   const int lane = threadIdx.x & (kWave - 1);
   const int c = lane % 16, q = lane / 16;
   // ---- stage B: element (step s, tile mt, lane) = B[k(s, q)][16 mt + c]; float4 form: s = 4 jj + t, k = 16 jj + 4 q + t, stored [jj][mt][lane][t]
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, i
           if (row_scale && m0 + t >= scale_from) v[t] *= rs[r];
         }
         if (ACT) {  // (the host checked: float4 stores possible, M % 4 == 0)
+          v4f kept = (v4f)(0.f);
           if (row < n && m0 + 3 < M) {
             const uint64_t i = (uint64_t)row * (uint64_t)(M / 4) + (uint64_t)(m0 / 4);
             const uint64_t q0 = splitmix64(act.seed ^ ((act.offset + i) * 2));
@@ -158,6 +165,11 @@ __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, i
             o.w = k3 ? v[3] * act.scale : 0.f;
             *reinterpret_cast<v4f*>(C + row * ldc + m0) = o;
             act.mask[i] = (uint8_t)((k0 ? 1 : 0) | (k1 ? 2 : 0) | (k2 ? 4 : 0) | (k3 ? 8 : 0));
+            kept = o;
+          }
+          if (act.slots) {  // wave-uniform; M == 64: lane (q, c) holds columns 4 c .. 4 c + 3 of row r0 + 4 q + r
+            const bool over = slot_pack_rows4(kept, q, c, slot_stage + (threadIdx.x / kWave) * 128, row < n ? act.slots + row * 32 : nullptr);
+            over_rows += (unsigned long long)__popcll(__ballot(over && c == 0 && row < n));
           }
         } else if (row < n) {
           float* dst = (C2 && m0 >= split_col) ? C2 + row * ldc2 + (m0 - split_col) : C + row * ldc + m0;
@@ -173,6 +185,7 @@ __global__ __launch_bounds__(kRgBlock) void rows_gemm_kernel(int64_t n, int K, i
       }
     }
   }
+  if (ACT && act.overflow && lane == 0 && over_rows) atomicAdd(act.overflow, over_rows);
 }
 
 template <int KS, int MT, bool V4>
@@ -243,7 +256,7 @@ extern "C" int32_t mgx_rows_gemm_supported(int64_t K, int64_t M, int64_t lda) {
 
 extern "C" int32_t mgx_rows_gemm_relu_dropout(int64_t n, int64_t K, int64_t M, const float* a, int64_t lda, const float* b, int64_t ldb,
                                               int32_t b_transposed, const float* bias, float p, uint64_t seed, uint64_t offset, float* y,
-                                              int64_t ldy, uint8_t* mask, void* stream) {
+                                              int64_t ldy, uint8_t* mask, void* slots, int64_t* overflow_rows, void* stream) {
   using namespace mgx;
   MGX_ENTER();
   MGX_CHECK_ARG(n >= 0 && K >= 1 && M >= 1 && M % 4 == 0, "mgx_rows_gemm_relu_dropout: bad sizes (M must be a multiple of 4)");
@@ -259,6 +272,9 @@ extern "C" int32_t mgx_rows_gemm_relu_dropout(int64_t n, int64_t K, int64_t M, c
   act.scale = 1.f / (1.f - p);
   act.seed = seed;
   act.offset = offset;
+  MGX_CHECK_ARG(!slots || (M == 64 && (uintptr_t)slots % 16 == 0), "mgx_rows_gemm_relu_dropout: slots are for M == 64 (16-byte aligned)");
+  act.slots = (uint32_t*)slots;
+  act.overflow = slots ? (unsigned long long*)overflow_rows : nullptr;
   if (!rows_gemm_dispatch(false, n, K, M, a, lda, b, ldb, b_transposed, bias, nullptr, 0, y, ldy, &act, (hipStream_t)stream))
     MGX_UNSUPPORTED("mgx_rows_gemm_relu_dropout: no kernel for K = %lld, M = %lld", (long long)K, (long long)M);
   MGX_CHECK_LAUNCH();

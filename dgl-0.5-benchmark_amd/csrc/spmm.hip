@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "slots.h"
 
 namespace mgx {
 

@@ -94,7 +94,7 @@ SIGNATURES = {
     "mgx_rows_gemm": (_i32, [_i64, _i64, _i64, _fp, _i64, _fp, _i64, _i32, _fp, _fp, _i64, _fp, _i64, _fp, _i64, _i64, _vp]),
     "mgx_rows_gemm_supported": (_i32, [_i64, _i64, _i64]),
     "mgx_rows_gemm_relu_dropout": (_i32, [_i64, _i64, _i64, _fp, _i64, _fp, _i64, _i32, _fp, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64,
-                                          _fp, _i64, _vp, _vp]),
+                                          _fp, _i64, _vp, _vp, _vp, _vp]),
     "mgx_column_sum_workspace": (_i64, [_i64]),
     "mgx_column_sum": (_i32, [_i64, _i64, _fp, _fp, _vp, _vp]),
     "mgx_coo_to_csr_workspace": (_i64, [_i64, _i64, _i32]),

@@ -582,6 +582,10 @@ class _SlotGate(object):
                 self.dense_until = self.calls + 64
         return self.calls > self.dense_until
 
+    def open(self):
+        """allow() without counting a call: asked by the PRODUCER of the rows (should its epilogue write the slots as well?)."""
+        return self.calls >= self.dense_until
+
     def watch(self, overflow, n):
         if self.pending is not None:
             return
@@ -593,10 +597,10 @@ class _SlotGate(object):
         self.pending = (ev, int(n))
 
 
-def _packed_rows(be, gidx, csc, h, left):
-    """The 128-byte slots of `left` (== h, a [N, 64] relu + dropout output) for the forward aggregation over `csc`, or None: the dense rows."""
-    if (not config.PACKED_GATHER or left.shape[1] != 64 or not has_structural_zeros(h) or csc.nnz < config.PACKED_GATHER_MIN_NNZ
-            or not hasattr(be, "rows_slots_pack") or capture_path() or not be.rows_slots_supported(left, csc)):
+def _slot_gate(be, gidx, csc, n):
+    """The gate of `gidx` when the forward aggregation of an [n, 64] relu + dropout output over `csc` may take the slot form at all."""
+    if (not config.PACKED_GATHER or csc.nnz < config.PACKED_GATHER_MIN_NNZ or not hasattr(be, "rows_slots_pack") or capture_path()
+            or csc.idx_bits != 32 or csc.num_cols != n or n >= (1 << 25) or csc.tile_plan(64) is not None):
         return None
     plan, short = csc.spmm_plan_for(64)
     if short and (plan is None or plan.rest is None):
@@ -604,9 +608,24 @@ def _packed_rows(be, gidx, csc, h, left):
     gate = getattr(gidx, "_slot_gate", None)
     if gate is None:
         gate = gidx._slot_gate = _SlotGate()
-    if not gate.allow():
+    return gate
+
+
+def _packed_rows(be, gidx, csc, h, left):
+    """The 128-byte slots of `left` (== h, a [N, 64] relu + dropout output) for the forward aggregation over `csc`, or None: the dense
+    rows.  The layer that produced h may have written them already (h._mgx_slots, the GEMM epilogue of sage_mean_layer_act)."""
+    if left.shape[1] != 64 or not has_structural_zeros(h):
         return None
-    slots, overflow = be.rows_slots_pack(left)
+    gate = _slot_gate(be, gidx, csc, left.shape[0])
+    if gate is None or not gate.allow():
+        return None
+    made = getattr(h, "_mgx_slots", None)
+    if made is not None and made[2] == int(h._version) and made[0].shape[0] == left.shape[0]:
+        slots, overflow = made[0], made[1]
+    elif be.rows_slots_supported(left, csc):
+        slots, overflow = be.rows_slots_pack(left)
+    else:
+        return None
     gate.watch(overflow, left.shape[0])
     return slots
 
@@ -856,12 +875,16 @@ class SageMeanCatFn(torch.autograd.Function):
         if act is not None:
             # relu + dropout in the GEMM's epilogue (mgx_rows_gemm_relu_dropout): the activation lands in the next layer's buffer and
             # the N x out pre-activation is never stored.  Same position in the random stream as ops.relu_dropout would take.
-            p, into = act
+            p, into = act[0], act[1]
+            made = act[2] if len(act) > 2 else None  # [slots, overflow, written?]: the activation's rows as 128-byte slots too
             seed = torch.initial_seed() & (2 ** 64 - 1)
             offset = (ReluDropout._calls * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
             ReluDropout._calls += 1
             wcat = torch.cat([w_self, w_neigh], dim=1)
-            fused = be.rows_gemm_relu_dropout(cat.buf, wcat, True, bias, float(p), seed, offset, out=None if into is None else into.t)
+            fused = be.rows_gemm_relu_dropout(cat.buf, wcat, True, bias, float(p), seed, offset, out=None if into is None else into.t,
+                                              slots=None if made is None else made[0], overflow=None if made is None else made[1])
+            if fused is not None and made is not None:
+                made[2] = True
             if fused is None:  # no fused kernel for this operand after all: the composition it stands for, same seed and offset (same bits)
                 y, mask = be.relu_dropout_fwd(_rows_linear(be, cat.buf, wcat, bias), float(p), seed, offset,
                                               out=None if into is None else into.t)
@@ -1149,7 +1172,18 @@ def sage_mean_layer_act(g, h, w_self, w_neigh, bias, cat, p, out):
         return None  # sage_project_first's rule: this layer aggregates fewer columns projected first (reddit: 602 -> 16)
     if os.environ.get("MGX_SAGE_L1_PROJECT_FIRST", "0") == "1" and not h.requires_grad and K < D:
         return None  # the opt-in layer-1 form (sage_static_input_project) takes this layer
-    return _structural_zeros(SageMeanCatFn.apply(g._index, cat, h, w_self, w_neigh, bias, (float(p), None if out is None else _Into(out))))
+    # the NEXT layer aggregates this layer's output over the same graph: when that aggregation will gather 128-byte slots (64 columns,
+    # _slot_gate), the GEMM's epilogue writes them beside the rows and the pack pass over the N x 64 activation is saved
+    made = None
+    be = sparse.backend_for(h)
+    if K == 64 and out is not None:
+        gate = _slot_gate(be, g._index, g._index.csc(), h.shape[0])
+        if gate is not None and gate.open():
+            made = [torch.empty((h.shape[0], 32), dtype=torch.int32, device=h.device), torch.zeros(1, dtype=torch.int64, device=h.device), False]
+    y = _structural_zeros(SageMeanCatFn.apply(g._index, cat, h, w_self, w_neigh, bias, (float(p), None if out is None else _Into(out), made)))
+    if made is not None and made[2]:
+        y._mgx_slots = (made[0], made[1], int(y._version))
+    return y
 
 
 def _cat_eligible(g, h, cat):

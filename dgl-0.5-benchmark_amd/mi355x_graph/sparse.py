@@ -982,10 +982,11 @@ class HipBackend(object):
     def rows_gemm_supported(self, K, M, lda):
         return bool(_lib.lib().mgx_rows_gemm_supported(int(K), int(M), int(lda)))
 
-    def rows_gemm_relu_dropout(self, a2d, b2d, b_transposed, bias, p, seed, offset, out=None):
+    def rows_gemm_relu_dropout(self, a2d, b2d, b_transposed, bias, p, seed, offset, out=None, slots=None, overflow=None):
         """dropout(relu(a2d x B + bias), p) written into `out` (a row-strided [n, M] view, or a new matrix) + the mask of
         relu_dropout_fwd -- bit for bit what rows_gemm followed by relu_dropout_fwd(seed, offset) gives, without storing the product.
-        None when mgx_rows_gemm has no kernel for the shape."""
+        `slots` ([n, 32] int32, M == 64): the rows as 128-byte slots too -- what rows_slots_pack(result) would write --, `overflow`
+        (int64[1]) += rows above 24 non-zeros.  None when mgx_rows_gemm has no kernel for the shape."""
         dev = self._check_dev(a2d, b2d, bias, out)
         n, K = a2d.shape
         M = b2d.shape[0] if b_transposed else b2d.shape[1]
@@ -996,10 +997,13 @@ class HipBackend(object):
         if not self._row_strided(y) or y.shape != (n, M) or y.data_ptr() % 16:
             return None
         mask = torch.empty(n * M // 4, dtype=torch.uint8, device=dev)
+        if slots is not None and (M != 64 or slots.shape != (n, 32) or slots.dtype != torch.int32 or not slots.is_contiguous()):
+            raise DGLError("rows_gemm_relu_dropout: slots are [n, 32] int32 for 64 output columns")
         with torch.cuda.device(dev):
             st = _lib.lib().mgx_rows_gemm_relu_dropout(n, K, M, _ptr(a2d), a2d.stride(0), _ptr(b2d), b2d.stride(0),
                                                        1 if b_transposed else 0, _ptr(bias), ctypes.c_float(p), ctypes.c_uint64(seed),
-                                                       ctypes.c_uint64(offset), _ptr(y), y.stride(0), _ptr(mask), _stream(dev))
+                                                       ctypes.c_uint64(offset), _ptr(y), y.stride(0), _ptr(mask), _ptr(slots),
+                                                       _ptr(overflow) if slots is not None else None, _stream(dev))
         if st == _lib.ERR_UNSUPPORTED:  # e.g. an operand that is only dword aligned: mgx_rows_gemm_supported() never sees the pointer
             return None
         _lib.check(st)

@@ -436,10 +436,14 @@ int32_t mgx_rows_gemm(int64_t n, int64_t K, int64_t M, const float* a, int64_t l
 int32_t mgx_rows_gemm_supported(int64_t K, int64_t M, int64_t lda);
 /* The same product followed by relu and inverted dropout (main_dgl_product_sage.py:93-95) in the epilogue: y[r, :] (row stride ldy) and the
  * 4 mask bits per float4 exactly as mgx_relu_dropout_fwd_strided(p, seed, offset) would produce them from the stored product -- which is
- * never written.  M % 4 == 0, y 16-byte aligned, ldy % 4 == 0; mask: [n * M / 4] bytes. */
+ * never written.  M % 4 == 0, y 16-byte aligned, ldy % 4 == 0; mask: [n * M / 4] bytes.
+ * slots (optional, M == 64 only): the rows of y as 128-byte slots as well, byte for byte what mgx_rows_slots_pack(y) would write (the
+ * epilogue holds a row exactly as that pass reads it), *overflow_rows (device, may be NULL) += rows with more than 24 non-zeros -- the
+ * next layer's aggregation (mgx_spmm_copy_u_slots) then needs no pack pass. */
 int32_t mgx_rows_gemm_relu_dropout(int64_t n, int64_t K, int64_t M, const float* a, int64_t lda, const float* b, int64_t ldb,
                                    int32_t b_transposed, const float* bias /* [M] or NULL */, float p, uint64_t seed, uint64_t offset,
-                                   float* y, int64_t ldy, uint8_t* mask, void* stream);
+                                   float* y, int64_t ldy, uint8_t* mask, void* slots /* [n, 128 bytes] or NULL */,
+                                   int64_t* overflow_rows /* or NULL */, void* stream);
 
 /* y = dropout_p(relu(x)) in one pass (inverted dropout: kept values scaled by 1/(1-p)); the activation between two
  * aggregations (main_dgl_product_sage.py:93-95).  n elements, n % 4 == 0, 16-byte aligned; mask: n/4 bytes, 4 bits per

@@ -65,6 +65,27 @@ def test_pack_follows_the_slot_format(density):
         be.rows_slots_pack(torch.zeros(8, 32, device=DEV))
 
 
+@pytest.mark.gpu
+def test_the_layer_gemm_writes_the_same_slots_as_the_pack_pass():
+    """mgx_rows_gemm_relu_dropout with a slots operand: byte for byte mgx_rows_slots_pack of the activation it stores, overflow rows counted."""
+    be = sparse.backend_for(torch.empty(1, device=DEV))
+    n, K, M = 50021, 128, 64
+    torch.manual_seed(3)
+    a = torch.randn(n, K, device=DEV)
+    w = torch.randn(M, K, device=DEV) * 0.1
+    b = torch.randn(M, device=DEV) * 0.1
+    for p in (0.5, 0.05):                                   # 25 % non-zero: a handful of rows above 24; 48 %: most of them
+        wide = torch.zeros(n, 2 * M, device=DEV)
+        slots = torch.full((n, 32), -1, dtype=torch.int32, device=DEV)
+        ovf = torch.zeros(1, dtype=torch.int64, device=DEV)
+        y, mask = be.rows_gemm_relu_dropout(a, w, True, b, p, 12345, 777, out=wide[:, :M], slots=slots, overflow=ovf)
+        plain = be.rows_gemm_relu_dropout(a, w, True, b, p, 12345, 777)
+        assert torch.equal(y, plain[0]) and torch.equal(mask, plain[1])            # the activation itself is unchanged
+        want, want_ovf = be.rows_slots_pack(y)
+        assert torch.equal(slots, want) and int(ovf) == int(want_ovf)
+        assert (int(ovf) > n // 2) == (p < 0.1)
+
+
 def _skewed_graph(n_src, n_dst, seed):
     """Mostly short rows, 2 % of the rows holding half of the edges, two rows beyond the split threshold: the policy's two-part plan."""
     rng = np.random.default_rng(seed)
@@ -176,9 +197,16 @@ def test_the_sage_layer_with_and_without_slots(monkeypatch):
         return orig(self, csr, reduce, U2d, out2d, accumulate=accumulate, dst_scale=dst_scale, slots=slots)
 
     monkeypatch.setattr(sparse.HipBackend, "spmm_copy_u_strided", spy)
+    orig_pack = sparse.HipBackend.rows_slots_pack
+
+    def pack_spy(self, x2d, overflow=None):
+        seen["packs"] = seen.get("packs", 0) + 1
+        return orig_pack(self, x2d, overflow)
+
+    monkeypatch.setattr(sparse.HipBackend, "rows_slots_pack", pack_spy)
     for packed in (True, False):
         monkeypatch.setattr(mgx_config, "PACKED_GATHER", packed)
-        seen["slots"] = 0
+        seen["slots"] = seen["packs"] = 0
         g._index.__dict__.pop("_slot_gate", None)
         torch.manual_seed(7)
         ops.ReluDropout._calls = 0
@@ -192,6 +220,7 @@ def test_the_sage_layer_with_and_without_slots(monkeypatch):
             losses.append(float(loss))
         results[packed] = (losses, [p.grad.clone() for p in model.parameters()])
         assert seen["slots"] == (4 if packed else 0)        # the two hidden layers' forward aggregations, both passes
+        assert seen["packs"] == 0                           # ... on slots written by the producing layer's GEMM epilogue: no pack pass
     (la, ga), (lb, gb) = results[True], results[False]
     for a, b in zip(la, lb):
         assert abs(a - b) <= 1e-5 * abs(b)
