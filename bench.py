@@ -534,6 +534,17 @@ def main():
         achieved = algo / avg / 1e9
         variants = sorted({r.get("variant", "row") for r in sel})
         entry = "mgx_spmm_tile_copy_u" if variants == ["tile"] else "mgx_spmm_csr / mgx_spmm_copy_u_strided"
+        # the launches of this width by FORM: dense 256-byte rows, or 128-byte slots of a mostly-zero operand (mgx_spmm_copy_u_slots:
+        # the forward aggregations of relu + dropout outputs and the reversed aggregation of the gradient behind one)
+        forms = []
+        for name, pick in (("dense rows", lambda r: "slots" not in r.get("variant", "")), ("128-byte slots (mgx_spmm_copy_u_slots)", lambda r: "slots" in r.get("variant", ""))):
+            fd = [r["start"].elapsed_time(r["end"]) * 1e-3 for r in sel if pick(r)]
+            if fd and len(fd) != len(durs):
+                favg = sum(fd) / len(fd)
+                forms.append({"form": name, "launches_per_epoch": len(fd) // max(args.steps, 1), "avg_launch_ms": round(favg * 1e3, 4),
+                              "frac": round(algo / favg / 1e9 / HBM_PEAK_GBPS, 4)})
+        if any("slots" in v for v in variants):
+            entry += " / mgx_spmm_copy_u_slots"
         kernels.append({"bound": "hbm", "kernel": "g-SpMM copy_u/sum|mean, D=%d (%s; %s kernel)" % (width, entry, "+".join(variants)),
                         "D": width,
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -546,6 +557,7 @@ def main():
                         "profile_avg_us": traced.get(width),
                         "launches_per_epoch": len(durs) // max(args.steps, 1),
                         "accumulating_launches_per_epoch": sum(1 for r in sel if r.get("accumulate")) // max(args.steps, 1),
+                        "forms": forms or None,
                         "rows": r0["n_rows"], "nnz": r0["nnz"]})
 
     # backward aggregations of a GRADIENT go through the row-sparse kernel (zero rows skipped): listed apart, never mixed into

@@ -7,6 +7,7 @@
 // backward needs neither x nor y.  Random bits: counter-based (splitmix64 of seed and element index), reproducible for a
 // given (seed, offset) whatever the launch shape.
 #include "common.h"
+#include "slots.h"
 
 namespace mgx {
 
@@ -50,6 +51,38 @@ __global__ __launch_bounds__(kBlock) void relu_dropout_bwd_kernel(int64_t n4, co
     o.w = (m & 8) ? g.w * scale : 0.f;
     dx[r * lddx4 + c] = o;
   }
+}
+
+// The same for rows of exactly 64 columns, and the result's rows -- times row_scale[r] when given -- as 128-byte slots as well
+// (slots.h): the gradient behind relu + dropout is as sparse as the activation was, and the reversed aggregation that follows gathers
+// the slots (mgx_spmm_copy_u_slots).  A wave holds four rows exactly as the stand-alone pack pass reads them.
+__global__ __launch_bounds__(kBlock) void relu_dropout_bwd_slots_kernel(int64_t rows, const v4f* __restrict__ dy, const uint8_t* __restrict__ mask,
+                                                                        v4f* __restrict__ dx, float scale, int64_t lddy4, int64_t lddx4,
+                                                                        const float* __restrict__ row_scale, uint32_t* __restrict__ slots,
+                                                                        unsigned long long* __restrict__ overflow) {
+  __shared__ uint32_t stage_all[kWavesPerBlock][4 * 32];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int sub = lane >> 4, l = lane & 15;
+  const int64_t rows_per_pass = (int64_t)gridDim.x * kWavesPerBlock * 4;
+  unsigned long long over_rows = 0;
+  for (int64_t base = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 4; base < rows; base += rows_per_pass) {
+    const int64_t r = base + sub;
+    v4f o = (v4f)(0.f);
+    if (r < rows) {
+      const v4f g = __builtin_nontemporal_load(&dy[r * lddy4 + l]);
+      const uint8_t m = mask[r * 16 + l];
+      o.x = (m & 1) ? g.x * scale : 0.f;
+      o.y = (m & 2) ? g.y * scale : 0.f;
+      o.z = (m & 4) ? g.z * scale : 0.f;
+      o.w = (m & 8) ? g.w * scale : 0.f;
+      dx[r * lddx4 + l] = o;
+      if (row_scale) o *= row_scale[r];
+    }
+    const bool over = slot_pack_rows4(o, sub, l, stage_all[wave], r < rows ? slots + r * 32 : nullptr);
+    over_rows += (unsigned long long)__popcll(__ballot(over && l == 0 && r < rows));
+  }
+  if (overflow && lane == 0 && over_rows) atomicAdd(overflow, over_rows);
 }
 
 static unsigned ew_grid(int64_t n4) {
@@ -122,6 +155,24 @@ extern "C" int32_t mgx_relu_dropout_bwd_strided(int64_t rows, int64_t cols, cons
   MGX_CHECK_ARG(dy && dx && mask && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0, "mgx_relu_dropout_bwd_strided: NULL or unaligned pointer");
   hipLaunchKernelGGL(relu_dropout_bwd_kernel, dim3(ew_grid(n / 4)), dim3(kBlock), 0, (hipStream_t)stream, n / 4, (const v4f*)dy, mask,
                      (v4f*)dx, 1.f / (1.f - p), cols / 4, dy_stride / 4, dx_stride / 4);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_relu_dropout_bwd_slots(int64_t rows, const float* dy, int64_t dy_stride, const uint8_t* mask, float p, float* dx,
+                                              int64_t dx_stride, const float* row_scale, void* slots, int64_t* overflow_rows, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(rows >= 0 && dy_stride % 4 == 0 && dx_stride % 4 == 0 && dy_stride >= 64 && dx_stride >= 64,
+                "mgx_relu_dropout_bwd_slots: rows of 64 columns, strides multiples of 4 and >= 64");
+  MGX_CHECK_ARG(p >= 0.f && p < 1.f, "mgx_relu_dropout_bwd_slots: p must be in [0, 1)");
+  if (rows == 0) return MGX_OK;
+  MGX_CHECK_ARG(dy && dx && mask && slots && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 && (uintptr_t)slots % 16 == 0,
+                "mgx_relu_dropout_bwd_slots: NULL or unaligned pointer");
+  int64_t blocks = (rows + 4 * kWavesPerBlock - 1) / (4 * kWavesPerBlock);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(relu_dropout_bwd_slots_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, rows, (const v4f*)dy, mask,
+                     (v4f*)dx, 1.f / (1.f - p), dy_stride / 4, dx_stride / 4, row_scale, (uint32_t*)slots, (unsigned long long*)overflow_rows);
   MGX_CHECK_LAUNCH();
   return MGX_OK;
 }

@@ -50,8 +50,8 @@ SIGNATURES = {
     "mgx_row_nonzero_bits": (_i32, [_i64, _i64, _fp, _vp, _vp]),
     "mgx_spmm_copy_u_masked": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _vp, _fp, _fp, _fp, _i32, _vp]),
     "mgx_spmm_copy_u_strided": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _i64, _fp, _fp, _i64, _fp, _i32, _vp]),
-    "mgx_rows_slots_pack": (_i32, [_i64, _i64, _fp, _i64, _vp, _vp, _vp]),
-    "mgx_spmm_copy_u_slots": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _i64, _vp, _fp, _fp, _i64, _fp, _i32, _vp]),
+    "mgx_rows_slots_pack": (_i32, [_i64, _i64, _fp, _i64, _fp, _vp, _vp, _vp]),
+    "mgx_spmm_copy_u_slots": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _i64, _vp, _fp, _fp, _fp, _i64, _fp, _i32, _vp]),
     "mgx_spmm_tile_copy_u": (_i32, [_csr_p, _vp, _vp, _i32, _fp, _i64, _i64, _fp, _fp, _i64, _fp, _i32, _vp]),
     "mgx_rows_mask_words": (_i64, [_i64]),
     "mgx_rows_pack_count": (_i32, [_i64, _vp, _i32, _i64, _fp, _i64, _vp, _vp, _vp]),
@@ -85,6 +85,7 @@ SIGNATURES = {
     "mgx_relu_dropout_bwd": (_i32, [_i64, _fp, _vp, ctypes.c_float, _fp, _vp]),
     "mgx_relu_dropout_fwd_strided": (_i32, [_i64, _i64, _fp, _i64, ctypes.c_float, ctypes.c_uint64, ctypes.c_uint64, _fp, _i64, _vp, _vp]),
     "mgx_relu_dropout_bwd_strided": (_i32, [_i64, _i64, _fp, _i64, _vp, ctypes.c_float, _fp, _i64, _vp]),
+    "mgx_relu_dropout_bwd_slots": (_i32, [_i64, _fp, _i64, _vp, ctypes.c_float, _fp, _i64, _fp, _vp, _vp, _vp]),
     "mgx_relu_dropout_fwd_counter": (_i32, [_i64, _i64, _fp, _i64, ctypes.c_float, ctypes.c_uint64, _vp, _fp, _i64, _vp, _vp]),
     "mgx_column_pair_sums": (_i32, [_i64, _i64, _i32, _fp, _fp, _fp, _fp, _vp, _vp]),
     "mgx_column_affine": (_i32, [_i64, _i64, _fp, _fp, _fp, _fp, _fp, _fp, _vp]),

@@ -900,24 +900,48 @@ class SageMeanCatFn(torch.autograd.Function):
     @staticmethod
     @once_differentiable  # raw kernels inside: second-order gradients would silently be wrong
     def backward(ctx, dy):
-        if ctx.p is not None:
-            w_self, w_neigh, mask = ctx.saved_tensors
-            be = sparse.backend_for(dy)
-            if not dy.is_contiguous() and not be._row_strided(dy):
-                dy = dy.contiguous()
-            dy = be.relu_dropout_bwd(dy, mask, ctx.p)  # the gradient of the pre-activation, as ReluDropout.backward forms it
-        else:
-            w_self, w_neigh = ctx.saved_tensors
         cat = ctx.cat
         if cat.generation != ctx.generation:
             raise DGLError("SAGEConv: a later forward pass overwrote the [h | neigh] buffer this backward pass needs "
                            "(two forwards before one backward); set MGX_SAGE_CAT=0")
-        dy = dy.contiguous()
         need = ctx.needs_input_grad
         be = sparse.backend_for(dy)
         K = cat.K
         dh = None
-        if need[2]:
+        aggregated_first = False
+        if ctx.p is not None:
+            w_self, w_neigh, mask = ctx.saved_tensors
+            if not dy.is_contiguous() and not be._row_strided(dy):
+                dy = dy.contiguous()
+            gate = None
+            if need[2] and dy.dim() == 2 and dy.shape[1] == 64 and K % 4 == 0 and config.ROWS_GEMM and be.rows_gemm_supported(128, K, 128):
+                gate = _slot_gate(be, ctx.gidx, ctx.gidx.csr(), dy.shape[0])
+                if gate is not None and not gate.allow():
+                    gate = None
+            if gate is not None:
+                # d h = d y W_self + A^T (D^-1 d y) W_neigh: the gradient behind relu + dropout is as sparse as the activation, so the
+                # reversed aggregation runs on IT -- as 128-byte slots, 1 / deg folded into the packed values -- and the projection
+                # follows as one GEMM on [d y | A^T D^-1 d y], instead of projecting first and aggregating 64 dense columns
+                dcat = torch.empty((dy.shape[0], 128), dtype=torch.float32, device=dy.device)
+                inv = ctx.gidx.csc().inv_degrees()
+                if dy.data_ptr() % 16 == 0:
+                    dy, slots, overflow = be.relu_dropout_bwd_slots(dy, mask, ctx.p, dcat[:, :64], row_scale=inv)
+                else:
+                    dy = be.relu_dropout_bwd(dy, mask, ctx.p, out=dcat[:, :64])
+                    slots, overflow = be.rows_slots_pack(dy, row_scale=inv)
+                gate.watch(overflow, dy.shape[0])
+                be.spmm_copy_u_strided(ctx.gidx.csr(), "sum", dy, dcat[:, 64:], slots=slots, src_scale=inv)
+                dh = be.rows_gemm(dcat, torch.cat([w_self, w_neigh], dim=0))  # [N, 128] x [128, K]
+                if dh is None:
+                    dh = dcat @ torch.cat([w_self, w_neigh], dim=0)
+                aggregated_first = True
+            else:
+                dy = be.relu_dropout_bwd(dy, mask, ctx.p)  # the gradient of the pre-activation, as ReluDropout.backward forms it
+        else:
+            w_self, w_neigh = ctx.saved_tensors
+        if not aggregated_first:
+            dy = dy.contiguous()
+        if need[2] and not aggregated_first:
             # [N, 2K] = d[h | neigh], the `neigh` half times 1 / deg (d(sum / deg)): one mgx_rows_gemm with the factor in its epilogue,
             # else the GEMM and a streaming pass over that half -- never a per-edge factor
             dh, dn = _rows_dgrad(be, dy, torch.cat([w_self, w_neigh], dim=1), ctx.gidx.csc().inv_degrees(), K)
@@ -930,7 +954,7 @@ class SageMeanCatFn(torch.autograd.Function):
             dw = _weight_grad(dy, cat.buf)                        # [out, 2K]
             dws, dwn = dw[:, :K].contiguous(), dw[:, K:].contiguous()
         elif need[5]:
-            db = be.column_sum(dy)
+            db = be.column_sum(dy if dy.is_contiguous() else dy.contiguous())
         return None, None, dh, dws, dwn, db, None
 
 

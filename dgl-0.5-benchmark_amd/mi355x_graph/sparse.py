@@ -489,23 +489,27 @@ class HipBackend(object):
                 and x2d.data_ptr() % 16 == 0 and x2d.shape[0] < (1 << 25) and x2d.shape[0] * int(x2d.stride(0)) * 4 < 2 ** 32
                 and (csr is None or (csr.idx_bits == 32 and csr.num_cols == x2d.shape[0] and csr.tile_plan(64) is None)))
 
-    def rows_slots_pack(self, x2d, overflow=None):
-        """(slots [n, 32] int32 = one 128-byte slot per row of x2d [n, 64], overflow int64[1] on the device += rows with more than 24
-        non-zeros, which the consumer reads from x2d itself): include/mi355x_graph.h, mgx_rows_slots_pack."""
-        dev = self._check_dev(x2d, overflow)
+    def rows_slots_pack(self, x2d, overflow=None, row_scale=None):
+        """(slots [n, 32] int32 = one 128-byte slot per row of x2d [n, 64] (times row_scale[r] when given), overflow int64[1] on the device
+        += rows with more than 24 non-zeros, which the consumer reads from x2d itself): include/mi355x_graph.h, mgx_rows_slots_pack."""
+        dev = self._check_dev(x2d, overflow, row_scale)
         n = int(x2d.shape[0])
         slots = torch.empty((n, 32), dtype=torch.int32, device=dev)
         if overflow is None:
             overflow = torch.zeros(1, dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mgx_rows_slots_pack(n, int(x2d.shape[1]), _ptr(x2d), int(x2d.stride(0)), _ptr(slots), _ptr(overflow), _stream(dev)))
+            _lib.check(_lib.lib().mgx_rows_slots_pack(n, int(x2d.shape[1]), _ptr(x2d), int(x2d.stride(0)), _ptr(row_scale), _ptr(slots),
+                                                      _ptr(overflow), _stream(dev)))
         return slots, overflow
 
-    def spmm_copy_u_strided(self, csr, reduce, U2d, out2d, accumulate=False, dst_scale=None, slots=None):
+    def spmm_copy_u_strided(self, csr, reduce, U2d, out2d, accumulate=False, dst_scale=None, slots=None, src_scale=None):
         """copy_u / sum|mean reading rows of U2d [num_cols, D] and writing rows of out2d [num_rows, D] IN PLACE, both row-strided
         views (stride(1) == 1) -- column blocks of wider matrices (mgx_spmm_copy_u_strided).  `slots` = rows_slots_pack(U2d)[0]: the
-        wave-per-item part of the schedule gathers the 128-byte slots instead of the 256-byte rows (mgx_spmm_copy_u_slots)."""
-        dev = self._check_dev(csr.indptr, U2d, out2d, dst_scale)
+        work items gather the 128-byte slots instead of the 256-byte rows (mgx_spmm_copy_u_slots); `src_scale` (with slots only): the
+        row factors the slots were packed with -- out = sum_u src_scale[u] * U2d[u]."""
+        dev = self._check_dev(csr.indptr, U2d, out2d, dst_scale, src_scale)
+        if src_scale is not None and slots is None:
+            raise DGLError("spmm_copy_u_strided: src_scale comes with slots packed with the same factors")
         D = int(U2d.shape[1])
         if (U2d.dim() != 2 or out2d.dim() != 2 or U2d.stride(1) != 1 or out2d.stride(1) != 1 or out2d.shape[1] != D
                 or U2d.shape[0] != csr.num_cols or out2d.shape[0] != csr.num_rows):
@@ -533,7 +537,7 @@ class HipBackend(object):
                     rec["variant"] = (rec.get("variant", "") + "+slots").lstrip("+")
                 _lib.check(_lib.lib().mgx_spmm_copy_u_slots(
                     ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()), REDUCE[reduce], _ptr(U2d), D,
-                    int(U2d.stride(0)), _ptr(slots), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial),
+                    int(U2d.stride(0)), _ptr(slots), _ptr(src_scale), _ptr(dst_scale), _ptr(out2d), int(out2d.stride(0)), _ptr(partial),
                     (1 if accumulate else 0) | (2 if short else 0), _stream(dev)))
             else:
                 _lib.check(_lib.lib().mgx_spmm_copy_u_strided(
@@ -869,9 +873,17 @@ class HipBackend(object):
                                                                 _ptr(mask), _stream(dev)))
         return y, mask
 
-    def relu_dropout_bwd(self, dy, mask, p):
-        """dy: contiguous, or a row-strided [rows, cols] view (the gradient's column block); dx is dense."""
-        dev = self._check_dev(dy, mask)
+    def relu_dropout_bwd(self, dy, mask, p, out=None):
+        """dy: contiguous, or a row-strided [rows, cols] view (the gradient's column block); dx is dense, or `out`: a row-strided [rows, cols]
+        view to write into (the left half of a wider matrix)."""
+        dev = self._check_dev(dy, mask, out)
+        if out is not None:
+            if dy.dim() != 2 or out.shape != dy.shape or not self._row_strided(out) or not (dy.is_contiguous() or self._row_strided(dy)):
+                raise DGLError("relu_dropout_bwd: `out` must be a [rows, cols] view with unit column stride of the gradient's shape")
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().mgx_relu_dropout_bwd_strided(dy.shape[0], dy.shape[1], _ptr(dy), dy.stride(0), _ptr(mask),
+                                                                    ctypes.c_float(p), _ptr(out), out.stride(0), _stream(dev)))
+            return out
         dx = torch.empty(dy.shape, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             if dy.is_contiguous():
@@ -882,6 +894,21 @@ class HipBackend(object):
                 _lib.check(_lib.lib().mgx_relu_dropout_bwd_strided(dy.shape[0], dy.shape[1], _ptr(dy), dy.stride(0), _ptr(mask),
                                                                     ctypes.c_float(p), _ptr(dx), dx.stride(0), _stream(dev)))
         return dx
+
+    def relu_dropout_bwd_slots(self, dy, mask, p, out, row_scale=None):
+        """relu_dropout_bwd into `out` (a row-strided [rows, 64] view) + (slots, overflow) of row_scale * result, as rows_slots_pack would
+        give them -- one pass (mgx_relu_dropout_bwd_slots)."""
+        dev = self._check_dev(dy, mask, out, row_scale)
+        if (dy.dim() != 2 or dy.shape[1] != 64 or out.shape != dy.shape or not self._row_strided(out) or out.data_ptr() % 16
+                or not (dy.is_contiguous() or self._row_strided(dy)) or dy.data_ptr() % 16):
+            raise DGLError("relu_dropout_bwd_slots: [rows, 64] operands with unit column stride, 16-byte aligned")
+        n = int(dy.shape[0])
+        slots = torch.empty((n, 32), dtype=torch.int32, device=dev)
+        overflow = torch.zeros(1, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_relu_dropout_bwd_slots(n, _ptr(dy), dy.stride(0), _ptr(mask), ctypes.c_float(p), _ptr(out), out.stride(0),
+                                                             _ptr(row_scale), _ptr(slots), _ptr(overflow), _stream(dev)))
+        return out, slots, overflow
 
     def column_pair_sums(self, a2d, b2d=None, shifted=False):
         """(sum a, sum a*a) per column, or (sum a, sum a*b) when b2d is given.  `shifted`: relative to the first row p of

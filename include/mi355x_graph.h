@@ -201,18 +201,24 @@ int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan /*
  *     read --, three per group, c = their columns, 64 = no value (the value word is 0); at most 24 per row; a row with MORE has
  *     flag = 255 in all eight metas (columns 64, values 0): the consumer reads the dense row instead.  *overflow_rows (device, may be
  *     NULL) += the number of such rows.
- * mgx_spmm_copy_u_slots is mgx_spmm_copy_u_strided with the slots beside the dense matrix (same rows: slots = pack(ufeat)): the work
- * items that the wave-per-item kernel would walk -- a whole schedule, or the `rest` part of a two-part plan -- gather ONE cache line per
- * edge and add its values at their columns (per lane group of 8 lanes a 64-float accumulator row in LDS, updated by plain
- * read - add - write in a fixed order); short items (MGX_SPMM_SHORT_ROWS, the head of a two-part plan) keep the dense lane-group
- * kernel.  Exact (values are moved, never rounded); the order of additions inside a row differs from the dense kernels', so results
- * agree to fp32 rounding, not bit for bit.  products-shaped graph, D = 64, 25 % non-zero: the wave-per-item part 1.83 -> 1.21 ms.
+ *     row_scale (may be NULL): the slots hold row_scale[r] * x[r, :] (the dense matrix is left as it is).
+ * mgx_spmm_copy_u_slots is mgx_spmm_copy_u_strided with the slots beside the dense matrix (same rows: slots = pack(ufeat, src_scale)):
+ * every work item gathers ONE cache line per edge and adds its values at their columns -- per lane group of 8 lanes a 64-float
+ * accumulator row in LDS, updated by plain read - add - write in a fixed order; a wave per item (a whole schedule, the `rest` part of a
+ * two-part plan: the eight rows are summed at the end) or a lane group per item (MGX_SPMM_SHORT_ROWS, the head of a two-part plan).
+ *     out[v] (+)= dst_scale[v] * SUM | MEAN_{u -> v} src_scale[u] * ufeat[u, :]
+ * src_scale (may be NULL) must be the row_scale the slots were packed with: the kernel applies it only to the rows it reads from ufeat
+ * (those above 24 non-zeros).  The reversed aggregation of a mean layer is of this form: A^T (D^-1 dy) with dy the gradient behind a
+ * relu + dropout.  Exact (values are moved, never rounded; the products by row_scale are the ones the dense kernels form); the order of
+ * additions inside a row differs from the dense kernels', so results agree to fp32 rounding, not bit for bit.  products-shaped graph,
+ * D = 64, 21 % non-zero: 2.15 -> 1.49 ms per call.
  * int32 graphs, 16-byte aligned operands below 4 GiB (and fewer than 2^25 source rows); otherwise MGX_ERR_UNSUPPORTED. */
-int32_t mgx_rows_slots_pack(int64_t n, int64_t D /* 64 */, const float* x, int64_t x_stride, void* slots /* [n, 128 bytes] */,
-                            int64_t* overflow_rows /* device, may be NULL */, void* stream);
+int32_t mgx_rows_slots_pack(int64_t n, int64_t D /* 64 */, const float* x, int64_t x_stride, const float* row_scale /* [n] or NULL */,
+                            void* slots /* [n, 128 bytes] */, int64_t* overflow_rows /* device, may be NULL */, void* stream);
 int32_t mgx_spmm_copy_u_slots(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int32_t reduce, const float* ufeat,
-                              int64_t D /* 64 */, int64_t u_stride, const void* slots, const float* dst_scale /* may be NULL */,
-                              float* out, int64_t out_stride, float* partial_ws, int32_t flags, void* stream);
+                              int64_t D /* 64 */, int64_t u_stride, const void* slots, const float* src_scale /* may be NULL */,
+                              const float* dst_scale /* may be NULL */, float* out, int64_t out_stride, float* partial_ws, int32_t flags,
+                              void* stream);
 
 /* LDS-staged copy_u / sum | mean for DENSE neighbourhoods (round 3; csrc/spmm_tile.hip).  On graphs with hundreds of in-edges
  * per node (reddit, proteins: kernel/dgl-new.py:61; main_dgl_reddit_sage.py:73-80) destination rows scheduled next to each other
@@ -458,6 +464,12 @@ int32_t mgx_relu_dropout_fwd_strided(int64_t rows, int64_t cols, const float* x,
                                      uint64_t offset, float* y, int64_t y_stride, uint8_t* mask, void* stream);
 int32_t mgx_relu_dropout_bwd_strided(int64_t rows, int64_t cols, const float* dy, int64_t dy_stride, const uint8_t* mask, float p,
                                      float* dx, int64_t dx_stride, void* stream);
+/* mgx_relu_dropout_bwd_strided for rows of exactly 64 columns that ALSO writes the result's rows, times row_scale[r] when given, as
+ * 128-byte slots (mgx_rows_slots_pack's format, byte for byte what that pass would write from row_scale * dx): the gradient behind
+ * relu + dropout is as sparse as the activation, and the reversed aggregation that follows gathers the slots (mgx_spmm_copy_u_slots). */
+int32_t mgx_relu_dropout_bwd_slots(int64_t rows, const float* dy, int64_t dy_stride, const uint8_t* mask, float p, float* dx,
+                                   int64_t dx_stride, const float* row_scale /* [rows] or NULL */, void* slots /* [rows, 128 bytes] */,
+                                   int64_t* overflow_rows /* device, may be NULL */, void* stream);
 /* Forward whose offset into the random stream is read from device memory when the launch RUNS (offset = *counter *
  * 0x9E3779B97F4A7C15 mod 2^63): captured in a HIP graph next to an increment of the counter, every replay draws a new mask. */
 int32_t mgx_relu_dropout_fwd_counter(int64_t rows, int64_t cols, const float* x, int64_t x_stride, float p, uint64_t seed,

@@ -86,6 +86,27 @@ def test_the_layer_gemm_writes_the_same_slots_as_the_pack_pass():
         assert (int(ovf) > n // 2) == (p < 0.1)
 
 
+@pytest.mark.gpu
+def test_relu_dropout_backward_writes_scaled_slots():
+    """mgx_relu_dropout_bwd_slots: the gradient as mgx_relu_dropout_bwd_strided forms it, and its rows times a row factor as slots -- byte
+    for byte mgx_rows_slots_pack(result, row_scale)."""
+    be = sparse.backend_for(torch.empty(1, device=DEV))
+    n = 40003
+    torch.manual_seed(4)
+    x = torch.randn(n, 64, device=DEV)
+    y, mask = be.relu_dropout_fwd(x, 0.5, 99, 1234)
+    up = torch.randn(n, 128, device=DEV)[:, 64:]                 # the upstream gradient: a column block of a wider matrix
+    sc = torch.rand(n, device=DEV) + 0.1
+    plain = be.relu_dropout_bwd(up, mask, 0.5)
+    wide = torch.zeros(n, 128, device=DEV)
+    dx, slots, ovf = be.relu_dropout_bwd_slots(up, mask, 0.5, wide[:, :64], row_scale=sc)
+    assert torch.equal(dx, plain) and torch.equal(wide[:, 64:], torch.zeros_like(wide[:, 64:]))
+    want, want_ovf = be.rows_slots_pack(plain, row_scale=sc)
+    assert torch.equal(slots, want) and int(ovf) == int(want_ovf)
+    dx2, slots2, _ = be.relu_dropout_bwd_slots(up, mask, 0.5, torch.empty(n, 64, device=DEV))
+    assert torch.equal(dx2, plain) and torch.equal(slots2, be.rows_slots_pack(plain)[0])
+
+
 def _skewed_graph(n_src, n_dst, seed):
     """Mostly short rows, 2 % of the rows holding half of the edges, two rows beyond the split threshold: the policy's two-part plan."""
     rng = np.random.default_rng(seed)
@@ -139,6 +160,22 @@ def test_copy_u_over_slots_against_the_oracle(oracle, density):
     want = base[:, D:].cpu().numpy() + oracle.spmm(ip, ix, ei, "copy_lhs", "sum", X, None) * sc.cpu().numpy()[:, None]
     assert bool((np.abs(wide[:, D:].cpu().numpy() - want) <= 1e-4 * (absum * sc.cpu().numpy()[:, None] + np.abs(base[:, D:].cpu().numpy())) + 1e-30).all())
     assert torch.equal(wide[:, :D], base[:, :D])
+    # slots that carry a row factor (the reversed aggregation of a mean layer: A^T (D^-1 dy)): out = sum_u sc_src[u] * x[u]; the kernel
+    # applies the factor itself only to the rows it reads from the dense matrix (those above 24 non-zeros)
+    sc_src = torch.from_numpy(rng.random(n_src).astype(np.float32) + 0.25).to(DEV)
+    scaled_slots, ovf2 = be.rows_slots_pack(x, row_scale=sc_src)
+    assert int(ovf2) == int(ovf)
+    want_slots, _ = be.rows_slots_pack((x * sc_src.view(-1, 1)).contiguous())
+    keep = (want_slots[:, 0].view(torch.int32) >> 24) == 0                      # (overflow rows hold no values either way)
+    assert torch.equal(scaled_slots[keep], want_slots[keep])
+    out = torch.empty((n_dst, D), device=DEV)
+    be.spmm_copy_u_strided(csc, "sum", x, out, slots=scaled_slots, src_scale=sc_src)
+    assert _lib.lib().mgx_last_spmm_kernel().decode() == "slots"
+    Xs = X * sc_src.cpu().numpy()[:, None]
+    ref = oracle.spmm(ip, ix, ei, "copy_lhs", "sum", Xs, None)
+    assert bool((np.abs(out.cpu().numpy() - ref) <= 1e-4 * oracle.spmm(ip, ix, ei, "copy_lhs", "sum", np.abs(Xs), None) + 1e-30).all())
+    with pytest.raises(_lib.DGLError):
+        be.spmm_copy_u_strided(csc, "sum", x, out, src_scale=sc_src)             # a factor without slots packed with it
     # ONE schedule (no short part): every item on the slot kernel, hub rows through the partial slots and the fix-up
     csc._short = {nb: None for nb in (2, 4, 8, 16, 32, 64)}
     plan1, short1 = csc.spmm_plan_for(D)
@@ -152,7 +189,7 @@ def test_copy_u_over_slots_against_the_oracle(oracle, density):
     nat._plan = None
     nat._short = {nb: None for nb in (2, 4, 8, 16, 32, 64)}
     status = _lib.lib().mgx_spmm_copy_u_slots(ctypes.byref(nat.c_struct()), None, sparse.REDUCE["mean"], sparse._ptr(x), D, int(x.stride(0)),
-                                              sparse._ptr(slots), None, sparse._ptr(out), D, None, 0, None)
+                                              sparse._ptr(slots), None, None, sparse._ptr(out), D, None, 0, None)
     torch.cuda.synchronize()
     if max(deg) <= 100000:
         assert status == 0, _lib.lib().mgx_last_error()
@@ -168,10 +205,10 @@ def test_slots_refuse_what_they_cannot_do():
     out = torch.empty(3, 32, device=DEV)
     slots = torch.zeros(3, 32, dtype=torch.int32, device=DEV)
     status = _lib.lib().mgx_spmm_copy_u_slots(ctypes.byref(csc.c_struct()), None, sparse.REDUCE["sum"], sparse._ptr(x), 32, 32, sparse._ptr(slots),
-                                              None, sparse._ptr(out), 32, None, 0, None)
+                                              None, None, sparse._ptr(out), 32, None, 0, None)
     assert status == 2                                                     # MGX_ERR_UNSUPPORTED: 64 columns only
     status = _lib.lib().mgx_spmm_copy_u_slots(ctypes.byref(csc.c_struct()), None, sparse.REDUCE["max"], sparse._ptr(x), 64, 64, sparse._ptr(slots),
-                                              None, sparse._ptr(out), 64, None, 0, None)
+                                              None, None, sparse._ptr(out), 64, None, 0, None)
     assert status == 1                                                     # MGX_ERR_INVALID_ARGUMENT: SUM or MEAN only
 
 
@@ -192,21 +229,22 @@ def test_the_sage_layer_with_and_without_slots(monkeypatch):
     seen = {}
     orig = sparse.HipBackend.spmm_copy_u_strided
 
-    def spy(self, csr, reduce, U2d, out2d, accumulate=False, dst_scale=None, slots=None):
+    def spy(self, csr, reduce, U2d, out2d, accumulate=False, dst_scale=None, slots=None, src_scale=None):
         seen["slots"] = seen.get("slots", 0) + (slots is not None)
-        return orig(self, csr, reduce, U2d, out2d, accumulate=accumulate, dst_scale=dst_scale, slots=slots)
+        seen["scaled"] = seen.get("scaled", 0) + (src_scale is not None)
+        return orig(self, csr, reduce, U2d, out2d, accumulate=accumulate, dst_scale=dst_scale, slots=slots, src_scale=src_scale)
 
     monkeypatch.setattr(sparse.HipBackend, "spmm_copy_u_strided", spy)
     orig_pack = sparse.HipBackend.rows_slots_pack
 
-    def pack_spy(self, x2d, overflow=None):
+    def pack_spy(self, x2d, overflow=None, row_scale=None):
         seen["packs"] = seen.get("packs", 0) + 1
-        return orig_pack(self, x2d, overflow)
+        return orig_pack(self, x2d, overflow, row_scale)
 
     monkeypatch.setattr(sparse.HipBackend, "rows_slots_pack", pack_spy)
     for packed in (True, False):
         monkeypatch.setattr(mgx_config, "PACKED_GATHER", packed)
-        seen["slots"] = seen["packs"] = 0
+        seen["slots"] = seen["packs"] = seen["scaled"] = 0
         g._index.__dict__.pop("_slot_gate", None)
         torch.manual_seed(7)
         ops.ReluDropout._calls = 0
@@ -219,8 +257,10 @@ def test_the_sage_layer_with_and_without_slots(monkeypatch):
             loss.backward()
             losses.append(float(loss))
         results[packed] = (losses, [p.grad.clone() for p in model.parameters()])
-        assert seen["slots"] == (4 if packed else 0)        # the two hidden layers' forward aggregations, both passes
-        assert seen["packs"] == 0                           # ... on slots written by the producing layer's GEMM epilogue: no pack pass
+        # the two hidden layers' forward aggregations (slots written by the producing layer's GEMM epilogue) and the reversed
+        # aggregation of layer 2's backward -- on the relu + dropout gradient itself, 1 / deg folded into the slots its own kernel
+        # writes (d h = d y W_self + A^T (D^-1 d y) W_neigh) --, in both passes; never a separate pack pass
+        assert seen["slots"] == (6 if packed else 0) and seen["scaled"] == (2 if packed else 0) and seen["packs"] == 0
     (la, ga), (lb, gb) = results[True], results[False]
     for a, b in zip(la, lb):
         assert abs(a - b) <= 1e-5 * abs(b)
