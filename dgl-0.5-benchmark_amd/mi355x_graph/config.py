@@ -47,5 +47,6 @@ WIDE_PAD_MIN_NNZ = 1 << 20
 
 # ---- mostly-zero rows as 128-byte slots (ops._packed_rows, csrc/spmm_slots.inc)
 PACKED_GATHER = True       # the forward aggregation of a [N, 64] relu + dropout output gathers one 128-byte slot per edge instead of the 256-byte row
-PACKED_GATHER_MIN_NNZ = 4_000_000    # smaller graphs: the pack pass and a second launch cost more than the gathers they halve
+PACKED_GATHER_MIN_NNZ = 20_000_000   # products shape x 0.1 / 0.2 / 0.3 / 0.5 / 1 (12 .. 124 M edges): dense 0.21 / 0.39 / 0.59 / 1.02 / 2.13 ms, slots +
+                                     # pack pass 0.21 / 0.36 / 0.53 / 0.82 / 1.62 ms: small operands sit in L2 / MALL, where whole rows are cheap
 PACKED_GATHER_MAX_OVERFLOW = 0.10    # share of rows with more than 24 non-zeros (read from the dense matrix) above which the dense kernels are used

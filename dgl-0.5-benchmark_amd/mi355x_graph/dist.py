@@ -607,7 +607,10 @@ class DistSageMeanCatFn(torch.autograd.Function):
                 cat.static_key = None if h.requires_grad else (h, h._version)
         cat.generation += 1
         comm.mark("owned-source aggregation")
-        be.spmm_copy_u_strided(plan.loc.csc(), "sum", cat.left, cat.right, dst_scale=plan.inv_deg)
+        from . import ops
+        # (a relu + dropout output is gathered as 128-byte slots, as on one GPU: ops._packed_rows)
+        be.spmm_copy_u_strided(plan.loc.csc(), "sum", cat.left, cat.right, dst_scale=plan.inv_deg,
+                               slots=ops._packed_rows(be, plan.loc, plan.loc.csc(), h, cat.left) if hasattr(be, "rows_slots_pack") else None)
         if halo_x is not None:
             comm.mark("unpack")
             recv = halo_x.finish()
@@ -619,7 +622,6 @@ class DistSageMeanCatFn(torch.autograd.Function):
         ctx.plan, ctx.comm, ctx.cat, ctx.generation = plan, comm, cat, cat.generation
         ctx.halo_x = halo_x
         comm.mark("dense")
-        from . import ops
         wcat = torch.cat([w_self, w_neigh], dim=1)
         if act is not None:
             # dropout(relu(.)) in the GEMM's epilogue, written into the next layer's left half (ops.SageMeanCatFn's fused form: same

@@ -8,7 +8,9 @@ from mi355x_graph import _lib, sparse
 from mi355x_graph.datasets import SHAPES, synthetic_edges
 dev = torch.device("cuda:0")
 spec = SHAPES["products"]
-n, m = spec["n"], spec["m"]
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+n, m = int(spec["n"] * scale), int(spec["m"] * scale)
+print("# products shape x %.3f: N = %d, E = %d directed" % (scale, n, 2 * m))
 src, dst = synthetic_edges(n, m, spec["max_deg"], spec["seed"], dev, symmetric=True)
 g = dgl.graph((src, dst), num_nodes=n).int().formats(["csr", "csc"]).to(dev)
 del src, dst
