@@ -228,6 +228,37 @@ int main(void) {
       }
   }
 
+  /* round 5: mostly-zero rows of 64 columns as 128-byte slots -- the slot aggregation equals the dense one (small integers: exact in any
+     order), with a row factor folded into the slots, and a row above 24 non-zeros read from the dense matrix */
+  {
+    enum { SW = 64 };
+    static float X64[5 * SW], sc5[5], o_dense[5 * SW], o_slots[5 * SW];
+    static uint32_t slot_words[5 * 32];
+    for (int i = 0; i < 5 * SW; ++i) X64[i] = (i * 7 + i / SW) % 5 == 0 ? (float)(i % 11 - 5) : 0.f;   /* ~20 % non-zero */
+    for (int c = 0; c < 40; ++c) X64[3 * SW + c] = (float)(c % 7 + 1);                                  /* row 3: 40 non-zeros */
+    for (int r = 0; r < 5; ++r) sc5[r] = (float)(1 << r);                                                /* powers of two: exact products */
+    float *d_X = dev_copy(X64, sizeof X64), *d_sc = dev_copy(sc5, sizeof sc5);
+    float *d_o1 = dev_copy(NULL, sizeof o_dense), *d_o2 = dev_copy(NULL, sizeof o_slots);
+    uint32_t* d_slots = dev_copy(NULL, sizeof slot_words);
+    int64_t zero64 = 0, over = -1;
+    int64_t* d_over = dev_copy(&zero64, sizeof zero64);
+    CHECK_MGX(mgx_rows_slots_pack(5, SW, d_X, SW, d_sc, d_slots, d_over, NULL));
+    CHECK_MGX(mgx_spmm_copy_u_slots(&csr, NULL, MGX_REDUCE_SUM, d_X, SW, SW, d_slots, d_sc, NULL, d_o2, SW, NULL, 0, NULL));
+    CHECK_HIP(hipDeviceSynchronize());
+    CHECK_HIP(hipMemcpy(&over, d_over, sizeof over, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(slot_words, d_slots, sizeof slot_words, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(o_slots, d_o2, sizeof o_slots, hipMemcpyDeviceToHost));
+    if (over != 1 || (slot_words[3 * 32] >> 24) != 255u || (slot_words[0] >> 24) != 0u) { printf("rows_slots_pack: overflow row not flagged\n"); return 14; }
+    for (int v = 0; v < n; ++v)
+      for (int c = 0; c < SW; ++c) {
+        float ref = 0.f;
+        for (int e = 0; e < nnz; ++e)
+          if (dst[e] == v) ref += sc5[src[e]] * X64[src[e] * SW + c];
+        if (o_slots[v * SW + c] != ref) { printf("spmm_copy_u_slots mismatch at (%d, %d): %f != %f\n", v, c, o_slots[v * SW + c], ref); return 14; }
+      }
+    (void)d_o1; (void)o_dense;
+  }
+
   /* error path: bad argument must return a code and a message, not crash */
   if (mgx_spmm_csr(NULL, NULL, 0, 0, NULL, NULL, 1, 1, 1, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL) != MGX_ERR_INVALID_ARGUMENT ||
       strstr(mgx_last_error(), "csr is NULL") == NULL) { printf("error path broken\n"); return 8; }
