@@ -240,10 +240,10 @@ def self_launch(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def pmc_traffic(widths, reps, scale, timeout_s=240):
+def pmc_traffic(widths, reps, scale, timeout_s=240, slots=False):
     """HBM-side bytes per launch of the g-SpMM kernels on the benchmark graph from rocprofv3 counter passes run as CHILD
     processes (rocprofv3 -- python3 kernel_controls.py ...; --pmc alone, one pass per counter group as gfx950's TCC slots
-    require).  Returns (list per width | None, note)."""
+    require).  Returns (list per width | None, note); slots=True: two more entries -- the pack pass and the slot-form D = 64 launches."""
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
@@ -259,7 +259,7 @@ def pmc_traffic(widths, reps, scale, timeout_s=240):
             cmd = [rocprof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable,
                                                      os.path.join(PKG, "kernel_controls.py"), "--graphs", "products",
                                                      "--widths", ",".join(str(w) for w in widths), "--reps", str(reps),
-                                                     "--scale", str(scale)]
+                                                     "--scale", str(scale)] + (["--slots"] if slots else [])
             env = dict(os.environ, TMPDIR=work)
             r = subprocess.run(cmd, cwd=work, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=left)
             if r.returncode != 0:
@@ -767,13 +767,23 @@ def main():
                 roofline["controls"] = {"error": str(err)[:200]}
         if single and args.dataset == "products" and not args.no_pmc:
             widths = [k["D"] for k in kernels]
-            traffic, note = pmc_traffic(widths, 3, args.scale)
+            slot_forms = [f for k in kernels for f in (k.get("forms") or []) if "slots" in f["form"]]
+            traffic, note = pmc_traffic(widths, 3, args.scale, slots=bool(slot_forms))
             roofline["traffic_source"] = note
             if traffic:
                 for k, t in zip(kernels, traffic):
                     if "hbm_read_bytes" in t and "hbm_write_bytes" in t:
                         k["traffic"] = t["hbm_read_bytes"] + t["hbm_write_bytes"]
                         k["traffic_detail"] = t
+                        for f in (k.get("forms") or []):
+                            if "slots" not in f["form"]:
+                                f["traffic"] = k["traffic"]
+                if slot_forms and len(traffic) >= len(kernels) + 2:  # [.., pack pass, slot launches]
+                    t = traffic[len(kernels) + 1]
+                    if "hbm_read_bytes" in t and "hbm_write_bytes" in t:
+                        for f in slot_forms:
+                            f["traffic"] = t["hbm_read_bytes"] + t["hbm_write_bytes"]
+                            f["traffic_detail"] = t
                 roofline["traffic"] = head["traffic"]
                 if "traffic_detail" in head:
                     roofline["traffic_detail"] = head["traffic_detail"]

@@ -225,15 +225,40 @@ def run_controls(device, kinds=CONTROLS, widths=(64,), scale=1.0, reps=6, peak_g
     return out
 
 
+def slot_block(device, kind, scale, reps, density=0.21):
+    """One more block of a counter trace: the D = 64 aggregation over 128-byte slots (mgx_spmm_copy_u_slots) of a relu + dropout-like
+    operand on the `kind` graph -- the form three of the benchmark epoch's four D = 64 launches take."""
+    import dgl
+    from mi355x_graph import sparse
+    n, (src, dst) = control_edges(kind, device, scale)
+    g = dgl.graph((src, dst), num_nodes=n).int().formats(["csc"]).to(device)
+    del src, dst
+    csc = g._index.csc()
+    be = sparse.backend_for(csc.indptr)
+    gen = torch.Generator(device=device).manual_seed(7)
+    X = torch.rand(n, 64, generator=gen, device=device) * (torch.rand(n, 64, generator=gen, device=device) < density)
+    out = torch.empty(n, 64, device=device)
+    slots, _ = be.rows_slots_pack(X)
+    torch.cuda.synchronize()
+    _marker(device)                       # (closes the pack pass: its own block, dropped by the reader)
+    for _ in range(reps):
+        be.spmm_copy_u_strided(csc, "sum", X, out, slots=slots)
+    torch.cuda.synchronize()
+    _marker(device)
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--graphs", default=",".join(CONTROLS))
     p.add_argument("--widths", default="64")
     p.add_argument("--scale", type=float, default=1.0)
     p.add_argument("--reps", type=int, default=6)
+    p.add_argument("--slots", action="store_true", help="after the width blocks of the FIRST graph: the pack pass and the slot-form D = 64 launches as two more blocks")
     args = p.parse_args()
-    res = run_controls(torch.device("cuda:0"), [k for k in args.graphs.split(",") if k],
-                       [int(w) for w in args.widths.split(",")], args.scale, args.reps)
+    kinds = [k for k in args.graphs.split(",") if k]
+    res = run_controls(torch.device("cuda:0"), kinds, [int(w) for w in args.widths.split(",")], args.scale, args.reps)
+    if args.slots:
+        slot_block(torch.device("cuda:0"), kinds[0], args.scale, args.reps)
     print(json.dumps(res))
 
 

@@ -144,3 +144,7 @@ if rest.num_slots:
     print("the %d hub rows (partial slots combined on the host side of this script): max |diff| / max |ref| = %.2e" % (rest.num_hubs, float(herr)))
 print("\n# decision rule (VERDICT r04 item 5): build it if short part (0.34) + fix-up (0.035) + packed rest < 1.8 ms, i.e. packed rest < 1.42 ms; "
       "dense today: %.3f ms" % ms_full)
+print("# Reading (docs/LOG_r05.md sections 5, 9c).  One 128-byte line per edge over the wave-per-item part: 0.93 - 1.03 ms against 1.83 ms for the dense\n"
+      "# rows -- both at ~15 TB/s of L2 -> CU row bytes.  A register-side unpack (mode 1 is half of one) or LDS float atomics (mode 2 / 4) give the\n"
+      "# gain back; mode 3 -- the accumulator rows in LDS updated by plain read - add - write, no atomics: the columns of a source row are distinct,\n"
+      "# lane groups own different rows, a wave's LDS operations run in order -- is exact and meets the rule.  Built: csrc/spmm_slots.inc.")
