@@ -69,7 +69,7 @@ static void coo_to_csr_host_impl(int64_t n_rows, int64_t nnz, const Idx* row, co
 
 extern "C" const char* mgx_last_error(void) { return mgx::g_err; }
 
-extern "C" int32_t mgx_abi_version(void) { return 34; }
+extern "C" int32_t mgx_abi_version(void) { return 35; }
 
 namespace mgx {
 static thread_local const char* g_last_spmm_kernel = "";

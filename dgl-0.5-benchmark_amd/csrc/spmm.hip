@@ -949,6 +949,13 @@ static void launch_fast(const SpmmFastArgs<Idx>& a, int64_t nnz, hipStream_t s) 
 }
 
 #include "spmm_slots.inc"
+#include "spmm_tail.inc"
+static bool try_spmm_edge_tail(const SpmmFastArgs<int32_t>& a, const void* tail, hipStream_t s) {
+  if (!tail) return false;
+  launch_spmm_edge_tail(a, tail, s);
+  return true;
+}
+static bool try_spmm_edge_tail(const SpmmFastArgs<int64_t>&, const void*, hipStream_t) { return false; }
 static bool try_spmm_slots(const SpmmFastArgs<int32_t>& a, const void* slots, hipStream_t s) {
   if (!slots || !spmm_slots_eligible(a)) return false;
   // short items whose rows carry no factor keep the dense lane-group kernel (products head: 0.32 - 0.33 ms against 0.37 - 0.38 ms on
@@ -966,7 +973,7 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
                          int64_t u_len, int64_t e_len, int64_t out_len, const int64_t* u_off,
                          const int64_t* e_off, const float* src_scale, const float* dst_scale, float* out,
                          void* arg_u, void* arg_e, hipStream_t s, const uint32_t* src_bits = nullptr, int64_t u_stride = 0,
-                         int64_t out_stride = 0, const void* slots = nullptr) {
+                         int64_t out_stride = 0, const void* slots = nullptr, const void* edge_tail = nullptr) {
   const int64_t n_rows = csr->num_rows;
   const int accumulate = (flag_bits & MGX_SPMM_ACCUMULATE) ? 1 : 0;
   if (n_rows == 0 || out_len == 0) return MGX_OK;
@@ -980,11 +987,11 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
     mgx_spmm_plan head = *plan;
     head.rest = nullptr;
     int32_t st = spmm_impl<Idx>(csr, &head, partial_ws, flag_bits | kSpmmPartialPlan, op, reduce, U, E, u_len, e_len, out_len, u_off, e_off,
-                                src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride, slots);
+                                src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride, slots, edge_tail);
     if (st != MGX_OK) return st;
     const char* head_kernel = mgx_last_spmm_kernel();
     st = spmm_impl<Idx>(csr, plan->rest, partial_ws, (flag_bits & ~MGX_SPMM_SHORT_ROWS) | kSpmmPartialPlan, op, reduce, U, E, u_len, e_len,
-                        out_len, u_off, e_off, src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride, slots);
+                        out_len, u_off, e_off, src_scale, dst_scale, out, arg_u, arg_e, s, src_bits, u_stride, out_stride, slots, edge_tail);
     if (slots && st == MGX_OK) return st;  // (the name of the family that walked `rest` -- "slots" or not -- is what a caller of the packed form asks for)
     note_spmm_kernel(head_kernel);  // the family that walked the short items (the bulk of such a plan)
     return st;
@@ -1039,6 +1046,10 @@ static int32_t spmm_impl(const mgx_csr* csr, const mgx_spmm_plan* plan, float* p
                         !src_bits;
         if (!ok) MGX_UNSUPPORTED("mgx_spmm_copy_u_strided: needs int32 ids, D and both strides multiples of 4, 16-byte aligned "
                                  "pointers and a gathered matrix under 4 GiB");
+      }
+      if (try_spmm_edge_tail(a, edge_tail, s)) {  // a constant 100-column matrix as [rows, 96] + its last four columns along the edge list
+        MGX_CHECK_LAUNCH();
+        return fixup();
       }
       if (try_spmm_slots(a, slots, s)) {  // mostly-zero rows as 128-byte slots (spmm_slots.inc): the wave-per-item part only
         MGX_CHECK_LAUNCH();
@@ -1190,6 +1201,40 @@ extern "C" int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_pl
   return spmm_impl<int32_t>(csr, plan, partial_ws, flags & (MGX_SPMM_ACCUMULATE | MGX_SPMM_SHORT_ROWS), MGX_OP_COPY_LHS, reduce, ufeat, nullptr, D, 0,
                             D, nullptr, nullptr, nullptr, dst_scale, out, nullptr, nullptr, (hipStream_t)stream, nullptr, u_stride,
                             out_stride);
+}
+
+extern "C" int32_t mgx_edge_tail_fill(const mgx_csr* csr, const float* x, int64_t x_stride, float* edge_tail, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(csr != nullptr && csr->nnz >= 0 && x_stride >= 100, "mgx_edge_tail_fill: csr is NULL, or a row stride below 100");
+  if (csr->idx_bits != 32 || (uintptr_t)edge_tail % 16 != 0) MGX_UNSUPPORTED("mgx_edge_tail_fill: int32 graphs, a 16-byte aligned tail");
+  if (csr->nnz == 0) return MGX_OK;
+  MGX_CHECK_ARG(csr->indices && x && edge_tail, "mgx_edge_tail_fill: NULL pointer");
+  int64_t blocks = (csr->nnz + kBlock - 1) / kBlock;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(edge_tail_fill_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, csr->nnz, (const int32_t*)csr->indices, x,
+                     x_stride, (v4f*)edge_tail);
+  MGX_CHECK_LAUNCH();
+  return MGX_OK;
+}
+
+extern "C" int32_t mgx_spmm_copy_u_edge_tail(const mgx_csr* csr, const mgx_spmm_plan* plan, int32_t reduce, const float* block_a,
+                                             const float* edge_tail, const float* dst_scale, float* out, int64_t out_stride, float* partial_ws,
+                                             int32_t flags, void* stream) {
+  using namespace mgx;
+  MGX_ENTER();
+  MGX_CHECK_ARG(csr != nullptr, "mgx_spmm_copy_u_edge_tail: csr is NULL");
+  MGX_CHECK_ARG(csr->num_rows >= 0 && csr->nnz >= 0, "mgx_spmm_copy_u_edge_tail: negative sizes");
+  MGX_CHECK_ARG(csr->num_rows == 0 || csr->indptr != nullptr, "mgx_spmm_copy_u_edge_tail: indptr is NULL");
+  MGX_CHECK_ARG(csr->nnz == 0 || (csr->indices != nullptr && block_a != nullptr && edge_tail != nullptr), "mgx_spmm_copy_u_edge_tail: NULL pointer");
+  MGX_CHECK_ARG(reduce == MGX_REDUCE_SUM || reduce == MGX_REDUCE_MEAN, "mgx_spmm_copy_u_edge_tail: SUM or MEAN only, got %d", reduce);
+  MGX_CHECK_ARG(out_stride >= 100 && (out != nullptr || csr->num_rows == 0), "mgx_spmm_copy_u_edge_tail: out is NULL or its stride below 100");
+  if (csr->idx_bits != 32 || out_stride % 4 != 0 || (uintptr_t)block_a % 128 != 0 || (uintptr_t)edge_tail % 16 != 0 || (uintptr_t)out % 16 != 0 ||
+      csr->num_cols * (int64_t)384 >= (int64_t(1) << 32) || (flags & MGX_SPMM_SHORT_ROWS) || (plan && plan->rest))
+    MGX_UNSUPPORTED("mgx_spmm_copy_u_edge_tail: int32 graphs, block_a 128-byte aligned and below 4 GiB, 16-byte aligned tail / output, one schedule");
+  // (u_stride = 100: the logical width; the kernel addresses block_a by its own 96-column stride)
+  return spmm_impl<int32_t>(csr, plan, partial_ws, flags & MGX_SPMM_ACCUMULATE, MGX_OP_COPY_LHS, reduce, block_a, nullptr, 100, 0, 100, nullptr,
+                            nullptr, nullptr, dst_scale, out, nullptr, nullptr, (hipStream_t)stream, nullptr, 100, out_stride, nullptr, edge_tail);
 }
 
 extern "C" int32_t mgx_rows_slots_pack(int64_t n, int64_t D, const float* x, int64_t x_stride, const float* row_scale, void* slots,

@@ -50,6 +50,8 @@ SIGNATURES = {
     "mgx_row_nonzero_bits": (_i32, [_i64, _i64, _fp, _vp, _vp]),
     "mgx_spmm_copy_u_masked": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _vp, _fp, _fp, _fp, _i32, _vp]),
     "mgx_spmm_copy_u_strided": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _i64, _fp, _fp, _i64, _fp, _i32, _vp]),
+    "mgx_edge_tail_fill": (_i32, [_csr_p, _fp, _i64, _fp, _vp]),
+    "mgx_spmm_copy_u_edge_tail": (_i32, [_csr_p, _vp, _i32, _fp, _fp, _fp, _fp, _i64, _fp, _i32, _vp]),
     "mgx_rows_slots_pack": (_i32, [_i64, _i64, _fp, _i64, _fp, _vp, _vp, _vp]),
     "mgx_spmm_copy_u_slots": (_i32, [_csr_p, _vp, _i32, _fp, _i64, _i64, _vp, _fp, _fp, _fp, _i64, _fp, _i32, _vp]),
     "mgx_spmm_tile_copy_u": (_i32, [_csr_p, _vp, _vp, _i32, _fp, _i64, _i64, _fp, _fp, _i64, _fp, _i32, _vp]),

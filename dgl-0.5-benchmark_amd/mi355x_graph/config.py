@@ -50,3 +50,7 @@ PACKED_GATHER = True       # the forward aggregation of a [N, 64] relu + dropout
 PACKED_GATHER_MIN_NNZ = 20_000_000   # products shape x 0.1 / 0.2 / 0.3 / 0.5 / 1 (12 .. 124 M edges): dense 0.21 / 0.39 / 0.59 / 1.02 / 2.13 ms, slots +
                                      # pack pass 0.21 / 0.36 / 0.53 / 0.82 / 1.62 ms: small operands sit in L2 / MALL, where whole rows are cheap
 PACKED_GATHER_MAX_OVERFLOW = 0.10    # share of rows with more than 24 non-zeros (read from the dense matrix) above which the dense kernels are used
+
+# ---- a constant 100-column input as [N, 96] + its last four columns along the edge list (ops._edge_tail_operands, csrc/spmm_tail.inc)
+EDGE_TAIL = True           # products layer 1: 4.74 -> 4.09 ms per aggregation, for 16 bytes per edge (2 GB) + the [N, 96] copy, laid out once
+EDGE_TAIL_MIN_NNZ = 20_000_000

@@ -483,6 +483,44 @@ class HipBackend(object):
                 PROFILE.append(rec)
         return out
 
+    def edge_tail_of(self, csr, x2d):
+        """(block_a [n, 96] compact, 128-byte aligned; edge_tail [nnz, 4] = x2d[csr.indices, 96:100]) of a CONSTANT x2d [n, 100]: the operands
+        of spmm_copy_u_edge_tail, laid out once per (CSR, matrix).  None when mgx_spmm_copy_u_edge_tail would not take them."""
+        plan, short = csr.spmm_plan_for(100)
+        if (x2d.dim() != 2 or x2d.shape != (csr.num_cols, 100) or x2d.dtype != torch.float32 or x2d.stride(1) != 1 or csr.idx_bits != 32
+                or short or (plan is not None and plan.rest is not None) or csr.num_cols * 384 >= 2 ** 32 or csr.tile_plan(100) is not None):
+            return None
+        dev = self._check_dev(csr.indptr, x2d)
+        block_a = torch.empty((csr.num_cols, 96), dtype=torch.float32, device=dev)   # (the allocator aligns to 512 bytes)
+        block_a.copy_(x2d[:, :96])
+        tail = torch.empty((csr.nnz, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mgx_edge_tail_fill(ctypes.byref(csr.c_struct()), _ptr(x2d), int(x2d.stride(0)), _ptr(tail), _stream(dev)))
+        return block_a, tail
+
+    def spmm_copy_u_edge_tail(self, csr, reduce, block_a, tail, out2d, accumulate=False, dst_scale=None):
+        """copy_u / sum|mean of the constant [num_cols, 100] matrix held as edge_tail_of() into out2d [num_rows, 100] (row-strided view allowed)."""
+        dev = self._check_dev(csr.indptr, block_a, tail, out2d, dst_scale)
+        if (block_a.shape != (csr.num_cols, 96) or tail.shape != (csr.nnz, 4) or not block_a.is_contiguous() or not tail.is_contiguous()
+                or out2d.shape != (csr.num_rows, 100) or out2d.stride(1) != 1):
+            raise DGLError("spmm_copy_u_edge_tail: operands of edge_tail_of() and a [num_rows, 100] output expected")
+        plan, _ = csr.spmm_plan_for(100)
+        partial = torch.empty((plan.total_slots, 100), dtype=torch.float32, device=dev) if plan is not None and plan.total_slots else None
+        with torch.cuda.device(dev):
+            rec = None
+            if PROFILE is not None:
+                rec = {"op": "copy_lhs", "reduce": reduce, "out_len": 100, "n_rows": csr.num_rows, "n_cols": csr.num_cols, "nnz": csr.nnz,
+                       "accumulate": bool(accumulate), "variant": "row+edge tail", "strides": (96, int(out2d.stride(0))),
+                       "start": torch.cuda.Event(enable_timing=True), "end": torch.cuda.Event(enable_timing=True)}
+                rec["start"].record(torch.cuda.current_stream(dev))
+            _lib.check(_lib.lib().mgx_spmm_copy_u_edge_tail(ctypes.byref(csr.c_struct()), None if plan is None else ctypes.byref(plan.c_struct()),
+                                                            REDUCE[reduce], _ptr(block_a), _ptr(tail), _ptr(dst_scale), _ptr(out2d),
+                                                            int(out2d.stride(0)), _ptr(partial), 1 if accumulate else 0, _stream(dev)))
+            if rec is not None:
+                rec["end"].record(torch.cuda.current_stream(dev))
+                PROFILE.append(rec)
+        return out2d
+
     def rows_slots_supported(self, x2d, csr=None):
         """Can x2d [n, 64] travel as 128-byte slots (mgx_rows_slots_pack) into the g-SpMM over `csr` (mgx_spmm_copy_u_slots)?"""
         return (x2d.dim() == 2 and x2d.shape[1] == 64 and x2d.dtype == torch.float32 and x2d.stride(1) == 1 and x2d.stride(0) % 4 == 0

@@ -46,7 +46,7 @@ x = torch.rand(n, 100, device=dev)
 ref = torch.empty(n, 100, device=dev)
 ms0 = timed(lambda: be.spmm_copy_u_strided(csc, "mean", x, ref))
 print("one launch, 400-byte rows:                         %.3f ms  (%s)" % (ms0, _lib.lib().mgx_last_spmm_kernel().decode()))
-for cut in (64, 48, 52, 32):
+for cut in (64, 48, 52, 32, 96):
     xa, xb = x[:, :cut].contiguous(), x[:, cut:].contiguous()
     out = torch.empty(n, 100, device=dev)
 

@@ -193,6 +193,22 @@ int32_t mgx_spmm_copy_u_strided(const mgx_csr* csr, const mgx_spmm_plan* plan /*
                                 const float* ufeat, int64_t D, int64_t u_stride, const float* dst_scale /* may be NULL */,
                                 float* out, int64_t out_stride, float* partial_ws, int32_t flags, void* stream);
 
+/* copy_u / sum | mean of a CONSTANT matrix of exactly 100 columns (round 5; csrc/spmm_tail.inc) -- the layer-1 aggregation of
+ * ogbn-products' input features (main_dgl_product_sage.py:61-62), the largest launch of the epoch.  The row kernel's time is the number of
+ * cache-line requests per edge, and a 400-byte row costs a fourth (4.125 on average) for its last 16 bytes.  The features never change, so
+ * they are laid out ONCE as
+ *     block_a    [num_cols, 96]  columns 0 .. 95, compact: 384-byte rows = three lines each (128-byte aligned)
+ *     edge_tail  [nnz, 4]        edge_tail[p] = x[indices[p], 96 .. 99] for every stored position p of the CSR (mgx_edge_tail_fill)
+ * and the lane that streams position p's id reads edge_tail[p] in the same coalesced pass: three gathered lines per edge + a 16-byte
+ * stream.  out: [num_rows, 100] (row stride out_stride), columns 0 .. 95 bit-identical to mgx_spmm_copy_u_strided of x, 96 .. 99 equal
+ * to fp32 rounding (another order of additions).  The tail belongs to ONE CSR (its position order) and ONE x.
+ * int32 graphs, one schedule (no two-part plan, no MGX_SPMM_SHORT_ROWS), block_a below 4 GiB; otherwise MGX_ERR_UNSUPPORTED. */
+int32_t mgx_edge_tail_fill(const mgx_csr* csr, const float* x /* [num_cols, 100] */, int64_t x_stride, float* edge_tail /* [nnz, 4] */,
+                           void* stream);
+int32_t mgx_spmm_copy_u_edge_tail(const mgx_csr* csr, const mgx_spmm_plan* plan /* may be NULL */, int32_t reduce, const float* block_a,
+                                  const float* edge_tail, const float* dst_scale /* may be NULL */, float* out, int64_t out_stride,
+                                  float* partial_ws, int32_t flags, void* stream);
+
 /* copy_u / sum | mean over MOSTLY-ZERO rows of exactly 64 columns (round 5; csrc/spmm_slots.inc) -- the input of a hidden GraphSAGE
  * layer is dropout(relu(.)) (main_dgl_product_sage.py:93-96; 20-25 % non-zero on the benchmark model), and the wave-per-item g-SpMM is
  * bound by the bytes of the gathered rows (L2 -> CU).  mgx_rows_slots_pack turns x [n, 64] into one 128-BYTE SLOT per row:

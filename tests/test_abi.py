@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(handle, s), "libmi355x_graph.so does not export %s" % s
     assert sorted(_lib.SIGNATURES) == syms, "ctypes SIGNATURES and the header disagree"
-    assert _lib.lib().mgx_abi_version() == 34
+    assert _lib.lib().mgx_abi_version() == 35
 
 
 def test_bad_arguments_raise_not_crash():
