@@ -49,6 +49,7 @@ WIDE_PAD_MIN_NNZ = 1 << 20
 PACKED_GATHER = True       # the forward aggregation of a [N, 64] relu + dropout output gathers one 128-byte slot per edge instead of the 256-byte row
 PACKED_GATHER_MIN_NNZ = 20_000_000   # products shape x 0.1 / 0.2 / 0.3 / 0.5 / 1 (12 .. 124 M edges): dense 0.21 / 0.39 / 0.59 / 1.02 / 2.13 ms, slots +
                                      # pack pass 0.21 / 0.36 / 0.53 / 0.82 / 1.62 ms: small operands sit in L2 / MALL, where whole rows are cheap
+PACKED_GATHER_PROBE = True          # dgl.ops.gspmm / update_all(copy_u, sum | mean) of an UNTAGGED [N, 64] operand on such a graph: pack it and let the overflow count decide
 PACKED_GATHER_MAX_OVERFLOW = 0.10    # share of rows with more than 24 non-zeros (read from the dense matrix) above which the dense kernels are used
 
 # ---- a constant 100-column input as [N, 96] + its last four columns along the edge list (ops._edge_tail_operands, csrc/spmm_tail.inc)

@@ -66,7 +66,7 @@ class CsrView(object):
     """An immutable CSR over torch tensors (in-CSR: rows = destination nodes)."""
 
     __slots__ = ("__weakref__", "num_rows", "num_cols", "indptr", "indices", "eids", "_c", "_deg", "_inv_deg", "_plan", "_sm_plan",
-                 "_row_order", "dst_is_src_prefix", "_tile_plan", "_short", "short_hint", "_rows")
+                 "_row_order", "dst_is_src_prefix", "_tile_plan", "_short", "short_hint", "_rows", "_gate")
 
     def __init__(self, num_rows, num_cols, indptr, indices, eids):
         self.num_rows, self.num_cols = int(num_rows), int(num_cols)
@@ -82,6 +82,7 @@ class CsrView(object):
                                 # worth it (a sampled block): True / False, or the average row length (see _short_choice)
         self._row_order = (None, None)  # (row order, kind) computed with the first plan
         self._rows = None  # row id of every stored position (the expanded indptr), built on first use by the permuted g-SDDMM walk
+        self._gate = None  # ops._SlotGate of untagged 64-column operands aggregated over this CSR (ops._gspmm_over_slots)
         self.dst_is_src_prefix = False  # block graphs whose destination nodes are the first source nodes
 
     @property

@@ -294,3 +294,42 @@ def test_the_gate_turns_the_slot_form_off_for_dense_rows(monkeypatch):
     assert ops._packed_rows(be, g._index, csc, sparse_h, sparse_h) is not None and gate.last_fraction < 0.1
     h.add_(1.0)                                                            # an in-place write voids the tag: dense kernels
     assert ops._packed_rows(be, g._index, csc, h, h) is None
+
+
+@pytest.mark.gpu
+def test_gspmm_probes_an_untagged_operand(monkeypatch, oracle):
+    """dgl.ops.gspmm / update_all(copy_u, mean) of a [N, 64] operand nobody tagged (the reference's own modules: F.relu + nn.Dropout): it is
+    packed, aggregated over slots, and the CSR's gate decides from the overflow count whether the next calls do the same."""
+    import dgl.function as fn
+    n = 30000
+    rng = np.random.default_rng(8)
+    src, dst = rng.integers(0, n, 600000), rng.integers(0, n, 600000)
+    g = mg.graph((torch.from_numpy(src), torch.from_numpy(dst)), num_nodes=n).int().to(DEV)
+    csc = g._index.csc()
+    csc._short = {nb: None for nb in (2, 4, 8, 16, 32, 64)}
+    monkeypatch.setattr(mgx_config, "PACKED_GATHER_MIN_NNZ", 0)
+    X = (rng.standard_normal((n, 64)) * (rng.random((n, 64)) < 0.2)).astype(np.float32)
+    h = torch.from_numpy(X).to(DEV).requires_grad_(True)
+    ip, ix, ei = oracle.coo_to_csr(n, dst, src)
+    ref = oracle.spmm(ip, ix, ei, "copy_lhs", "mean", X, None)
+    scale = oracle.spmm(ip, ix, ei, "copy_lhs", "mean", np.abs(X), None)
+    for _ in range(2):
+        g.ndata["h"] = h
+        g.update_all(fn.copy_u("h", "m"), fn.mean("m", "neigh"))
+        assert _lib.lib().mgx_last_spmm_kernel().decode() == "slots"
+        out = g.ndata["neigh"]
+        assert bool((np.abs(out.detach().cpu().numpy() - ref) <= 1e-4 * scale + 1e-30).all())
+        torch.cuda.synchronize()
+    out.sum().backward()                                              # the reversed aggregation of the (dense) gradient is not probed
+    assert h.grad is not None                                         # (it runs on autograd's thread: the kernel name here is still the forward's)
+    assert csc._gate is not None and csc._gate.last_fraction < 0.05 and g._index.csr()._gate is None
+    dense = torch.randn(n, 64, device=DEV)
+    ops.gspmm(g, "copy_lhs", "sum", dense, None)                      # probed once ...
+    assert _lib.lib().mgx_last_spmm_kernel().decode() == "slots"
+    torch.cuda.synchronize()
+    ops.gspmm(g, "copy_lhs", "sum", dense, None)                      # ... the count arrived: dense kernels for the next 64 calls
+    assert _lib.lib().mgx_last_spmm_kernel().decode() != "slots" and csc._gate.last_fraction > 0.9
+    monkeypatch.setattr(mgx_config, "PACKED_GATHER_PROBE", False)
+    csc._gate.dense_until = 0
+    ops.gspmm(g, "copy_lhs", "sum", h.detach(), None)
+    assert _lib.lib().mgx_last_spmm_kernel().decode() != "slots"
