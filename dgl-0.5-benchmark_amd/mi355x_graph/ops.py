@@ -67,14 +67,21 @@ def _gspmm_over_slots(csr, op, reduce_op, X):
         return None
     if csr._gate is None:
         csr._gate = _SlotGate()
-    if not csr._gate.allow():
+    gate = csr._gate
+    gate.calls += 1
+    if gate.calls <= gate.dense_until:
         return None
     if not X.is_contiguous():
         X = X.contiguous()
     if not be.rows_slots_supported(X, csr):
         return None
+    # the decision belongs to THIS operand, so its count is read back here (one host read per probed call): which kernels a call takes
+    # -- and with them the order of additions, i.e. the bits -- depends on the operands and the sequence of calls only, never on timing
     slots, overflow = be.rows_slots_pack(X)
-    csr._gate.watch(overflow, X.shape[0])
+    gate.last_fraction = float(int(overflow)) / max(int(X.shape[0]), 1)
+    if gate.last_fraction > config.PACKED_GATHER_MAX_OVERFLOW:
+        gate.dense_until = gate.calls + 64
+        return None
     out = torch.empty((csr.num_rows, 64), dtype=torch.float32, device=X.device)
     return be.spmm_copy_u_strided(csr, reduce_op, X, out, slots=slots)
 
@@ -600,8 +607,9 @@ def has_structural_zeros(t):
 class _SlotGate(object):
     """Whether a graph's forward aggregations of relu + dropout outputs take the 128-byte-slot form (csrc/spmm_slots.inc).  The form is
     exact at any density -- a row with more than 24 non-zeros is read from the dense matrix -- but only pays while such rows are rare, so
-    every pack leaves its overflow count in pinned host memory (asynchronously: no synchronisation) and the NEXT call looks at the last
-    count that has arrived: above config.PACKED_GATHER_MAX_OVERFLOW of the rows the dense kernels take the following 64 calls."""
+    every producer leaves its overflow count in pinned host memory (asynchronously) and the NEXT call reads it -- waiting for it if it
+    should not have arrived yet, so that the decision is a function of the operands and the call sequence, not of timing: above
+    config.PACKED_GATHER_MAX_OVERFLOW of the rows the dense kernels take the following 64 calls."""
     __slots__ = ("pending", "host", "dense_until", "calls", "last_fraction")
 
     def __init__(self):
@@ -609,7 +617,10 @@ class _SlotGate(object):
 
     def allow(self):
         self.calls += 1
-        if self.pending is not None and self.pending[0].query():
+        if self.pending is not None:
+            # WAIT for the previous producer's count (it was recorded right behind that kernel, at least one aggregation ago: arrived in
+            # practice) rather than ask whether it happens to be there: the decision must not depend on timing, or reruns would differ
+            self.pending[0].synchronize()
             self.last_fraction = float(self.host[0]) / max(self.pending[1], 1)
             self.pending = None
             if self.last_fraction > config.PACKED_GATHER_MAX_OVERFLOW:

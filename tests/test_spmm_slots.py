@@ -271,7 +271,8 @@ def test_the_sage_layer_with_and_without_slots(monkeypatch):
 @pytest.mark.gpu
 def test_the_gate_turns_the_slot_form_off_for_dense_rows(monkeypatch):
     """relu alone leaves half of the entries: nearly every row has more than 24 non-zeros and would be read from the dense matrix anyway --
-    the second call finds the first one's overflow count and takes the dense kernels for the next 64 calls."""
+    the second call reads the first one's overflow count (waiting for it: the decision does not depend on timing) and takes the dense
+    kernels for the next 64 calls."""
     n = 20000
     src = torch.randint(0, n, (400000,))
     dst = torch.randint(0, n, (400000,))
@@ -283,14 +284,12 @@ def test_the_gate_turns_the_slot_form_off_for_dense_rows(monkeypatch):
     h = ops._structural_zeros(torch.relu(torch.randn(n, 64, device=DEV)))
     assert ops.has_structural_zeros(h)
     assert ops._packed_rows(be, g._index, csc, h, h) is not None          # nothing known yet: packed, and watched
-    torch.cuda.synchronize()
-    assert ops._packed_rows(be, g._index, csc, h, h) is None              # the count arrived: ~100 % overflow rows
+    assert ops._packed_rows(be, g._index, csc, h, h) is None              # the count is waited for: ~100 % overflow rows
     gate = g._index._slot_gate
     assert gate.last_fraction > 0.9 and gate.dense_until >= 64
     sparse_h = ops._structural_zeros(h * (torch.rand(n, 64, device=DEV) < 0.4))
     gate.dense_until = 0                                                   # (64 calls later)
     assert ops._packed_rows(be, g._index, csc, sparse_h, sparse_h) is not None
-    torch.cuda.synchronize()
     assert ops._packed_rows(be, g._index, csc, sparse_h, sparse_h) is not None and gate.last_fraction < 0.1
     h.add_(1.0)                                                            # an in-place write voids the tag: dense kernels
     assert ops._packed_rows(be, g._index, csc, h, h) is None
@@ -324,11 +323,11 @@ def test_gspmm_probes_an_untagged_operand(monkeypatch, oracle):
     assert h.grad is not None                                         # (it runs on autograd's thread: the kernel name here is still the forward's)
     assert csc._gate is not None and csc._gate.last_fraction < 0.05 and g._index.csr()._gate is None
     dense = torch.randn(n, 64, device=DEV)
-    ops.gspmm(g, "copy_lhs", "sum", dense, None)                      # probed once ...
-    assert _lib.lib().mgx_last_spmm_kernel().decode() == "slots"
-    torch.cuda.synchronize()
-    ops.gspmm(g, "copy_lhs", "sum", dense, None)                      # ... the count arrived: dense kernels for the next 64 calls
+    first = ops.gspmm(g, "copy_lhs", "sum", dense, None)              # probed: ~100 % of the rows above 24 non-zeros -> the dense kernels,
     assert _lib.lib().mgx_last_spmm_kernel().decode() != "slots" and csc._gate.last_fraction > 0.9
+    calls = csc._gate.calls
+    assert csc._gate.dense_until == calls + 64                        # ... for this call and the next 64 on this CSR
+    assert torch.equal(first, ops.gspmm(g, "copy_lhs", "sum", dense, None))   # same operand, same bits
     monkeypatch.setattr(mgx_config, "PACKED_GATHER_PROBE", False)
     csc._gate.dense_until = 0
     ops.gspmm(g, "copy_lhs", "sum", h.detach(), None)
