@@ -608,9 +608,13 @@ class DistSageMeanCatFn(torch.autograd.Function):
         cat.generation += 1
         comm.mark("owned-source aggregation")
         from . import ops
-        # (a relu + dropout output is gathered as 128-byte slots, as on one GPU: ops._packed_rows)
-        be.spmm_copy_u_strided(plan.loc.csc(), "sum", cat.left, cat.right, dst_scale=plan.inv_deg,
-                               slots=ops._packed_rows(be, plan.loc, plan.loc.csc(), h, cat.left) if hasattr(be, "rows_slots_pack") else None)
+        tail_ops = ops._edge_tail_operands(be, plan.loc.csc(), cat, h) if hasattr(be, "edge_tail_of") else None
+        if tail_ops is not None:  # the constant 100-column input, as on one GPU: [n_own, 96] + its last four columns along the owned edges
+            be.spmm_copy_u_edge_tail(plan.loc.csc(), "sum", tail_ops[0], tail_ops[1], cat.right, dst_scale=plan.inv_deg)
+        else:
+            # (a relu + dropout output is gathered as 128-byte slots, as on one GPU: ops._packed_rows)
+            be.spmm_copy_u_strided(plan.loc.csc(), "sum", cat.left, cat.right, dst_scale=plan.inv_deg,
+                                   slots=ops._packed_rows(be, plan.loc, plan.loc.csc(), h, cat.left) if hasattr(be, "rows_slots_pack") else None)
         if halo_x is not None:
             comm.mark("unpack")
             recv = halo_x.finish()
